@@ -1,0 +1,157 @@
+/*
+ * p2m.h -- C ABI of libp2m_hip.so: the MI355X (gfx950) implementation of the Pose2Mesh
+ * coarse-to-fine Chebyshev graph-convolution hot path.
+ *
+ * The reference (hongsukchoi/Pose2Mesh_RELEASE) is pure PyTorch and has no FFI layer; the
+ * "kernels" below replace the library ops that the reference dispatches to.  Every entry point
+ * cites the reference lines whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C symbols, device pointers + sizes + hipStream_t (passed as void*); the library never
+ *    allocates caller-visible device memory except the immutable per-level graph handle;
+ *  - all matrices fp32 row-major; a "row" is one (sample, vertex) pair, r = b*V + v;
+ *  - return 0 on success, negative p2m_status on error; p2m_last_error_string() has the detail;
+ *    nothing throws across the boundary;
+ *  - thread-safe: no mutable global state besides the thread-local error string;
+ *  - `shift` arguments implement the reference's nearest x2 vertex un-pooling
+ *    (lib/models/meshnet.py:71-78) *virtually*: a tensor stored at V/2 vertices is read as if it
+ *    had V vertices through row index r>>1 (valid because V is even and r = b*V+v).
+ */
+#ifndef P2M_H_
+#define P2M_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  P2M_OK = 0,
+  P2M_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  P2M_ERR_HIP = -2,       /* HIP runtime error (launch, alloc, copy) */
+  P2M_ERR_NOMEM = -3
+} p2m_status;
+
+typedef struct p2m_graph* p2m_graph_t;
+
+/* Thread-local description of the last error returned on this thread. */
+const char* p2m_last_error_string(void);
+/* Library version / build info (e.g. "p2m-hip 0.1 gfx950"). */
+const char* p2m_version(void);
+
+/* ---- graph handle: one per coarsening level ------------------------------------------------
+ * Replaces sparse_python_to_torch (lib/graph_utils.py:98-109) and the per-forward
+ * `self.graph_L[i].cuda()` upload (lib/models/meshnet.py:81).  Input: host CSR of the rescaled
+ * Laplacian L (fp32, V x V, symmetric).  The handle bakes, on the current device, the merged
+ * CSR of L and L2 = 2*L*L - I (double accumulation on the host, rounded once to fp32) so the
+ * K=3 Chebyshev recurrence T1 = L x, T2 = 2 L T1 - x (lib/models/backbones/cheby_graph_conv.py:25,28)
+ * becomes ONE gather pass  T1 = L x, T2 = L2 x.                                               */
+int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val,
+                     int32_t V, int32_t nnz, p2m_graph_t* out);
+int p2m_graph_destroy(p2m_graph_t g);
+/* info[0]=V, info[1]=nnz(L), info[2]=nnz(merged L|L2), info[3]=max merged row length */
+int p2m_graph_info(p2m_graph_t g, int32_t info[4]);
+
+/* ---- Chebyshev basis (sparse stage, HBM-bound) ----------------------------------------------
+ * cheby_graph_conv.py:16-34 without the permute/cat/permute shuffles.
+ * X: (B, V>>in_shift, F)   T1, T2: (B, V, F).   T0 = X is never rewritten.
+ * Algorithmic HBM bytes per call: 4*B*V*F*(1/(1<<in_shift) + 2).                               */
+int p2m_cheb_basis_fwd(p2m_graph_t g, const float* X, float* T1, float* T2,
+                       int32_t B, int32_t F, int32_t in_shift, void* stream);
+
+/* Backward of the basis stage (autograd of cheby_graph_conv.py:25-28; L symmetric,
+ * asserted at lib/coarsening.py:23):  dX = d0 + L d1 + L2 d2  (+ resid, same shape as d0).
+ * d0,d1,d2,resid: (B, V, F).  dX: (B, V>>out_shift, F); with out_shift=1 the two children of a
+ * coarse vertex are summed (backward of nn.Upsample nearest, meshnet.py:74).                  */
+int p2m_cheb_basis_bwd(p2m_graph_t g, const float* d0, const float* d1, const float* d2,
+                       const float* resid, float* dX,
+                       int32_t B, int32_t F, int32_t out_shift, void* stream);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * nn.Linear(Fin*K, Fout).weight is [Fout][fin*K + k] (cheby_graph_conv.py:32-37).  Packs it into
+ *   Wt [k*Fin + fin][Fout]   (B operand of the forward contraction, K-major)
+ *   W2 [Fout][k*Fin + fin]   (B operand of dZ = g W; may be NULL)
+ * K=1 gives a plain transpose (used for fc, meshnet.py:36-37).                                */
+int p2m_weight_pack(const float* W, float* Wt, float* W2, int32_t Fout, int32_t Fin, int32_t K,
+                    void* stream);
+/* Sums `nchunks` partial gradients P[chunk][k*Fin+fin][Fout], Pdb[chunk][Fout] produced by
+ * p2m_gemm_tn and writes dW in nn.Linear layout [Fout][fin*K+k] and db[Fout].
+ * accumulate!=0 adds into dW/db instead of overwriting.                                        */
+int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
+                           int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, void* stream);
+
+/* ---- dense contraction (FP32 MFMA, v_mfma_f32_32x32x2_f32) ---------------------------------
+ * C[r, n] = sum_p sum_k A_p[r (>> a0_shift if p==0), k] * Bm[p*Ka + k, n]  + bias[n]
+ * A_p: nplanesA row-major [M, Ka] matrices (the Chebyshev basis planes X|T1|T2, or one plane);
+ * Bm: [nplanesA*Ka, N] row-major; C is split in nplanesC column planes of width Nc (N = nplanesC*Nc),
+ * C_q: [M, Nc].  Replaces `cl(x)` (cheby_graph_conv.py:37), `self.fc` (meshnet.py:105) and the
+ * autograd dZ = g W.  If stats != NULL it receives per-row-tile BatchNorm partials
+ * stats[tile][0][n] = sum_r y, stats[tile][1][n] = sum_r (y - tile_mean)^2, tile = 128 rows
+ * (cheby_graph_conv.py:39 batch statistics; fake vertices included).
+ * Shapes with Ka%32!=0 or N%32!=0 take a scalar (VALU) path.                                    */
+int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                    int32_t a0_shift, const float* Bm, const float* bias,
+                    float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc,
+                    int64_t M, float* stats, void* stream);
+/* rows per BatchNorm partial tile and the number of tiles for M rows */
+int32_t p2m_stats_tile_rows(void);
+
+/* Weight-gradient contraction: P[chunk][p*Ka + k][n] = sum_{r in chunk} A_p[r][k] * G[r][n],
+ * Pdb[chunk][n] = sum_{r in chunk} G[r][n];  chunk c covers rows [c*chunk_rows, (c+1)*chunk_rows).
+ * (autograd of cheby_graph_conv.py:37 / meshnet.py:105.)                                       */
+int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                int32_t a0_shift, const float* G, int32_t N, int64_t M, int64_t chunk_rows,
+                float* P, float* Pdb, void* stream);
+
+/* ---- BatchNorm1d over B*V rows + ReLU + residual (cheby_graph_conv.py:39, meshnet.py:100,108-115)
+ * finalize: reduces the GEMM's partials to batch mean / biased var, writes
+ *   mean[N], invstd[N], scale = gamma*invstd, shift = beta - mean*scale and updates
+ *   running_mean/var (momentum, unbiased var) exactly like nn.BatchNorm1d in train().         */
+int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* mean, float* invstd, float* scale, float* shift, int32_t N, void* stream);
+/* eval(): scale/shift/invstd from the running statistics. */
+int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                       float* shift, int32_t N, void* stream);
+/* x[r,f] = act(y[r,f]*scale[f] + shift[f]) + lerp_F(resid[r>>res_shift, 0..Fres))[f]
+ * act = ReLU if relu!=0; scale/shift may be NULL (identity); resid may be NULL.
+ * lerp_F is F.interpolate(mode='linear', align_corners=False) along the FEATURE axis
+ * (meshnet.py:109,114).                                                                        */
+int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
+                   const float* resid, int32_t Fres, int32_t res_shift,
+                   float* x, int64_t M, int32_t F, void* stream);
+/* backward through ReLU + BatchNorm (train: batch statistics; eval: running statistics).
+ *   go = gx * (y*scale+shift > 0 or !relu)
+ *   reduce:   part[blk][0][f] = sum go, part[blk][1][f] = sum go * yhat       (nblk = p2m_bn_bwd_blocks(M,F))
+ *   finalize: dgamma, dbeta (accumulate!=0 adds), coef[0][f]=dbeta/M, coef[1][f]=dgamma/M
+ *   apply:    gy = gamma*invstd*(go - coef0 - yhat*coef1)   (training)   |   gamma*invstd*go (eval, coef NULL) */
+int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F);
+int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, int32_t relu, float* part,
+                      int64_t M, int32_t F, void* stream);
+int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
+                        float* coef, int32_t accumulate, int32_t F, void* stream);
+int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, const float* gamma, const float* coef,
+                     int32_t relu, float* gy, int64_t M, int32_t F, void* stream);
+
+/* out[p, f] = in[2p, f] + in[2p+1, f]   (backward of the x2 nearest un-pool, meshnet.py:74) */
+int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* stream);
+/* dst[r, i] += sum_j w(j,i) g[r, j]: transpose of the feature-axis resize (meshnet.py:109,114);
+ * g: [M, F], dst: [M, Fres].                                                                   */
+int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream);
+
+/* ---- composite: one Chebyshev graph convolution (cheby_graph_conv.py:5-40, K=3) ------------
+ * Y = [X|L X|L2 X] Wt + bias, BatchNorm partials in `stats` (may be NULL).  T1/T2 are caller
+ * workspaces of B*V*Fin floats each and hold the basis planes afterwards (saved for backward). */
+int p2m_chebconv_fwd(p2m_graph_t g, const float* X, const float* Wt, const float* bias,
+                     float* T1, float* T2, float* Y, float* stats,
+                     int32_t B, int32_t Fin, int32_t Fout, int32_t in_shift, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2M_H_ */

@@ -1,0 +1,93 @@
+"""TEST INFRASTRUCTURE ONLY -- loader for the *real* reference implementation.
+
+Imports hongsukchoi/Pose2Mesh_RELEASE from /root/reference (read-only) so that
+ (a) the CPU restatement in oracle/meshnet_oracle.py / oracle/coarsen_oracle.py can be
+     validated against the real code, and
+ (b) tests/golden/make_golden.py can generate the committed fixtures.
+
+/root/reference does NOT exist on the GPU box; nothing under `-m gpu`, smoke() or bench.py
+calls this module.  Three shims are needed:
+  1. fake `core.config` exposing the 3 cfg keys the model files read
+     (lib/models/meshnet.py:21, lib/models/pose2mesh_net.py:13, lib/models/posenet.py:89);
+     the real lib/core/config.py needs easydict and mkdirs under the read-only tree.
+  2. empty `cv2` module (lib/funcs_utils.py:6 imports it; never used on this path).
+  3. Tensor.cuda -> identity while the reference forward runs (lib/models/meshnet.py:81
+     hard-codes .cuda()).
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("P2M_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "lib", "models"))
+
+
+class _Cfg:  # attribute bag
+    pass
+
+
+_loaded = {}
+
+
+def load(target_joint_set: str = "human36"):
+    """Returns a namespace with the reference modules: coarsening, graph_utils, meshnet,
+    pose2mesh_net, posenet, cheby (graph_conv_cheby) and the fake cfg."""
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    if "ns" in _loaded:
+        _loaded["ns"].cfg.DATASET.target_joint_set = target_joint_set
+        return _loaded["ns"]
+    lib = os.path.join(REF_ROOT, "lib")
+    if lib not in sys.path:
+        sys.path.insert(0, lib)
+    cfg = _Cfg()
+    cfg.DATASET = _Cfg()
+    cfg.DATASET.target_joint_set = target_joint_set
+    cfg.MODEL = _Cfg()
+    cfg.MODEL.posenet_pretrained = False
+    cfg.MODEL.posenet_path = ""
+    core = types.ModuleType("core")
+    core.__path__ = []
+    core_config = types.ModuleType("core.config")
+    core_config.cfg = cfg
+    core.config = core_config
+    sys.modules.setdefault("core", core)
+    sys.modules.setdefault("core.config", core_config)
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with contextlib.redirect_stdout(io.StringIO()):
+            import coarsening  # noqa
+            import graph_utils  # noqa
+            from models import meshnet, pose2mesh_net, posenet  # noqa
+            from models.backbones import cheby_graph_conv  # noqa
+    ns = types.SimpleNamespace(coarsening=coarsening, graph_utils=graph_utils, meshnet=meshnet,
+                               pose2mesh_net=pose2mesh_net, posenet=posenet,
+                               cheby=cheby_graph_conv, cfg=cfg)
+    _loaded["ns"] = ns
+    return ns
+
+
+@contextlib.contextmanager
+def cpu_cuda_shim():
+    """Make Tensor.cuda() a no-op so the reference forward (meshnet.py:81) runs on CPU."""
+    import torch
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda = orig
+
+
+def build_coarse_graphs(faces, joint_num, skeleton, flip_pairs, levels):
+    ns = load()
+    with contextlib.redirect_stdout(io.StringIO()):
+        return ns.graph_utils.build_coarse_graphs(faces, joint_num, skeleton, flip_pairs, levels=levels)

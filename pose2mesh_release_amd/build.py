@@ -1,0 +1,67 @@
+"""Builds the two native libraries of the package in-tree (pose2mesh_release_amd/lib/):
+
+  libp2m_hip.so   HIP kernels + C ABI (include/p2m.h), cross-compiled for gfx950 with hipcc
+  libp2m_host.so  CPU-only helpers for graph preparation (g++)
+
+`python -m pose2mesh_release_amd.build` or __graft_entry__.build() runs this; a rebuild happens
+only when a source is newer than the library.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+HIP_SOURCES = ["capi.hip", "basis.hip", "gemm.hip", "bn.hip"]
+HIP_HEADERS = ["p2m_common.h", os.path.join("..", "..", "include", "p2m.h")]
+HIP_LIB = os.path.join(LIBDIR, "libp2m_hip.so")
+HOST_LIB = os.path.join(LIBDIR, "libp2m_host.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
+    if not force and not _stale(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    src = os.path.join(CSRC, "p2m_host.cpp")
+    if not force and not _stale(HOST_LIB, [src]):
+        return HOST_LIB
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", HOST_LIB, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

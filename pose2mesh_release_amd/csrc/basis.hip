@@ -1,0 +1,214 @@
+// Sparse (Chebyshev-basis) stage of the Pose2Mesh GCN on gfx950 -- the HBM-bound part.
+//
+// Reference arithmetic: lib/models/backbones/cheby_graph_conv.py:16-34
+//     x1 = L x0 ;  x2 = 2 L x1 - x0      (two cuSPARSE SpMMs + 4 layout shuffles per conv)
+// Here: activations stay (B, V, F) row-major (F contiguous); per level the merged CSR of L and
+// L2 = 2 L L - I is baked once (p2m_graph_create), and ONE gather pass produces both planes:
+//     T1[r] = sum_j a_j x[col_j],  T2[r] = sum_j b_j x[col_j].
+// Each row group of F/4 lanes streams whole feature rows as float4 (a wave reads 1 KiB
+// contiguous per gather when F=256, 2 rows of 512 B when F=128): coalesced, every neighbour row
+// is re-used from L2 (one sample's level is <= 6 MB).  A block owns a contiguous tile of rows of
+// ONE sample, and block ids are swizzled so that consecutive tiles of a sample share an XCD (L2).
+// Algorithmic HBM bytes: read X once, write T1 and T2 once.
+#include "p2m_common.h"
+
+namespace p2m {
+
+constexpr int ROWS_PER_BLOCK = 64;
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
+  // observed dispatch: block b runs on XCD b % 8 -> give each XCD a contiguous range of logical ids
+  return (nb & 7) == 0 ? (bid & 7) * (nb >> 3) + (bid >> 3) : bid;
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
+  acc.x = fmaf(s, x.x, acc.x); acc.y = fmaf(s, x.y, acc.y);
+  acc.z = fmaf(s, x.z, acc.z); acc.w = fmaf(s, x.w, acc.w);
+}
+
+template <int LPR>  // lanes per row, F = 4*LPR
+__global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restrict__ X, float* __restrict__ T1,
+                                                    float* __restrict__ T2, int in_shift, int tiles_per_sample) {
+  constexpr int F = LPR * 4;
+  constexpr int RP = 256 / LPR;  // rows per pass
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = lid / tiles_per_sample;
+  const int tile = lid - b * tiles_per_sample;
+  const int t = threadIdx.x;
+  const int rloc = t / LPR, f4 = (t % LPR) * 4;
+  const float* Xb = X + (long)b * (g.V >> in_shift) * F + f4;
+  const long obase = (long)b * g.V * F + f4;
+  int row_end = (tile + 1) * ROWS_PER_BLOCK;
+  if (row_end > g.V) row_end = g.V;
+  for (int row = tile * ROWS_PER_BLOCK + rloc; row < row_end; row += RP) {
+    const int s = g.rowptr[row], e = g.rowptr[row + 1];
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    int j = s;
+    for (; j + 4 <= e; j += 4) {
+      int c0 = g.col[j], c1 = g.col[j + 1], c2 = g.col[j + 2], c3 = g.col[j + 3];
+      float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(c0 >> in_shift) * F);
+      float4 x1 = *reinterpret_cast<const float4*>(Xb + (long)(c1 >> in_shift) * F);
+      float4 x2 = *reinterpret_cast<const float4*>(Xb + (long)(c2 >> in_shift) * F);
+      float4 x3 = *reinterpret_cast<const float4*>(Xb + (long)(c3 >> in_shift) * F);
+      fma4(t1, g.a[j], x0); fma4(t2, g.b[j], x0);
+      fma4(t1, g.a[j + 1], x1); fma4(t2, g.b[j + 1], x1);
+      fma4(t1, g.a[j + 2], x2); fma4(t2, g.b[j + 2], x2);
+      fma4(t1, g.a[j + 3], x3); fma4(t2, g.b[j + 3], x3);
+    }
+    for (; j < e; j++) {
+      float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(g.col[j] >> in_shift) * F);
+      fma4(t1, g.a[j], x0); fma4(t2, g.b[j], x0);
+    }
+    *reinterpret_cast<float4*>(T1 + obase + (long)row * F) = t1;
+    *reinterpret_cast<float4*>(T2 + obase + (long)row * F) = t2;
+  }
+}
+
+// any F (first conv F=5): one thread per (b, row, f)
+__global__ void k_basis_fwd_generic(Graph g, const float* __restrict__ X, float* __restrict__ T1,
+                                    float* __restrict__ T2, int B, int F, int in_shift) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)B * g.V * F;
+  if (idx >= tot) return;
+  int f = (int)(idx % F);
+  long rv = idx / F;
+  int row = (int)(rv % g.V);
+  int b = (int)(rv / g.V);
+  const float* Xb = X + (long)b * (g.V >> in_shift) * F + f;
+  float t1 = 0.f, t2 = 0.f;
+  for (int j = g.rowptr[row]; j < g.rowptr[row + 1]; j++) {
+    float x = Xb[(long)(g.col[j] >> in_shift) * F];
+    t1 = fmaf(g.a[j], x, t1);
+    t2 = fmaf(g.b[j], x, t2);
+  }
+  T1[idx] = t1;
+  T2[idx] = t2;
+}
+
+// dX[p] = sum_{children r of p} ( d0[r] + resid[r] + sum_j a_j d1[col_j] + b_j d2[col_j] )
+template <int LPR>
+__global__ __launch_bounds__(256) void k_basis_bwd(Graph g, const float* __restrict__ d0, const float* __restrict__ d1,
+                                                    const float* __restrict__ d2, const float* __restrict__ resid,
+                                                    float* __restrict__ dX, int out_shift, int tiles_per_sample) {
+  constexpr int F = LPR * 4;
+  constexpr int RP = 256 / LPR;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int b = lid / tiles_per_sample;
+  const int tile = lid - b * tiles_per_sample;
+  const int t = threadIdx.x;
+  const int rloc = t / LPR, f4 = (t % LPR) * 4;
+  const long ibase = (long)b * g.V * F + f4;
+  const int Vout = g.V >> out_shift;
+  const long obase = (long)b * Vout * F + f4;
+  const int nchild = 1 << out_shift;
+  int p_end = (tile + 1) * ROWS_PER_BLOCK;
+  if (p_end > Vout) p_end = Vout;
+  for (int p = tile * ROWS_PER_BLOCK + rloc; p < p_end; p += RP) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ch = 0; ch < nchild; ch++) {
+      const int row = (p << out_shift) + ch;
+      float4 v = *reinterpret_cast<const float4*>(d0 + ibase + (long)row * F);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      if (resid != nullptr) {
+        float4 q = *reinterpret_cast<const float4*>(resid + ibase + (long)row * F);
+        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+      }
+      const int s = g.rowptr[row], e = g.rowptr[row + 1];
+      int j = s;
+      for (; j + 2 <= e; j += 2) {
+        int c0 = g.col[j], c1 = g.col[j + 1];
+        float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
+        float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
+        float4 u1 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c1 * F);
+        float4 w1 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c1 * F);
+        fma4(acc, g.a[j], u0); fma4(acc, g.b[j], w0);
+        fma4(acc, g.a[j + 1], u1); fma4(acc, g.b[j + 1], w1);
+      }
+      for (; j < e; j++) {
+        int c0 = g.col[j];
+        float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
+        float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
+        fma4(acc, g.a[j], u0); fma4(acc, g.b[j], w0);
+      }
+    }
+    *reinterpret_cast<float4*>(dX + obase + (long)p * F) = acc;
+  }
+}
+
+__global__ void k_basis_bwd_generic(Graph g, const float* __restrict__ d0, const float* __restrict__ d1,
+                                    const float* __restrict__ d2, const float* __restrict__ resid,
+                                    float* __restrict__ dX, int B, int F, int out_shift) {
+  const int Vout = g.V >> out_shift;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)B * Vout * F;
+  if (idx >= tot) return;
+  int f = (int)(idx % F);
+  long rv = idx / F;
+  int p = (int)(rv % Vout);
+  int b = (int)(rv / Vout);
+  const long ibase = (long)b * g.V * F + f;
+  float acc = 0.f;
+  for (int ch = 0; ch < (1 << out_shift); ch++) {
+    int row = (p << out_shift) + ch;
+    acc += d0[ibase + (long)row * F];
+    if (resid) acc += resid[ibase + (long)row * F];
+    for (int j = g.rowptr[row]; j < g.rowptr[row + 1]; j++) {
+      long o = ibase + (long)g.col[j] * F;
+      acc = fmaf(g.a[j], d1[o], acc);
+      acc = fmaf(g.b[j], d2[o], acc);
+    }
+  }
+  dX[idx] = acc;
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+extern "C" int p2m_cheb_basis_fwd(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
+                                  int32_t in_shift, void* stream) {
+  P2M_CHECK_ARG(gh && X && T1 && T2 && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(in_shift == 0 || in_shift == 1, "in_shift must be 0 or 1");
+  if (B <= 0) return P2M_OK;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  P2M_CHECK_ARG(in_shift == 0 || (g.V % 2 == 0), "virtual un-pool needs an even vertex count");
+  hipStream_t s = (hipStream_t)stream;
+  const int tps = cdiv(g.V, ROWS_PER_BLOCK);
+  const int grid = B * tps;
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_basis_fwd<8>,  dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
+    case 64:  hipLaunchKernelGGL(k_basis_fwd<16>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
+    case 128: hipLaunchKernelGGL(k_basis_fwd<32>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
+    case 256: hipLaunchKernelGGL(k_basis_fwd<64>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
+    default: {
+      long tot = (long)B * g.V * F;
+      hipLaunchKernelGGL(k_basis_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, X, T1, T2, B, F, in_shift);
+    }
+  }
+  return check_launch("cheb_basis_fwd");
+}
+
+extern "C" int p2m_cheb_basis_bwd(p2m_graph_t gh, const float* d0, const float* d1, const float* d2,
+                                  const float* resid, float* dX, int32_t B, int32_t F, int32_t out_shift,
+                                  void* stream) {
+  P2M_CHECK_ARG(gh && d0 && d1 && d2 && dX && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(out_shift == 0 || out_shift == 1, "out_shift must be 0 or 1");
+  if (B <= 0) return P2M_OK;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  P2M_CHECK_ARG(out_shift == 0 || (g.V % 2 == 0), "pair-sum needs an even vertex count");
+  hipStream_t s = (hipStream_t)stream;
+  const int Vout = g.V >> out_shift;
+  const int tps = cdiv(Vout, ROWS_PER_BLOCK);
+  const int grid = B * tps;
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_basis_bwd<8>,  dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
+    case 64:  hipLaunchKernelGGL(k_basis_bwd<16>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
+    case 128: hipLaunchKernelGGL(k_basis_bwd<32>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
+    case 256: hipLaunchKernelGGL(k_basis_bwd<64>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
+    default: {
+      long tot = (long)B * Vout * F;
+      hipLaunchKernelGGL(k_basis_bwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, F, out_shift);
+    }
+  }
+  return check_launch("cheb_basis_bwd");
+}

@@ -1,0 +1,384 @@
+// BatchNorm1d-over-(B*V)-rows, ReLU, feature-axis residual resize and un-pool helpers (gfx950).
+//
+// Reference arithmetic: nn.BatchNorm1d inside graph_conv_cheby (lib/models/backbones/cheby_graph_conv.py:39,
+// statistics over ALL B*V rows, fake vertices included), F.relu (lib/models/meshnet.py:100),
+// F.interpolate(mode='linear') along the feature axis + residual add (meshnet.py:109-110,114-115),
+// nn.Upsample(scale_factor=2) (meshnet.py:71-78; here virtual: consumers index r>>1).
+// All of these are streaming HBM-bound passes: float4 per lane, one row group of F/4 lanes per row.
+#include "p2m_common.h"
+
+namespace p2m {
+
+// ---- statistics finalize --------------------------------------------------------------------
+// stats[tile][0][n] = sum, stats[tile][1][n] = sum (y - tile_mean)^2.  sum y^2 over a tile is
+// M2 + sum^2/n; tile-centred partials make the double-precision E[y^2]-E[y]^2 benign.
+constexpr int FIN_CG = 8;     // columns per block
+constexpr int FIN_RG = 128;   // tile groups per block
+__global__ __launch_bounds__(FIN_CG * FIN_RG) void k_bn_finalize(const float* __restrict__ stats, int ntiles, long M,
+                                                                  int tile_rows, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* running_mean,
+                                                                  float* running_var, float momentum, float eps,
+                                                                  float* mean_o, float* invstd_o, float* scale_o,
+                                                                  float* shift_o, int N) {
+  __shared__ double s1[FIN_RG][FIN_CG];
+  __shared__ double s2[FIN_RG][FIN_CG];
+  const int cg = threadIdx.x % FIN_CG, rg = threadIdx.x / FIN_CG;
+  const int n = blockIdx.x * FIN_CG + cg;
+  double a1 = 0.0, a2 = 0.0;
+  if (n < N) {
+    for (int i = rg; i < ntiles; i += FIN_RG) {
+      long left = M - (long)i * tile_rows;
+      double cnt = (double)(left < tile_rows ? left : tile_rows);
+      double s = (double)stats[(long)i * 2 * N + n];
+      double m2 = (double)stats[(long)i * 2 * N + N + n];
+      a1 += s;
+      a2 += m2 + s * s / cnt;
+    }
+  }
+  s1[rg][cg] = a1;
+  s2[rg][cg] = a2;
+  __syncthreads();
+  for (int st = FIN_RG / 2; st > 0; st >>= 1) {
+    if (rg < st) {
+      s1[rg][cg] += s1[rg + st][cg];
+      s2[rg][cg] += s2[rg + st][cg];
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && n < N) {
+    double mean = s1[0][cg] / (double)M;
+    double var = s2[0][cg] / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float meanf = (float)mean;
+    mean_o[n] = meanf;
+    invstd_o[n] = invstd;
+    float sc = gamma[n] * invstd;
+    scale_o[n] = sc;
+    shift_o[n] = beta[n] - meanf * sc;
+    if (running_mean != nullptr) {
+      double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+      running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * meanf;
+      running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float invstd = 1.0f / sqrtf(rv[n] + eps);
+  float sc = gamma[n] * invstd;
+  mean_o[n] = rm[n];
+  invstd_o[n] = invstd;
+  scale_o[n] = sc;
+  shift_o[n] = beta[n] - rm[n] * sc;
+}
+
+// ---- forward activation ---------------------------------------------------------------------
+__device__ __forceinline__ float lerp_feat(const float* __restrict__ row, int Fres, int F, int j) {
+  // F.interpolate(mode='linear', align_corners=False) along an axis of length Fres -> F
+  float src = ((float)j + 0.5f) * ((float)Fres / (float)F) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)src;
+  int i1 = i0 + 1 < Fres ? i0 + 1 : Fres - 1;
+  float w = src - (float)i0;
+  return row[i0] * (1.f - w) + row[i1] * w;
+}
+
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int relu,
+                                                     const float* __restrict__ resid, int Fres, int res_shift,
+                                                     float* __restrict__ x, long M, int F) {
+  const int F4 = F >> 2;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = M * F4;
+  if (idx >= tot) return;
+  long r = idx / F4;
+  int f = (int)(idx - r * F4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(y + r * F + f);
+  if (scale != nullptr) {
+    float4 sc = *reinterpret_cast<const float4*>(scale + f);
+    float4 sh = *reinterpret_cast<const float4*>(shift + f);
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+  }
+  if (relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  if (resid != nullptr) {
+    const float* rr = resid + (r >> res_shift) * Fres;
+    if (Fres == F) {
+      float4 q = *reinterpret_cast<const float4*>(rr + f);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    } else {
+      v.x += lerp_feat(rr, Fres, F, f);
+      v.y += lerp_feat(rr, Fres, F, f + 1);
+      v.z += lerp_feat(rr, Fres, F, f + 2);
+      v.w += lerp_feat(rr, Fres, F, f + 3);
+    }
+  }
+  *reinterpret_cast<float4*>(x + r * F + f) = v;
+}
+
+// scalar version for F % 4 != 0
+__global__ void k_bn_act_fwd_generic(const float* __restrict__ y, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, int relu, const float* __restrict__ resid,
+                                     int Fres, int res_shift, float* __restrict__ x, long M, int F) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * F) return;
+  long r = idx / F;
+  int f = (int)(idx - r * F);
+  float v = y[idx];
+  if (scale) v = fmaf(v, scale[f], shift[f]);
+  if (relu) v = fmaxf(v, 0.f);
+  if (resid) v += lerp_feat(resid + (r >> res_shift) * Fres, Fres, F, f);
+  x[idx] = v;
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+constexpr int BWD_ROWS_PER_BLOCK = 512;
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ gx, const float* __restrict__ y,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int relu, float* __restrict__ part, long M) {
+  constexpr int F = LPR * 4;
+  constexpr int RP = 256 / LPR;
+  __shared__ float red[2][RP][F];
+  const int t = threadIdx.x;
+  const int rloc = t / LPR, f = (t % LPR) * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + f);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + f);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + f);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + f);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
+  long r1 = r0 + BWD_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  for (long r = r0 + rloc; r < r1; r += RP) {
+    float4 g = *reinterpret_cast<const float4*>(gx + r * F + f);
+    float4 v = *reinterpret_cast<const float4*>(y + r * F + f);
+    if (relu) {
+      if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
+      if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
+      if (fmaf(v.z, sc.z, sh.z) <= 0.f) g.z = 0.f;
+      if (fmaf(v.w, sc.w, sh.w) <= 0.f) g.w = 0.f;
+    }
+    s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+    s1.x = fmaf(g.x, (v.x - mu.x) * is.x, s1.x);
+    s1.y = fmaf(g.y, (v.y - mu.y) * is.y, s1.y);
+    s1.z = fmaf(g.z, (v.z - mu.z) * is.z, s1.z);
+    s1.w = fmaf(g.w, (v.w - mu.w) * is.w, s1.w);
+  }
+  *reinterpret_cast<float4*>(&red[0][rloc][f]) = s0;
+  *reinterpret_cast<float4*>(&red[1][rloc][f]) = s1;
+  __syncthreads();
+  for (int o = t; o < 2 * F; o += 256) {
+    const int which = o / F, c = o - which * F;
+    float s = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < RP; q++) s += red[which][q][c];
+    part[(long)blockIdx.x * 2 * F + o] = s;
+  }
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long M, float* dgamma, float* dbeta,
+                                  float* coef, int accumulate, int F) {
+  // one wave per column: lanes stride over blocks
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = lane; i < nblk; i += 64) {
+    a0 += (double)part[(long)i * 2 * F + c];
+    a1 += (double)part[(long)i * 2 * F + F + c];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o);
+    a1 += __shfl_xor(a1, o);
+  }
+  if (lane == 0) {
+    float db = (float)a0, dg = (float)a1;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    if (coef) {
+      coef[c] = (float)(a0 / (double)M);
+      coef[F + c] = (float)(a1 / (double)M);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ gx, const float* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                       int relu, float* __restrict__ gy, long M, int F) {
+  const int F4 = F >> 2;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * F4) return;
+  long r = idx / F4;
+  int f = (int)(idx - r * F4) * 4;
+  float g[4], v[4];
+  *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gx + r * F + f);
+  *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(y + r * F + f);
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float go = g[i];
+    if (relu && fmaf(v[i], scale[f + i], shift[f + i]) <= 0.f) go = 0.f;
+    float k = gamma[f + i] * invstd[f + i];
+    if (coef != nullptr) {
+      float yhat = (v[i] - mean[f + i]) * invstd[f + i];
+      o[i] = k * (go - coef[f + i] - yhat * coef[F + f + i]);
+    } else {
+      o[i] = k * go;
+    }
+  }
+  *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+}
+
+__global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F) {
+  const int F4 = F >> 2;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mout * F4) return;
+  long p = idx / F4;
+  int f = (int)(idx - p * F4) * 4;
+  float4 a = *reinterpret_cast<const float4*>(in + (2 * p) * F + f);
+  float4 b = *reinterpret_cast<const float4*>(in + (2 * p + 1) * F + f);
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  *reinterpret_cast<float4*>(out + p * F + f) = a;
+}
+
+// dst[r][i] += sum_j w(j, i) * g[r][j]  -- deterministic gather form of the resize transpose
+__global__ void k_lerp_bwd_add(const float* __restrict__ g, float* __restrict__ dst, long M, int F, int Fres) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * Fres) return;
+  long r = idx / Fres;
+  int i = (int)(idx - r * Fres);
+  const float* gr = g + r * F;
+  float ratio = (float)Fres / (float)F;
+  // candidate outputs j whose i0 or i1 can be i:  src(j) in (i-1, i+1)
+  int jlo = (int)floorf(((float)i - 1.f + 0.5f) / ratio - 0.5f) - 1;
+  int jhi = (int)ceilf(((float)i + 1.f + 0.5f) / ratio - 0.5f) + 1;
+  if (jlo < 0) jlo = 0;
+  if (jhi > F - 1) jhi = F - 1;
+  float acc = 0.f;
+  for (int j = jlo; j <= jhi; j++) {
+    float src = ((float)j + 0.5f) * ratio - 0.5f;
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)src;
+    int i1 = i0 + 1 < Fres ? i0 + 1 : Fres - 1;
+    float w = src - (float)i0;
+    if (i0 == i) acc = fmaf(1.f - w, gr[j], acc);
+    if (i1 == i) acc = fmaf(w, gr[j], acc);
+  }
+  dst[idx] += acc;
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                               float* invstd, float* scale, float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift && N > 0 && M > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+  const int tile_rows = p2m_stats_tile_rows();
+  P2M_CHECK_ARG(ntiles == cdiv(M, tile_rows), "ntiles does not match M");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, stats, ntiles,
+                     (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                     shift, N);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                                  float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(gamma && beta && running_mean && running_var && mean && invstd && scale && shift && N > 0,
+                "null pointer or empty shape");
+  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, mean, invstd, scale, shift, N);
+  return check_launch("bn_eval_coeffs");
+}
+
+extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
+                              const float* resid, int32_t Fres, int32_t res_shift, float* x, int64_t M, int32_t F,
+                              void* stream) {
+  P2M_CHECK_ARG(y && x && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale/shift must both be given or both NULL");
+  P2M_CHECK_ARG(resid == nullptr || Fres > 0, "Fres must be positive with a residual");
+  P2M_CHECK_ARG(res_shift == 0 || res_shift == 1, "res_shift must be 0 or 1");
+  if (M <= 0) return P2M_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (F % 4 == 0 && (resid == nullptr || Fres != F || Fres % 4 == 0)) {
+    long tot = M * (F / 4);
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
+                       res_shift, x, (long)M, F);
+  } else {
+    long tot = M * F;
+    hipLaunchKernelGGL(k_bn_act_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid,
+                       Fres, res_shift, x, (long)M, F);
+  }
+  return check_launch("bn_act_fwd");
+}
+
+extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
+  (void)F;
+  return cdiv(M, BWD_ROWS_PER_BLOCK);
+}
+
+extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, int32_t relu, float* part, int64_t M,
+                                 int32_t F, void* stream) {
+  P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && M > 0, "null pointer or empty shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = p2m_bn_bwd_blocks(M, F);
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
+    default:
+      set_error("p2m_bn_bwd_reduce: unsupported feature width %d (need 32/64/128/256)", F);
+      return P2M_ERR_INVALID;
+  }
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
+                                   float* coef, int32_t accumulate, int32_t F, void* stream) {
+  P2M_CHECK_ARG(part && nblk > 0 && M > 0 && F > 0, "null pointer or empty shape");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(64), 0, (hipStream_t)stream, part, nblk, (long)M, dgamma, dbeta,
+                     coef, accumulate, F);
+  return check_launch("bn_bwd_finalize");
+}
+
+extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* gamma, const float* coef,
+                                int32_t relu, float* gy, int64_t M, int32_t F, void* stream) {
+  P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(F % 4 == 0, "feature width must be a multiple of 4");
+  long tot = M * (F / 4);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, gx, y, scale, shift, mean,
+                     invstd, gamma, coef, relu, gy, (long)M, F);
+  return check_launch("bn_bwd_apply");
+}
+
+extern "C" int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* stream) {
+  P2M_CHECK_ARG(in && out && F > 0 && F % 4 == 0, "null pointer or feature width not a multiple of 4");
+  if (Mout <= 0) return P2M_OK;
+  long tot = Mout * (F / 4);
+  hipLaunchKernelGGL(k_pair_sum, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long)Mout, F);
+  return check_launch("pair_sum");
+}
+
+extern "C" int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream) {
+  P2M_CHECK_ARG(g && dst && F > 0 && Fres > 0, "null pointer or empty shape");
+  if (M <= 0) return P2M_OK;
+  long tot = M * Fres;
+  hipLaunchKernelGGL(k_lerp_bwd_add, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, g, dst, (long)M, F, Fres);
+  return check_launch("lerp_bwd_add");
+}

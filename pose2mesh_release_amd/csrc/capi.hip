@@ -1,0 +1,142 @@
+// Graph handles, error plumbing and the composite ChebConv entry point of libp2m_hip.so.
+#include <algorithm>
+#include <cstdarg>
+#include <vector>
+
+#include "p2m_common.h"
+
+namespace p2m {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return P2M_ERR_HIP;
+  }
+  return P2M_OK;
+}
+
+static int upload(const void* src, size_t bytes, void** dst) {
+  hipError_t e = hipMalloc(dst, bytes ? bytes : 4);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return P2M_ERR_NOMEM;
+  }
+  if (bytes) {
+    e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+      return P2M_ERR_HIP;
+    }
+  }
+  return P2M_OK;
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+extern "C" const char* p2m_last_error_string(void) { return g_err; }
+extern "C" const char* p2m_version(void) { return "p2m-hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+
+// Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).
+extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val, int32_t V, int32_t nnz,
+                                p2m_graph_t* out) {
+  P2M_CHECK_ARG(row_ptr && col && val && out && V > 0 && nnz >= 0, "null pointer or empty graph");
+  P2M_CHECK_ARG(row_ptr[0] == 0 && row_ptr[V] == nnz, "row_ptr inconsistent with nnz");
+  for (int i = 0; i < V; i++) P2M_CHECK_ARG(row_ptr[i] <= row_ptr[i + 1], "row_ptr not monotone");
+  for (int j = 0; j < nnz; j++) P2M_CHECK_ARG(col[j] >= 0 && col[j] < V, "column index out of range");
+
+  std::vector<int> rp(V + 1, 0), mc;
+  std::vector<float> ma, mb;
+  std::vector<double> accA(V, 0.0), accB(V, 0.0);
+  std::vector<int> mark(V, -1), touched;
+  int max_row = 0;
+  for (int i = 0; i < V; i++) {
+    touched.clear();
+    auto touch = [&](int c) {
+      if (mark[c] != i) {
+        mark[c] = i;
+        accA[c] = 0.0;
+        accB[c] = 0.0;
+        touched.push_back(c);
+      }
+    };
+    for (int j = row_ptr[i]; j < row_ptr[i + 1]; j++) {
+      const int k = col[j];
+      const double lik = (double)val[j];
+      touch(k);
+      accA[k] += lik;  // duplicates in the input are summed (COO semantics of the reference tensor)
+      for (int q = row_ptr[k]; q < row_ptr[k + 1]; q++) {
+        touch(col[q]);
+        accB[col[q]] += 2.0 * lik * (double)val[q];
+      }
+    }
+    touch(i);
+    accB[i] -= 1.0;
+    std::sort(touched.begin(), touched.end());
+    for (int c : touched) {
+      mc.push_back(c);
+      ma.push_back((float)accA[c]);
+      mb.push_back((float)accB[c]);
+    }
+    rp[i + 1] = (int)mc.size();
+    max_row = std::max(max_row, rp[i + 1] - rp[i]);
+  }
+  Graph* g = new Graph();
+  g->V = V;
+  g->nnz = (int)mc.size();
+  g->nnz_L = nnz;
+  g->max_row = max_row;
+  int rc;
+  if ((rc = upload(rp.data(), sizeof(int) * (V + 1), (void**)&g->rowptr)) != P2M_OK ||
+      (rc = upload(mc.data(), sizeof(int) * mc.size(), (void**)&g->col)) != P2M_OK ||
+      (rc = upload(ma.data(), sizeof(float) * ma.size(), (void**)&g->a)) != P2M_OK ||
+      (rc = upload(mb.data(), sizeof(float) * mb.size(), (void**)&g->b)) != P2M_OK) {
+    p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
+    return rc;
+  }
+  *out = reinterpret_cast<p2m_graph_t>(g);
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
+  if (!gh) return P2M_OK;
+  Graph* g = reinterpret_cast<Graph*>(gh);
+  if (g->rowptr) (void)hipFree(g->rowptr);
+  if (g->col) (void)hipFree(g->col);
+  if (g->a) (void)hipFree(g->a);
+  if (g->b) (void)hipFree(g->b);
+  delete g;
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_info(p2m_graph_t gh, int32_t info[4]) {
+  P2M_CHECK_ARG(gh && info, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  info[0] = g->V;
+  info[1] = g->nnz_L;
+  info[2] = g->nnz;
+  info[3] = g->max_row;
+  return P2M_OK;
+}
+
+extern "C" int p2m_chebconv_fwd(p2m_graph_t gh, const float* X, const float* Wt, const float* bias, float* T1,
+                                float* T2, float* Y, float* stats, int32_t B, int32_t Fin, int32_t Fout,
+                                int32_t in_shift, void* stream) {
+  P2M_CHECK_ARG(gh, "null graph");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  int rc = p2m_cheb_basis_fwd(gh, X, T1, T2, B, Fin, in_shift, stream);
+  if (rc != P2M_OK) return rc;
+  return p2m_gemm_planes(X, T1, T2, 3, Fin, in_shift, Wt, bias, Y, nullptr, nullptr, 1, Fout, (int64_t)B * g->V,
+                         stats, stream);
+}

@@ -1,0 +1,563 @@
+// Dense contractions of the Pose2Mesh Chebyshev GCN on gfx950 FP32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   k_gemm_planes : C = [A0|A1|A2] * Bm + bias  (+ BatchNorm partial statistics in the epilogue)
+//   k_gemm_tn     : P[chunk] = [A0|A1|A2]^T * G  over a chunk of rows (weight gradient)
+//   k_naive_*     : scalar fall-backs for the odd shapes (Fin=5 first conv, Fout=3 last conv)
+//
+// Replaces nn.Linear inside graph_conv_cheby (lib/models/backbones/cheby_graph_conv.py:37), the
+// fc lift (lib/models/meshnet.py:105) and their autograd backward.  1e-4 vertex parity needs exact
+// fp32 products: gfx950 has no TF32/xf32, the f32 MFMA is bitwise an fmaf chain.
+//
+// Tiling (64-wide waves): block = 256 threads = 4 waves arranged 2(M) x 2(N); block tile 128 x BN
+// (BN = 128 or 64), K chunk 32; each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles.
+// A 32x32x2 f32 MFMA takes 64 cycles, so the 4 LDS reads that feed 4 MFMAs are noise; what matters
+// is keeping 4+ independent accumulators in flight and double-buffering the HBM->LDS staging.
+#include "p2m_common.h"
+
+namespace p2m {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int AS_LD = BK + 1;  // [m][k] with stride 33: bank = (m + k) % 32 -> conflict-free frag reads
+
+struct GemmArgs {
+  const float* A[3];
+  const float* Bm;
+  const float* bias;
+  float* C[3];
+  float* stats;
+  long M;
+  int nplanesA, Ka, a0_shift;
+  int N, Nc;
+  int ntm, ntn;
+};
+
+// blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
+// give the n-tiles of one m-tile consecutive slots of the SAME XCD so the A tile is re-read
+// from that XCD's L2, not from HBM.
+__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt, int& nt) {
+  int xcd = bid & 7;
+  int slot = bid >> 3;
+  nt = slot % ntn;
+  mt = (slot / ntn) * 8 + xcd;
+  return mt < ntm;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
+  constexpr int WTN = BN / 2;    // wave tile N
+  constexpr int TN = WTN / 32;   // MFMA tiles along N per wave
+  constexpr int TM = 2;          // wave tile M = 64
+  constexpr int BPASS = BN / 32; // float4 B loads per thread per chunk (32 x BN tile)
+  __shared__ float smem[2 * BM * AS_LD + 2 * BK * BN];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * AS_LD;
+
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
+  const long m0 = (long)mt * BM;
+  const int n0 = nt * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int cpp = g.Ka / BK;              // chunks per plane
+  const int nchunks = g.nplanesA * cpp;
+
+  // staging registers
+  float4 ra[4];
+  float4 rb[BPASS];
+  const int a_row = t >> 3, a_k4 = (t & 7) * 4;
+  const int b_row = t / (BN / 4), b_c4 = (t % (BN / 4)) * 4;
+  constexpr int BROWS = 256 / (BN / 4);   // rows of B covered per pass (8 for BN=128, 16 for BN=64)
+
+  auto load_chunk = [&](int kc) {
+    const int p = kc / cpp;
+    const int k0 = (kc - p * cpp) * BK;
+    const float* Ap = g.A[p];
+    const int sh = (p == 0) ? g.a0_shift : 0;
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      long r = m0 + ps * 32 + a_row;
+      if (r < g.M)
+        ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
+      else
+        ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* Bp = g.Bm + (long)(p * g.Ka + k0) * g.N;
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ps++) {
+      int kr = ps * BROWS + b_row;
+      int n = n0 + b_c4;
+      if (n < g.N)
+        rb[ps] = *reinterpret_cast<const float4*>(Bp + (long)kr * g.N + n);
+      else
+        rb[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * BM * AS_LD;
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      float* d = as + (ps * 32 + a_row) * AS_LD + a_k4;
+      d[0] = ra[ps].x; d[1] = ra[ps].y; d[2] = ra[ps].z; d[3] = ra[ps].w;
+    }
+    float* bs = Bs + buf * BK * BN;
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ps++)
+      *reinterpret_cast<float4*>(bs + (ps * BROWS + b_row) * BN + b_c4) = rb[ps];
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int kc = 0; kc < nchunks; kc++) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) load_chunk(kc + 1);
+    const float* as = As + cur * BM * AS_LD + (wm * 64 + l31) * AS_LD + lhi;
+    const float* bs = Bs + cur * BK * BN + lhi * BN + wn * WTN + l31;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ks++) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = as[i * 32 * AS_LD + 2 * ks];
+#pragma unroll
+      for (int j = 0; j < TN; j++) b[j] = bs[2 * ks * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nchunks) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, store, BatchNorm partials ------------------------------------------
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float bias_v[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    ncol[j] = n0 + wn * WTN + j * 32 + l31;
+    bias_v[j] = (g.bias != nullptr && ncol[j] < g.N) ? g.bias[ncol[j]] : 0.f;
+  }
+  float csum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) csum[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = ncol[j];
+      const int q = n / g.Nc;
+      const int c = n - q * g.Nc;
+      float* Cq = (n < g.N) ? g.C[q] : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float v = acc[i][j][r] + bias_v[j];
+        acc[i][j][r] = v;
+        if (row < g.M && Cq != nullptr) {
+          Cq[row * g.Nc + c] = v;
+          csum[j] += v;
+        }
+      }
+    }
+  if (g.stats == nullptr) return;
+
+  // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
+  float* red = smem;  // [2 (wm)][BN]   (safe: all waves passed the last __syncthreads of the k loop)
+  long rows_valid = g.M - m0;
+  if (rows_valid > BM) rows_valid = BM;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    csum[j] += __shfl_xor(csum[j], 32);
+    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = csum[j];
+  }
+  __syncthreads();
+  float cm2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int cl = wn * WTN + j * 32 + l31;
+    const float tot = red[cl] + red[BN + cl];
+    const float mean = tot / (float)rows_valid;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float d = acc[i][j][r] - mean;
+        if (row < g.M) m2 += d * d;
+      }
+    m2 += __shfl_xor(m2, 32);
+    cm2[j] = m2;
+    csum[j] = tot;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = cm2[j];
+  __syncthreads();
+  if (wm == 0 && lhi == 0) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int cl = wn * WTN + j * 32 + l31;
+      const int n = n0 + cl;
+      if (n < g.N) {
+        float* st = g.stats + (long)mt * 2 * g.N;
+        st[n] = csum[j];
+        st[g.N + n] = red[cl] + red[BN + cl];
+      }
+    }
+  }
+}
+
+// scalar fall-back (first conv Fin=5 -> K=15; last conv Fout=3): one thread per (row, n)
+__global__ void k_naive_gemm_planes(GemmArgs g) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= g.M * g.N) return;
+  long r = idx / g.N;
+  int n = (int)(idx - r * g.N);
+  float acc = 0.f;
+  for (int p = 0; p < g.nplanesA; p++) {
+    const float* a = g.A[p] + (r >> (p == 0 ? g.a0_shift : 0)) * g.Ka;
+    const float* b = g.Bm + (long)p * g.Ka * g.N + n;
+    for (int k = 0; k < g.Ka; k++) acc = fmaf(a[k], b[(long)k * g.N], acc);
+  }
+  if (g.bias) acc += g.bias[n];
+  int q = n / g.Nc;
+  g.C[q][r * g.Nc + (n - q * g.Nc)] = acc;
+}
+
+// per-128-row-tile statistics for the naive path (same partial format as the MFMA epilogue)
+__global__ void k_naive_tile_stats(const float* __restrict__ Y, float* __restrict__ stats, long M, int N) {
+  int tile = blockIdx.x;
+  long r0 = (long)tile * BM;
+  long r1 = r0 + BM < M ? r0 + BM : M;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float s = 0.f;
+    for (long r = r0; r < r1; r++) s += Y[r * N + n];
+    float mean = s / (float)(r1 - r0);
+    float m2 = 0.f;
+    for (long r = r0; r < r1; r++) {
+      float d = Y[r * N + n] - mean;
+      m2 += d * d;
+    }
+    stats[(long)tile * 2 * N + n] = s;
+    stats[(long)tile * 2 * N + N + n] = m2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: P[chunk][kk][n] = sum_{r in chunk} Z[r][kk] * G[r][n]
+// ---------------------------------------------------------------------------------------------
+struct TnArgs {
+  const float* A[3];
+  const float* G;
+  float* P;
+  float* Pdb;
+  long M, chunk_rows;
+  int nplanesA, Ka, a0_shift, Ktot, N;
+  int nkt, ntn;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
+  constexpr int WTN = BN / 2;
+  constexpr int TN = WTN / 32;
+  constexpr int TM = 2;
+  constexpr int RK = 32;                 // rows (reduction) per LDS stage
+  constexpr int GPASS = BN / 32;         // float4 loads of G per thread per stage
+  constexpr int GROWS = 256 / (BN / 4);
+  __shared__ float smem[2 * RK * BM + 2 * RK * BN];
+  float* As = smem;                      // [buf][r][kk]  (kk contiguous)
+  float* Gs = smem + 2 * RK * BM;        // [buf][r][n]
+
+  const int tile = blockIdx.x;
+  const int kt = tile / g.ntn, nt = tile % g.ntn;
+  const int chunk = blockIdx.y;
+  const int kk0 = kt * BM, n0 = nt * BN;
+  const long r_begin = (long)chunk * g.chunk_rows;
+  long r_end = r_begin + g.chunk_rows;
+  if (r_end > g.M) r_end = g.M;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // this thread's column of the A tile: fixed plane / offset for the whole kernel
+  const int a_r = t >> 5, a_c4 = (t & 31) * 4;
+  const int kk = kk0 + a_c4;
+  const bool a_ok = kk < g.Ktot;
+  const int ap = a_ok ? kk / g.Ka : 0;
+  const int ak = kk - ap * g.Ka;
+  const float* Ap = g.A[ap];
+  const int ash = (ap == 0) ? g.a0_shift : 0;
+  const int g_r = t / (BN / 4), g_c4 = (t % (BN / 4)) * 4;
+  const bool g_ok = (n0 + g_c4) < g.N;
+
+  float4 ra[4], rg[GPASS];
+  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_stage = [&](long r0) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      long r = r0 + ps * 8 + a_r;
+      if (a_ok && r < r_end)
+        ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> ash) * g.Ka + ak);
+      else
+        ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < GPASS; ps++) {
+      long r = r0 + ps * GROWS + g_r;
+      if (g_ok && r < r_end)
+        rg[ps] = *reinterpret_cast<const float4*>(g.G + r * g.N + n0 + g_c4);
+      else
+        rg[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dbs.x += rg[ps].x; dbs.y += rg[ps].y; dbs.z += rg[ps].z; dbs.w += rg[ps].w;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* as = As + buf * RK * BM;
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++)
+      *reinterpret_cast<float4*>(as + (ps * 8 + a_r) * BM + a_c4) = ra[ps];
+    float* gs = Gs + buf * RK * BN;
+#pragma unroll
+    for (int ps = 0; ps < GPASS; ps++)
+      *reinterpret_cast<float4*>(gs + (ps * GROWS + g_r) * BN + g_c4) = rg[ps];
+  };
+
+  load_stage(r_begin);
+  store_stage(0);
+  __syncthreads();
+  int it = 0;
+  for (long r0 = r_begin; r0 < r_end; r0 += RK, it++) {
+    const int cur = it & 1;
+    const bool more = (r0 + RK) < r_end;
+    if (more) load_stage(r0 + RK);
+    const float* as = As + cur * RK * BM + lhi * BM + wm * 64 + l31;
+    const float* gs = Gs + cur * RK * BN + lhi * BN + wn * WTN + l31;
+#pragma unroll
+    for (int ks = 0; ks < RK / 2; ks++) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = as[2 * ks * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; j++) b[j] = gs[2 * ks * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* Pc = g.P + (long)chunk * g.Ktot * g.N;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = acc[i][j][r];
+      }
+    }
+  if (kt == 0 && g.Pdb != nullptr) {
+    // bias gradient: column sums of G over this chunk (reduce the GROWS row groups through LDS)
+    float* red = smem;  // [GROWS][BN]
+    *reinterpret_cast<float4*>(red + g_r * BN + g_c4) = dbs;
+    __syncthreads();
+    if (t < BN) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < GROWS; q++) s += red[q * BN + t];
+      if (n0 + t < g.N) g.Pdb[(long)chunk * g.N + n0 + t] = s;
+    }
+  }
+}
+
+__global__ void k_naive_gemm_tn(TnArgs g) {
+  // one thread per output (kk, n), one block row per chunk
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunk = blockIdx.y;
+  const long r_begin = (long)chunk * g.chunk_rows;
+  long r_end = r_begin + g.chunk_rows;
+  if (r_end > g.M) r_end = g.M;
+  const int nout = g.Ktot * g.N;
+  if (o < nout) {
+    int kk = o / g.N, n = o - kk * g.N;
+    int p = kk / g.Ka, k = kk - p * g.Ka;
+    const float* Ap = g.A[p];
+    int sh = p == 0 ? g.a0_shift : 0;
+    float acc = 0.f;
+    for (long r = r_begin; r < r_end; r++) acc = fmaf(Ap[(r >> sh) * g.Ka + k], g.G[r * g.N + n], acc);
+    g.P[(long)chunk * nout + o] = acc;
+  }
+  if (g.Pdb != nullptr && o < g.N) {
+    float s = 0.f;
+    for (long r = r_begin; r < r_end; r++) s += g.G[r * g.N + o];
+    g.Pdb[(long)chunk * g.N + o] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight pack / gradient unpack
+// ---------------------------------------------------------------------------------------------
+__global__ void k_weight_pack(const float* __restrict__ W, float* __restrict__ Wt, float* __restrict__ W2,
+                              int Fout, int Fin, int K) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)Fout * Fin * K;
+  if (idx >= tot) return;
+  // idx enumerates Wt: [(k*Fin+fin)][fout]
+  int fout = (int)(idx % Fout);
+  long kk = idx / Fout;
+  int k = (int)(kk / Fin), fin = (int)(kk % Fin);
+  float v = W[(long)fout * Fin * K + (long)fin * K + k];
+  Wt[idx] = v;
+  if (W2) W2[(long)fout * Fin * K + kk] = v;
+}
+
+__global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks,
+                                     float* __restrict__ dW, float* __restrict__ db, int Fout, int Fin, int K,
+                                     int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)Fout * Fin * K;
+  if (idx < tot) {
+    int fout = (int)(idx % Fout);
+    long kk = idx / Fout;
+    int k = (int)(kk / Fin), fin = (int)(kk % Fin);
+    double s = 0.0;
+    for (int c = 0; c < nchunks; c++) s += (double)P[(long)c * tot + idx];
+    long o = (long)fout * Fin * K + (long)fin * K + k;
+    dW[o] = accumulate ? dW[o] + (float)s : (float)s;
+  }
+  if (db != nullptr && Pdb != nullptr && idx < Fout) {
+    double s = 0.0;
+    for (int c = 0; c < nchunks; c++) s += (double)Pdb[(long)c * Fout + idx];
+    db[idx] = accumulate ? db[idx] + (float)s : (float)s;
+  }
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
+
+extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                               int32_t a0_shift, const float* Bm, const float* bias, float* C0, float* C1,
+                               float* C2, int32_t nplanesC, int32_t Nc, int64_t M, float* stats, void* stream) {
+  P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesC >= 1 && nplanesC <= 3, "plane count must be 1..3");
+  P2M_CHECK_ARG(A0 && Bm && C0 && Ka > 0 && Nc > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
+  if (M <= 0) return P2M_OK;
+  GemmArgs g;
+  g.A[0] = A0; g.A[1] = A1; g.A[2] = A2;
+  g.C[0] = C0; g.C[1] = C1; g.C[2] = C2;
+  for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
+  for (int p = 0; p < nplanesC; p++) P2M_CHECK_ARG(g.C[p] != nullptr, "missing C plane");
+  g.Bm = Bm; g.bias = bias; g.stats = stats; g.M = M;
+  g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
+  g.N = nplanesC * Nc; g.Nc = Nc;
+  hipStream_t s = (hipStream_t)stream;
+  const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
+  if (!mfma_ok) {
+    long tot = M * g.N;
+    g.ntm = g.ntn = 0;
+    hipLaunchKernelGGL(k_naive_gemm_planes, dim3(cdiv(tot, 256)), dim3(256), 0, s, g);
+    if (stats) {
+      P2M_CHECK_ARG(nplanesC == 1, "stats need a single output plane");
+      hipLaunchKernelGGL(k_naive_tile_stats, dim3(cdiv(M, BM)), dim3(64), 0, s, C0, stats, (long)M, g.N);
+    }
+    return check_launch("gemm_planes(naive)");
+  }
+  g.ntm = cdiv(M, BM);
+  if (g.N % 128 == 0) {
+    g.ntn = g.N / 128;
+    int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
+    hipLaunchKernelGGL(k_gemm_planes<128>, dim3(grid), dim3(256), 0, s, g);
+  } else {
+    g.ntn = cdiv(g.N, 64);
+    int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
+    hipLaunchKernelGGL(k_gemm_planes<64>, dim3(grid), dim3(256), 0, s, g);
+  }
+  return check_launch("gemm_planes");
+}
+
+extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                           int32_t a0_shift, const float* G, int32_t N, int64_t M, int64_t chunk_rows, float* P,
+                           float* Pdb, void* stream) {
+  P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
+  P2M_CHECK_ARG(A0 && G && P && Ka > 0 && N > 0 && chunk_rows > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
+  if (M <= 0) return P2M_OK;
+  TnArgs g;
+  g.A[0] = A0; g.A[1] = A1; g.A[2] = A2;
+  for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
+  g.G = G; g.P = P; g.Pdb = Pdb; g.M = M; g.chunk_rows = chunk_rows;
+  g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = nplanesA * Ka; g.N = N;
+  const int nchunks = cdiv(M, chunk_rows);
+  hipStream_t s = (hipStream_t)stream;
+  const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (g.Ktot >= 32);
+  if (!mfma_ok) {
+    g.nkt = g.ntn = 0;
+    int nout = g.Ktot * N;
+    if (nout < N) nout = N;
+    hipLaunchKernelGGL(k_naive_gemm_tn, dim3(cdiv(nout, 256), nchunks), dim3(256), 0, s, g);
+    return check_launch("gemm_tn(naive)");
+  }
+  g.nkt = cdiv(g.Ktot, BM);
+  if (N % 128 == 0) {
+    g.ntn = N / 128;
+    hipLaunchKernelGGL(k_gemm_tn<128>, dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+  } else {
+    g.ntn = cdiv(N, 64);
+    hipLaunchKernelGGL(k_gemm_tn<64>, dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+  }
+  return check_launch("gemm_tn");
+}
+
+extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, int32_t Fout, int32_t Fin, int32_t K,
+                               void* stream) {
+  P2M_CHECK_ARG(W && Wt && Fout > 0 && Fin > 0 && K > 0, "null pointer or empty shape");
+  long tot = (long)Fout * Fin * K;
+  hipLaunchKernelGGL(k_weight_pack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, W, Wt, W2, Fout, Fin, K);
+  return check_launch("weight_pack");
+}
+
+extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
+                                      int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, void* stream) {
+  P2M_CHECK_ARG(P && dW && Fout > 0 && Fin > 0 && K > 0 && nchunks > 0, "null pointer or empty shape");
+  long tot = (long)Fout * Fin * K;
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+                     dW, db, Fout, Fin, K, accumulate);
+  return check_launch("weight_grad_unpack");
+}

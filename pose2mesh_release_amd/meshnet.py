@@ -1,0 +1,281 @@
+"""MeshNet -- the coarse-to-fine Chebyshev GCN of Pose2Mesh, on libp2m_hip.so.
+
+Drop-in for the reference's lib/models/meshnet.py: same constructor signature, same parameter
+names/shapes/initialisation (state dicts are interchangeable), same forward I/O
+  forward(x: FloatTensor[B, J*5 or B,J,5]) -> FloatTensor[B, V0, 3]   (tree order incl. fake vertices)
+but every device op is a hand-written gfx950 kernel reached through the C ABI (include/p2m.h):
+
+  reference op (file:line)                              here
+  ---------------------------------------------------  ------------------------------------------
+  permute/view, 2x torch.sparse.mm, 2x cat, permute     p2m_cheb_basis_fwd  (one gather pass, CSR of L|2LL-I)
+    (backbones/cheby_graph_conv.py:16-34)
+  cl(x) nn.Linear (cheby_graph_conv.py:37)              p2m_gemm_planes     (FP32 MFMA, BN partials in epilogue)
+  bn(x) BatchNorm1d over B*V rows (:39) + F.relu        p2m_bn_finalize + p2m_bn_act_fwd
+    (meshnet.py:100) + F.interpolate residual (:109)
+  nn.Upsample x2 (meshnet.py:71-78)                     not materialised: consumers index r>>1
+  self.fc (meshnet.py:105-106)                          p2m_gemm_planes
+  autograd backward of all of the above                 p2m_bn_bwd_*, p2m_gemm_tn, p2m_gemm_planes,
+                                                        p2m_cheb_basis_bwd, p2m_pair_sum, p2m_lerp_bwd_add
+The whole network is ONE autograd.Function so that intermediate buffers are owned explicitly
+(X|T1|T2 planes and raw conv outputs are kept for backward: ~145 MB per mesh, sized for 288 GB HBM).
+"""
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import P2MError
+
+K_CHEB = 3
+
+
+def channel_plan(mano, cin, cout):
+    """Block/layer feature widths (lib/models/meshnet.py:21-33)."""
+    if mano:
+        return [(cin, 32, 64, 64), (64, 128, 256), (256, 256, 256), (256, 256, 256), (256, 256, 256),
+                (256, 128, 128), (128, 64, cout)]
+    return [(cin, 32, 64, 64), (64, 128, 256), (256, 256, 256), (256, 256, 256), (256, 256, 256),
+            (256, 256, 256), (256, 128, 128), (128, 128, 128), (128, 128, 128), (128, 64, cout)]
+
+
+def _cfg_says_mano():
+    """Inside the reference's scripts the topology switch is cfg.DATASET.target_joint_set
+    (lib/models/meshnet.py:21).  Honour it when that module is loaded; otherwise None."""
+    mod = sys.modules.get("core.config")
+    try:
+        return None if mod is None else (mod.cfg.DATASET.target_joint_set == "mano")
+    except AttributeError:
+        return None
+
+
+class _Layer:
+    """Static description of one ChebConv (+BN+ReLU) layer."""
+    __slots__ = ("ci", "block", "graph", "Fin", "Fout", "has_bn", "first_in_block", "last_in_block")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class _MeshNetFn(torch.autograd.Function):
+    """forward/backward of the whole coarse-to-fine stack (lib/models/meshnet.py:80-117)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        dev = x.device
+        if not x.is_cuda:
+            raise P2MError("Pose2Mesh (HIP) needs CUDA/ROCm tensors: there is no CPU path in this package")
+        ctx.x_shape = x.shape
+        ctx.saved_params = params
+        with torch.cuda.device(dev):
+            return _MeshNetFn._forward(ctx, net, x, params)
+
+    @staticmethod
+    def _forward(ctx, net, x, params):
+        graphs = net._graph_cache.on(x.device)
+        training = net.training
+        keep = any(ctx.needs_input_grad)   # (autograd runs Function.forward with grad mode off)
+        J, cin = net.num_joint, net.num_joint_input_chan
+        x = x.reshape(-1, J * cin).contiguous().float()
+        B = x.shape[0]
+        P = net._param_index
+        saved = []
+        cur = x.view(B * J, cin)
+        cur_shift = 0
+        nblk = len(net.CL_F)
+        block_in, block_in_shift, block_in_F = None, 0, 0
+        fc_saved = None
+        for L in net._layers:
+            g = graphs[L.graph]
+            M = B * g.V
+            if L.first_in_block:
+                block_in, block_in_shift, block_in_F = cur, cur_shift, L.Fin
+            W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
+            T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
+            Wt, W2 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep)
+            need_stats = L.has_bn and training
+            (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats)
+            co = None
+            if L.has_bn:
+                bn = net.bn[L.ci]
+                gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
+                if training:
+                    co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+                    bn.num_batches_tracked.add_(1)
+                else:
+                    co = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
+                resid = None
+                if L.last_in_block and 1 <= L.block <= nblk - 2:       # meshnet.py:108-115
+                    resid = block_in
+                out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout)
+            else:
+                out = y                                               # final conv: no BN, no ReLU (:52-55,99)
+            if keep:
+                saved.append((cur, cur_shift, T1, T2, y, co, W2))
+            cur, cur_shift = out, 0
+            if L.last_in_block:
+                if L.block == 0:                                      # fc lift (:104-106)
+                    h = cur.view(B, J * L.Fout)
+                    fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
+                    fwt, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
+                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False)
+                    if keep:
+                        fc_saved = h
+                    cur = u.view(B * net._Vc, net.CL_F[1][0])
+                elif L.block < nblk - 2:                              # virtual x2 un-pool (:111)
+                    cur_shift = 1
+        V0 = graphs[0].V
+        ctx.net, ctx.saved, ctx.fc_saved, ctx.B, ctx.training = net, saved, fc_saved, B, training
+        ctx.n_params = len(params)
+        ctx.param_shapes = [p.shape for p in params]
+        return cur.view(B, V0, net.num_mesh_output_chan)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        with torch.cuda.device(grad_out.device):
+            return _MeshNetFn._backward(ctx, grad_out)
+
+    @staticmethod
+    def _backward(ctx, grad_out):
+        net, saved, B, training = ctx.net, ctx.saved, ctx.B, ctx.training
+        if saved is None or len(saved) == 0:
+            raise P2MError("backward called but the forward ran without gradient tracking (or twice)")
+        graphs = net._graph_cache.on(grad_out.device)
+        P = net._param_index
+        params = ctx.saved_params
+        grads = [None] * ctx.n_params
+        nblk = len(net.CL_F)
+        J = net.num_joint
+        G = grad_out.contiguous().float().view(-1, net.num_mesh_output_chan)   # grad wrt current block output
+        g_cur = G
+        for L in reversed(net._layers):
+            gph = graphs[L.graph]
+            M = B * gph.V
+            X, x_shift, T1, T2, y, co, W2 = saved[L.ci]
+            if L.last_in_block:
+                if L.block == 0:
+                    # fc backward (meshnet.py:105-106): G is d(fc out) as [B*Vc, 64]
+                    fw = params[P["fc.weight"]]
+                    dU = G.view(B, fw.shape[0])
+                    h = ctx.fc_saved
+                    Pw, Pb, nch = ops.gemm_tn([h], fw.shape[1], 0, dU, B, fw.shape[0])
+                    dW, db = ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
+                    grads[P["fc.weight"]], grads[P["fc.bias"]] = dW, db
+                    (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False)
+                    G = dh.view(B * J, L.Fout)
+                g_cur = G
+            # ---- BN + ReLU backward -> gy
+            if L.has_bn:
+                gamma = params[P[f"bn.{L.ci}.weight"]]
+                gy, dgamma, dbeta = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout)
+                grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = dgamma, dbeta
+            else:
+                gy = g_cur
+            # ---- weight gradient
+            Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
+            dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB)
+            grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+            del Pw, Pb
+            # ---- dZ planes and basis backward
+            d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
+            has_res = L.first_in_block and 1 <= L.block <= nblk - 2
+            Fblk = net.CL_F[L.block][-1]
+            fuse_res = has_res and (L.Fin == Fblk)
+            dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
+            if has_res and not fuse_res:                              # transpose of the feature resize
+                Gs = ops.pair_sum(G, M >> 1, Fblk) if x_shift else G
+                ops.lerp_bwd_add(Gs, dX, M >> x_shift, Fblk, L.Fin)
+            saved[L.ci] = None
+            g_cur = dX
+            if L.first_in_block:
+                G = dX
+        ctx.saved = None
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = g_cur.view(ctx.x_shape)
+        return (None, gx) + tuple(grads)
+
+
+class Pose2Mesh(nn.Module):
+    """Same constructor as the reference (lib/models/meshnet.py:12): graph_L is the list returned by
+    build_coarse_graphs (levels+1 scipy matrices, finest first, joint graph last).  Differences, all
+    deliberate: the caller's list is NOT mutated (the reference deletes graph_L[-2] and overwrites
+    the entries, meshnet.py:35,62); the MANO/SMPL switch may be given explicitly (`mano=`), else it is
+    taken from the reference's cfg when that is loaded, else from len(graph_L) (7 -> MANO, 10 -> SMPL).
+    """
+
+    def __init__(self, num_joint_input_chan, num_mesh_output_chan, graph_L, mano=None):
+        super().__init__()
+        self.num_joint_input_chan = num_joint_input_chan
+        self.num_mesh_output_chan = num_mesh_output_chan
+        graph_L = list(graph_L)
+        if mano is None:
+            mano = _cfg_says_mano()
+        if mano is None:
+            if len(graph_L) not in (7, 10):
+                raise ValueError(f"cannot infer SMPL/MANO topology from {len(graph_L)} graph levels; pass mano=")
+            mano = len(graph_L) == 7
+        self.mano = bool(mano)
+        self.CL_F = channel_plan(self.mano, num_joint_input_chan, num_mesh_output_chan)
+        self.CL_K = [K_CHEB] * len(self.CL_F)
+        need = len(self.CL_F)          # graphs used: blocks 0..n-2 one each, last block shares
+        if len(graph_L) != need:
+            raise ValueError(f"{'MANO' if self.mano else 'SMPL'} topology needs {need} graph levels "
+                             f"(levels={need - 1} in build_coarse_graphs), got {len(graph_L)}")
+        del graph_L[-2]                                                # meshnet.py:35 (on our copy)
+        self.graph_L = graph_L
+        self.num_joint = int(graph_L[-1].shape[0])
+        self._Vc = int(graph_L[-2].shape[0])
+        for a, b in zip(graph_L[:-2], graph_L[1:-1]):
+            if a.shape[0] != 2 * b.shape[0]:
+                raise ValueError("mesh levels must halve exactly (binary coarsening tree)")
+        self.fc = nn.Linear(self.num_joint * self.CL_F[0][-1], self._Vc * self.CL_F[1][0])   # meshnet.py:36-37
+
+        cl, bn, layers = [], [], []
+        nblk = len(self.CL_F)
+        for i, blk in enumerate(self.CL_F):
+            for l in range(len(blk) - 1):
+                Fin, Fout = blk[l], blk[l + 1]
+                lin = nn.Linear(K_CHEB * Fin, Fout)
+                scale = np.sqrt(2.0 / (K_CHEB * Fin + Fout))                 # meshnet.py:48-50
+                lin.weight.data.uniform_(-scale, scale)
+                lin.bias.data.fill_(0.0)
+                cl.append(lin)
+                last = (i == nblk - 1 and l == len(blk) - 2)
+                bn.append(None if last else nn.BatchNorm1d(Fout))              # meshnet.py:52-55
+                ldx = -(i + 1) + (1 if i == nblk - 1 else 0)                   # meshnet.py:91-93
+                layers.append(_Layer(ci=len(cl) - 1, block=i, graph=len(graph_L) + ldx, Fin=Fin, Fout=Fout,
+                                     has_bn=not last, first_in_block=(l == 0), last_in_block=(l == len(blk) - 2)))
+        self.cl = nn.ModuleList(cl)
+        self.bn = nn.ModuleList(bn)
+        self._layers = layers
+        self._graph_cache = ops.GraphCache(graph_L)
+        names, _ = self._param_list()
+        self._param_index = {n: i for i, n in enumerate(names)}
+
+    def _param_list(self):
+        names, params = ["fc.weight", "fc.bias"], [self.fc.weight, self.fc.bias]
+        for i, lin in enumerate(self.cl):
+            names += [f"cl.{i}.weight", f"cl.{i}.bias"]
+            params += [lin.weight, lin.bias]
+        for i, b in enumerate(self.bn):
+            if b is not None:
+                names += [f"bn.{i}.weight", f"bn.{i}.bias"]
+                params += [b.weight, b.bias]
+        return names, params
+
+    def init_weights(self, W, Fin, Fout):                                      # meshnet.py:64-68
+        scale = np.sqrt(2.0 / (Fin + Fout))
+        W.uniform_(-scale, scale)
+        return W
+
+    def forward(self, x):
+        _, params = self._param_list()
+        return _MeshNetFn.apply(self, x, *params)
+
+
+def get_model(num_joint_input_chan, num_mesh_output_chan, graph_L, mano=None):
+    """lib/models/meshnet.py:120-123."""
+    return Pose2Mesh(num_joint_input_chan, num_mesh_output_chan, graph_L, mano=mano)

@@ -1,0 +1,232 @@
+"""Host-side launch layer: torch tensors in, C-ABI calls (include/p2m.h) out.
+
+torch is plumbing here (device memory, streams); every arithmetic step of the hot path runs in
+libp2m_hip.so.  There is no fallback: CPU tensors or a missing library raise.
+"""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import P2MError, check
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise P2MError(f"{name}: expected a contiguous fp32 tensor on the GPU (got "
+                       f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}); "
+                       f"this path has no CPU implementation")
+    return t
+
+
+class DeviceGraph:
+    """One coarsening level baked on one GPU: merged CSR of L and 2LL-I (p2m_graph_create).
+    Replaces the torch sparse COO tensor + per-forward .cuda() of lib/models/meshnet.py:61-62,81."""
+
+    def __init__(self, L, device):
+        import scipy.sparse as sp
+        if isinstance(L, torch.Tensor):  # torch sparse COO/CSR as the reference keeps after __init__
+            Lc = L.coalesce() if L.layout == torch.sparse_coo else L.to_sparse_coo().coalesce()
+            idx = Lc.indices().cpu().numpy()
+            L = sp.coo_matrix((Lc.values().cpu().numpy(), (idx[0], idx[1])), shape=tuple(Lc.shape))
+        csr = sp.csr_matrix(L, dtype=np.float64)
+        csr.sum_duplicates()
+        csr.sort_indices()
+        if csr.shape[0] != csr.shape[1]:
+            raise P2MError("graph Laplacian must be square")
+        self.V = int(csr.shape[0])
+        self.device = torch.device(device)
+        rp = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        va = np.ascontiguousarray(csr.data.astype(np.float32))   # graph_utils.py:104: fp32 on device
+        h = _vp()
+        with torch.cuda.device(self.device):
+            check(_lib.hip().p2m_graph_create(rp.ctypes.data_as(_vp), ci.ctypes.data_as(_vp), va.ctypes.data_as(_vp),
+                                              self.V, int(ci.size), ctypes.byref(h)), "p2m_graph_create")
+        self.handle = h
+        info = (ctypes.c_int32 * 4)()
+        check(_lib.hip().p2m_graph_info(self.handle, ctypes.byref(info)), "p2m_graph_info")
+        self.nnz_L, self.nnz_merged, self.max_row = int(info[1]), int(info[2]), int(info[3])
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.hip().p2m_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class GraphCache:
+    """Per-device DeviceGraph lists for a list of scipy Laplacians (thread-safe: nn.DataParallel
+    calls forward from one thread per GPU on replicas that share this object)."""
+
+    def __init__(self, laplacians):
+        self.laplacians = list(laplacians)
+        self._per_device = {}
+        self._lock = threading.Lock()
+
+    def on(self, device):
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        g = self._per_device.get(key)
+        if g is None:
+            with self._lock:
+                g = self._per_device.get(key)
+                if g is None:
+                    g = [DeviceGraph(L, torch.device("cuda", key)) for L in self.laplacians]
+                    self._per_device[key] = g
+        return g
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers (one per C-ABI entry point)
+# ---------------------------------------------------------------------------------------------
+def stats_tile_rows():
+    return int(_lib.hip().p2m_stats_tile_rows())
+
+
+def cheb_basis_fwd(g, X, B, F, in_shift):
+    M = B * g.V
+    T1 = torch.empty((M, F), device=X.device, dtype=torch.float32)
+    T2 = torch.empty((M, F), device=X.device, dtype=torch.float32)
+    check(_lib.hip().p2m_cheb_basis_fwd(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
+          "p2m_cheb_basis_fwd")
+    return T1, T2
+
+
+def cheb_basis_bwd(g, d0, d1, d2, resid, B, F, out_shift):
+    dX = torch.empty((B * (g.V >> out_shift), F), device=d0.device, dtype=torch.float32)
+    check(_lib.hip().p2m_cheb_basis_bwd(g.handle, _p(_req(d0, "d0")), _p(_req(d1, "d1")), _p(_req(d2, "d2")),
+                                        _p(resid if resid is None else _req(resid, "resid")), _p(dX), B, F,
+                                        out_shift, _stream()), "p2m_cheb_basis_bwd")
+    return dX
+
+
+def weight_pack(W, Fin, K, need_w2=True):
+    Fout = W.shape[0]
+    Wt = torch.empty((K * Fin, Fout), device=W.device, dtype=torch.float32)
+    W2 = torch.empty((Fout, K * Fin), device=W.device, dtype=torch.float32) if need_w2 else None
+    check(_lib.hip().p2m_weight_pack(_p(_req(W, "weight")), _p(Wt), _p(W2), Fout, Fin, K, _stream()),
+          "p2m_weight_pack")
+    return Wt, W2
+
+
+def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
+    """A: list of 1..3 plane tensors.  Returns (list of C planes, stats or None)."""
+    dev = A[0].device
+    Nc = N // nplanesC
+    C = [torch.empty((M, Nc), device=dev, dtype=torch.float32) for _ in range(nplanesC)]
+    st = None
+    if stats:
+        nt = (M + stats_tile_rows() - 1) // stats_tile_rows()
+        st = torch.empty((nt, 2, N), device=dev, dtype=torch.float32)
+    a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
+    c = [_p(t) for t in C] + [None] * (3 - len(C))
+    check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")),
+                                     _p(bias if bias is None else _req(bias, "bias")), c[0], c[1], c[2], nplanesC, Nc,
+                                     M, _p(st), _stream()), "p2m_gemm_planes")
+    return C, st
+
+
+def pick_chunk_rows(M, ntiles_out, target_blocks=1024, quantum=32):
+    """Rows per split for the weight-gradient contraction: enough blocks to fill 256 CUs."""
+    nchunks = max(1, min((target_blocks + ntiles_out - 1) // ntiles_out, (M + 255) // 256))
+    rows = (M + nchunks - 1) // nchunks
+    rows = ((rows + quantum - 1) // quantum) * quantum
+    return rows
+
+
+def gemm_tn(A, Ka, a0_shift, G, M, N):
+    """Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks)."""
+    Ktot = len(A) * Ka
+    ntiles = ((Ktot + 127) // 128) * ((N + 127) // 128)
+    chunk_rows = pick_chunk_rows(M, ntiles)
+    nchunks = (M + chunk_rows - 1) // chunk_rows
+    P = torch.empty((nchunks, Ktot, N), device=G.device, dtype=torch.float32)
+    Pdb = torch.empty((nchunks, N), device=G.device, dtype=torch.float32)
+    a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
+    check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(G, "G")), N, M, chunk_rows, _p(P),
+                                 _p(Pdb), _stream()), "p2m_gemm_tn")
+    return P, Pdb, nchunks
+
+
+def weight_grad_unpack(P, Pdb, nchunks, Fout, Fin, K, dW=None, db=None):
+    acc = 1 if dW is not None else 0
+    if dW is None:
+        dW = torch.empty((Fout, Fin * K), device=P.device, dtype=torch.float32)
+        db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
+    check(_lib.hip().p2m_weight_grad_unpack(_p(P), _p(Pdb), nchunks, _p(dW), _p(db), Fout, Fin, K, acc, _stream()),
+          "p2m_weight_grad_unpack")
+    return dW, db
+
+
+def bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps):
+    N = gamma.shape[0]
+    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)  # mean, invstd, scale, shift
+    check(_lib.hip().p2m_bn_finalize(_p(stats), stats.shape[0], M, _p(_req(gamma, "bn.weight")),
+                                     _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
+                                     float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
+                                     _stream()), "p2m_bn_finalize")
+    return co
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    N = gamma.shape[0]
+    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
+    check(_lib.hip().p2m_bn_eval_coeffs(_p(_req(gamma, "bn.weight")), _p(_req(beta, "bn.bias")),
+                                        _p(_req(running_mean, "running_mean")), _p(_req(running_var, "running_var")),
+                                        float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N, _stream()),
+          "p2m_bn_eval_coeffs")
+    return co
+
+
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F):
+    x = torch.empty((M, F), device=y.device, dtype=torch.float32)
+    sc = None if co is None else co[2]
+    sh = None if co is None else co[3]
+    check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
+                                    _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),
+                                    _p(x), M, F, _stream()), "p2m_bn_act_fwd")
+    return x
+
+
+def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F):
+    """Returns (gy, dgamma, dbeta)."""
+    lib = _lib.hip()
+    nblk = int(lib.p2m_bn_bwd_blocks(M, F))
+    part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
+    dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
+    coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
+    check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
+                                int(relu), _p(part), M, F, _stream()), "p2m_bn_bwd_reduce")
+    check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgb[0]), _p(dgb[1]), _p(coef), 0, F, _stream()),
+          "p2m_bn_bwd_finalize")
+    gy = torch.empty((M, F), device=y.device, dtype=torch.float32)
+    check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
+                               _p(coef) if training else None, int(relu), _p(gy), M, F, _stream()),
+          "p2m_bn_bwd_apply")
+    return gy, dgb[0], dgb[1]
+
+
+def pair_sum(x, Mout, F):
+    out = torch.empty((Mout, F), device=x.device, dtype=torch.float32)
+    check(_lib.hip().p2m_pair_sum(_p(_req(x, "in")), _p(out), Mout, F, _stream()), "p2m_pair_sum")
+    return out
+
+
+def lerp_bwd_add(g, dst, M, F, Fres):
+    check(_lib.hip().p2m_lerp_bwd_add(_p(_req(g, "g")), _p(_req(dst, "dst")), M, F, Fres, _stream()),
+          "p2m_lerp_bwd_add")
+    return dst

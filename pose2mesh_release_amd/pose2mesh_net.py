@@ -1,0 +1,32 @@
+"""FlatPose2Mesh -- the module the reference's scripts instantiate (lib/models/pose2mesh_net.py).
+
+    model = pose2mesh_net.get_model(num_joint, graph_L)          # base.py:57, demo/run.py:120
+    cam_mesh, pose3d = model(pose2d)                             # (B,V0,3) metres, (B,J,3) millimetres
+
+State-dict keys are `pose_lifter.*` / `pose2mesh.*` exactly as in the reference, so its
+final.pth.tar checkpoints load with load_state_dict().
+"""
+import torch
+import torch.nn as nn
+
+from . import meshnet, posenet
+
+
+class FlatPose2Mesh(nn.Module):
+    def __init__(self, num_joint, graph_L, mano=None):
+        super().__init__()
+        self.num_joint = num_joint
+        self.pose_lifter = posenet.get_model(num_joint, hid_dim=4096, num_layer=2, p_dropout=0.5, pretrained=False)
+        self.pose2mesh = meshnet.get_model(num_joint_input_chan=2 + 3, num_mesh_output_chan=3, graph_L=graph_L,
+                                           mano=mano)
+
+    def forward(self, pose2d):
+        pose3d = self.pose_lifter(pose2d.view(len(pose2d), -1)).reshape(-1, self.num_joint, 3)
+        # MeshNet gets no gradient path into PoseNet (pose2mesh_net.py:19)
+        pose_combine = torch.cat((pose2d, pose3d.detach() / 1000), dim=2)
+        return self.pose2mesh(pose_combine), pose3d
+
+
+def get_model(num_joint, graph_L, mano=None):
+    """lib/models/pose2mesh_net.py:25-28."""
+    return FlatPose2Mesh(num_joint, graph_L, mano=mano)

@@ -1,0 +1,180 @@
+"""-m gpu: every C-ABI entry point against a plain fp32/fp64 torch restatement of the same op
+(seeded inputs; tolerances are fp32 round-off class, written next to each check)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_graph(V, seed, fake_frac=0.3):
+    """Symmetric rescaled-Laplacian-like matrix with isolated (diagonal-only) fake rows."""
+    rng = np.random.default_rng(seed)
+    nreal = max(2, int(V * (1 - fake_frac)))
+    rows, cols = [], []
+    for i in range(nreal):
+        for j in rng.choice(nreal, size=min(3, nreal - 1), replace=False):
+            if i != j:
+                rows += [i, j]
+                cols += [j, i]
+    A = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(V, V)).tocsr()
+    A.data[:] = 1.0
+    d = np.asarray(A.sum(axis=0)).ravel() + np.spacing(np.float64(0))
+    Dm = sp.diags(1 / np.sqrt(d))
+    L = sp.identity(V) - Dm @ A @ Dm
+    return (L / 3.0 - sp.identity(V)).tocsr()
+
+
+@pytest.fixture(scope="module")
+def ops(hip_libs):
+    from pose2mesh_release_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("V,Fdim,shift", [(17, 5, 0), (96, 64, 0), (184, 256, 1), (1472, 128, 1), (736, 32, 0),
+                                          (46, 3, 0)])
+def test_cheb_basis_fwd_bwd(ops, V, Fdim, shift):
+    B = 3
+    L = _rand_graph(V, V)
+    g = ops.DeviceGraph(L, "cuda:0")
+    Ld = torch.from_numpy(L.toarray())
+    gen = torch.Generator().manual_seed(V + Fdim)
+    Xs = torch.randn(B, V >> shift, Fdim, generator=gen)
+    X = Xs.repeat_interleave(1 << shift, dim=1).double()
+    T1r = torch.einsum("vw,bwf->bvf", Ld, X)
+    T2r = 2 * torch.einsum("vw,bwf->bvf", Ld, T1r) - X            # cheby_graph_conv.py:25,28
+    T1, T2 = ops.cheb_basis_fwd(g, Xs.cuda().view(-1, Fdim).contiguous(), B, Fdim, shift)
+    assert (T1.cpu().view(B, V, Fdim) - T1r).abs().max() < 2e-6 * max(1, T1r.abs().max())
+    assert (T2.cpu().view(B, V, Fdim) - T2r).abs().max() < 4e-6 * max(1, T2r.abs().max())
+    # backward: dX = d0 + L d1 + (2LL-I) d2, children summed when shifted
+    d = [torch.randn(B, V, Fdim, generator=gen) for _ in range(3)]
+    res = torch.randn(B, V, Fdim, generator=gen)
+    L2 = 2 * Ld @ Ld - torch.eye(V, dtype=torch.float64)
+    full = d[0].double() + res.double() + torch.einsum("vw,bwf->bvf", Ld, d[1].double()) + \
+        torch.einsum("vw,bwf->bvf", L2, d[2].double())
+    if shift:
+        full = full.view(B, V // 2, 2, Fdim).sum(2)
+    dX = ops.cheb_basis_bwd(g, *[t.cuda().view(-1, Fdim).contiguous() for t in d],
+                            res.cuda().view(-1, Fdim).contiguous(), B, Fdim, shift)
+    assert (dX.cpu().view(full.shape) - full).abs().max() < 5e-6 * max(1, full.abs().max())
+
+
+@pytest.mark.parametrize("M,Ka,N,planes,shift", [(300, 32, 64, 3, 0), (1000, 128, 256, 3, 1), (257, 64, 128, 1, 0),
+                                                 (513, 5, 32, 3, 0), (640, 64, 3, 3, 0), (256, 1088, 5888, 1, 0),
+                                                 (129, 256, 96, 1, 0)])
+def test_gemm_planes_and_stats(ops, M, Ka, N, planes, shift):
+    gen = torch.Generator().manual_seed(M + N)
+    A = [torch.randn((M + 1) >> shift if (p == 0 and shift) else M, Ka, generator=gen) for p in range(planes)]
+    Bm = torch.randn(planes * Ka, N, generator=gen) / np.sqrt(planes * Ka)
+    bias = torch.randn(N, generator=gen)
+    Afull = [a.repeat_interleave(2, 0)[:M] if (p == 0 and shift) else a for p, a in enumerate(A)]
+    ref = torch.cat(Afull, 1).double() @ Bm.double() + bias.double()
+    (C,), st = ops.gemm_planes([a.cuda() for a in A], Ka, shift, Bm.cuda(), bias.cuda(), M, N, 1, True)
+    torch.cuda.synchronize()
+    assert (C.cpu() - ref).abs().max() < 2e-5
+    tr = ops.stats_tile_rows()
+    nt = (M + tr - 1) // tr
+    assert st.shape == (nt, 2, N)
+    for t in range(nt):
+        blk = ref[t * tr:(t + 1) * tr]
+        assert (st[t, 0].cpu() - blk.sum(0)).abs().max() < 1e-3
+        assert (st[t, 1].cpu() - ((blk - blk.mean(0)) ** 2).sum(0)).abs().max() < 2e-3
+
+
+def test_gemm_planes_output_planes(ops):
+    M, K, Nc = 500, 128, 64
+    gen = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=gen)
+    Bm = torch.randn(K, 3 * Nc, generator=gen) / 11
+    ref = A.double() @ Bm.double()
+    C, _ = ops.gemm_planes([A.cuda()], K, 0, Bm.cuda(), None, M, 3 * Nc, 3, False)
+    for q in range(3):
+        assert (C[q].cpu() - ref[:, q * Nc:(q + 1) * Nc]).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,Ka,N,planes,shift", [(3000, 128, 128, 3, 1), (700, 32, 64, 3, 0), (513, 5, 32, 3, 0),
+                                                 (2000, 64, 3, 3, 0), (256, 1088, 320, 1, 0), (999, 256, 256, 3, 0)])
+def test_gemm_tn_and_unpack(ops, M, Ka, N, planes, shift):
+    gen = torch.Generator().manual_seed(M + Ka)
+    A = [torch.randn((M + 1) >> shift if (p == 0 and shift) else M, Ka, generator=gen) for p in range(planes)]
+    G = torch.randn(M, N, generator=gen)
+    Afull = [a.repeat_interleave(2, 0)[:M] if (p == 0 and shift) else a for p, a in enumerate(A)]
+    Z = torch.cat(Afull, 1).double()                       # [M, planes*Ka], column = k*Ka + fin
+    dWt = Z.t() @ G.double()                               # [planes*Ka, N]
+    P, Pdb, nch = ops.gemm_tn([a.cuda() for a in A], Ka, shift, G.cuda(), M, N)
+    dW, db = ops.weight_grad_unpack(P, Pdb, nch, N, Ka, planes)
+    # nn.Linear layout: dW[fout][fin*K + k]
+    ref = dWt.view(planes, Ka, N).permute(2, 1, 0).reshape(N, Ka * planes)
+    scale = max(1.0, ref.abs().max().item())
+    assert (dW.cpu() - ref).abs().max() < 3e-6 * scale * np.sqrt(M)
+    assert (db.cpu() - G.double().sum(0)).abs().max() < 1e-4 * np.sqrt(M)
+
+
+def test_weight_pack(ops):
+    Fout, Fin, K = 64, 32, 3
+    W = torch.randn(Fout, Fin * K)
+    Wt, W2 = ops.weight_pack(W.cuda(), Fin, K)
+    ref = W.view(Fout, Fin, K).permute(2, 1, 0).reshape(K * Fin, Fout)
+    assert torch.equal(Wt.cpu(), ref)
+    assert torch.equal(W2.cpu(), ref.t().contiguous())
+
+
+@pytest.mark.parametrize("M,Fd,Fres,rshift,training", [(1000, 64, 64, 0, True), (2048, 256, 64, 0, True),
+                                                       (640, 128, 256, 1, True), (777, 32, 32, 0, False),
+                                                       (5000, 128, 128, 1, True)])
+def test_bn_relu_residual_fwd_bwd(ops, M, Fd, Fres, rshift, training):
+    """BatchNorm1d (train/eval) + ReLU + feature-axis-resized residual, forward and backward, against
+    torch autograd in fp64 (cheby_graph_conv.py:39, meshnet.py:100,109-110)."""
+    gen = torch.Generator().manual_seed(M)
+    y = torch.randn(M, Fd, generator=gen) * 2 + 0.5
+    gamma = torch.rand(Fd, generator=gen) + 0.5
+    beta = torch.randn(Fd, generator=gen) * 0.2
+    rm, rv = torch.randn(Fd, generator=gen) * 0.1, torch.rand(Fd, generator=gen) + 0.5
+    resid = torch.randn((M + 1) >> rshift, Fres, generator=gen)
+    gx = torch.randn(M, Fd, generator=gen)
+    # --- reference in fp64
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    rd = resid.double().requires_grad_(True)
+    o = F.relu(F.batch_norm(yd, rmd, rvd, gd, bd, training, 0.1, 1e-5))
+    rfull = rd.repeat_interleave(1 << rshift, 0)[:M]
+    o = o + F.interpolate(rfull.unsqueeze(0), size=Fd, mode="linear").squeeze(0) if Fres != Fd else o + rfull
+    o.backward(gx.double())
+    # --- HIP
+    yc = y.cuda()
+    if training:
+        tr = ops.stats_tile_rows()
+        nt = (M + tr - 1) // tr
+        st = torch.empty(nt, 2, Fd)
+        for t in range(nt):
+            blk = y[t * tr:(t + 1) * tr].double()
+            st[t, 0] = blk.sum(0).float()
+            st[t, 1] = ((blk - blk.mean(0)) ** 2).sum(0).float()
+        rmc, rvc = rm.cuda(), rv.cuda()
+        co = ops.bn_finalize(st.cuda(), M, gamma.cuda(), beta.cuda(), rmc, rvc, 0.1, 1e-5)
+        assert (rmc.cpu() - rmd).abs().max() < 1e-6 and (rvc.cpu() - rvd).abs().max() < 1e-5
+    else:
+        co = ops.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    x = ops.bn_act_fwd(yc, co, True, resid.cuda(), Fres, rshift, M, Fd)
+    assert (x.cpu() - o.detach()).abs().max() < 1e-5
+    gy, dgamma, dbeta = ops.bn_relu_bwd(gx.cuda(), yc, co, gamma.cuda(), True, training, M, Fd)
+    assert (gy.cpu() - yd.grad).abs().max() < 2e-5 * max(1.0, yd.grad.abs().max().item())
+    assert (dgamma.cpu() - gd.grad).abs().max() < 1e-5 * max(1.0, gd.grad.abs().max().item()) * np.sqrt(M)
+    assert (dbeta.cpu() - bd.grad).abs().max() < 1e-5 * max(1.0, bd.grad.abs().max().item()) * np.sqrt(M)
+    # residual transpose
+    G = gx.cuda()
+    Mr = M >> rshift if rshift else M
+    if rshift and M % 2 == 0:
+        Gs = ops.pair_sum(G, M // 2, Fd)
+    else:
+        Gs = G
+    if not rshift or M % 2 == 0:
+        dst = torch.zeros(Mr, Fres, device="cuda")
+        if Fres == Fd:
+            dst += Gs
+        else:
+            ops.lerp_bwd_add(Gs, dst, Mr, Fd, Fres)
+        assert (dst.cpu() - rd.grad[:Mr]).abs().max() < 1e-5
