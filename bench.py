@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- SMPL meshes/sec, forward + backward + Adam, batch 256 per GPU (BASELINE.json configs[2]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one full reference train step (lib/core/base.py:122-148) on one synthetic batch that is
+already resident in HBM: FlatPose2Mesh forward (PoseNet + coarse-to-fine GCN), perm-reverse gather,
+joint regression, the five reference losses, backward, [gradient all-reduce], Adam.  Weak scaling:
+every rank owns `--batch` samples.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (FP32-MFMA contraction k_gemm_planes): algorithmic FLOPs of its
+                launches / their HIP-event time, against the 157.3 TFLOP/s dense FP32 MFMA peak
+  roofline_sparse  the Chebyshev-basis gather kernels (HBM-bound): algorithmic bytes / event time vs 8 TB/s
+  cpu_baseline  the oracle port of the reference CPU path (oracle/meshnet_oracle.py), same train step,
+                small batch, timed on this host's cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pose2mesh_release_amd import dist as p2m_dist  # noqa: E402
+from pose2mesh_release_amd import loss as p2m_loss  # noqa: E402
+from pose2mesh_release_amd import ops, optim, pose2mesh_net, synth  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense FP32 matrix peak
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec peak (achievable copy ceiling ~6300 GB/s)
+
+
+def synthetic_regressor(J, nv, seed=5):
+    """Sparse-ish row-stochastic joint regressor like J_regressor_h36m_correct.npy (107 nnz / 17 rows)."""
+    rng = np.random.default_rng(seed)
+    R = np.zeros((J, nv), dtype=np.float32)
+    for j in range(J):
+        idx = rng.choice(nv, size=6, replace=False)
+        w = rng.random(6).astype(np.float32)
+        R[j, idx] = w / w.sum()
+    return R
+
+
+class TrainStep:
+    """The reference train step (lib/core/base.py:122-148) on resident synthetic data."""
+
+    def __init__(self, device, B, joint_set, world, edge_loss=True, seed=123):
+        self.device, self.B = device, B
+        faces, graph_L, perm_rev, J = synth.make_graphs(joint_set)
+        self.J, self.nv = J, int(faces.max()) + 1
+        torch.manual_seed(seed)                                     # main/train.py:12
+        self.model = pose2mesh_net.get_model(J, graph_L).to(device).train()
+        self.opt = optim.FlatAdam(self.model.parameters(), lr=1e-3)          # funcs_utils.py:92-96
+        self.reducer = p2m_dist.BucketedAllReduce(self.opt.params, self.opt.offsets, self.opt.flat_grad) \
+            if world > 1 else None
+        self.losses = p2m_loss.get_loss(faces)
+        self.edge_loss = edge_loss
+        self.perm = torch.as_tensor(np.asarray(perm_rev)[:self.nv], dtype=torch.long, device=device)
+        self.Jreg = torch.from_numpy(synthetic_regressor(J, self.nv)).to(device)
+        g = torch.Generator().manual_seed(seed + int(os.environ.get("RANK", "0")))
+        self.pose2d = synth.pose2d_batch(B, J, seed + int(os.environ.get("RANK", "0"))).to(device)
+        self.gt_mesh = (torch.randn(B, self.nv, 3, generator=g) * 0.3).to(device)
+        self.gt_reg = (torch.randn(B, J, 3, generator=g) * 300).to(device)
+        self.gt_lift = (torch.randn(B, J, 3, generator=g) * 300).to(device)
+        self.one = torch.ones(B, 1, 1, device=device)
+        self.V0 = graph_L[0].shape[0]
+        self.graph_L = graph_L
+        self.faces = faces
+
+    def __call__(self):
+        m = self.model
+        self.opt.zero_grad()
+        pred_mesh, lift_pose = m(self.pose2d)
+        pred_mesh = pred_mesh[:, self.perm, :]                                        # base.py:130
+        pred_pose = torch.matmul(self.Jreg[None, :, :], pred_mesh * 1000)             # base.py:131
+        L = self.losses
+        loss = L[0](pred_mesh, self.gt_mesh, self.one) + 1e-1 * L[1](pred_mesh, self.gt_mesh) \
+            + 1e-3 * L[3](pred_pose, self.gt_reg, self.one) + 1e-3 * L[4](lift_pose, self.gt_lift, self.one)
+        if self.edge_loss:
+            loss = loss + 20 * L[2](pred_mesh, self.gt_mesh)                          # base.py:141-143
+        loss.backward()
+        scale = self.reducer.finish() if self.reducer is not None else 1.0
+        self.opt.step(scale)
+        return loss
+
+
+def cpu_baseline(joint_set, budget_s, edge_loss=True):
+    """Oracle port of the reference CPU path, same train step, on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import meshnet_oracle as mo
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    faces, graph_L, perm_rev, J = synth.make_graphs(joint_set)
+    nv = int(faces.max()) + 1
+    torch.manual_seed(123)
+    ref_model = pose2mesh_net.get_model(J, graph_L)                 # only to get identically-shaped weights
+    sd = {k: v.detach().clone() for k, v in ref_model.state_dict().items()}
+    del ref_model
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    glt = [mo.scipy_to_torch_coo(L) for L in mo.trim_graph_list(graph_L)]
+    losses = p2m_loss.get_loss(faces)
+    B = 8
+    perm = torch.as_tensor(np.asarray(perm_rev)[:nv], dtype=torch.long)
+    Jreg = torch.from_numpy(synthetic_regressor(J, nv))
+    g = torch.Generator().manual_seed(123)
+    pose2d = synth.pose2d_batch(B, J)
+    gt_mesh = torch.randn(B, nv, 3, generator=g) * 0.3
+    gt_j = torch.randn(B, J, 3, generator=g) * 300
+    one = torch.ones(B, 1, 1)
+
+    def step():
+        opt.zero_grad()
+        mesh, lift = mo.flat_forward(sd, glt, pose2d, joint_set == "mano", True)
+        mesh = mesh[:, perm, :]
+        pose = torch.matmul(Jreg[None], mesh * 1000)
+        loss = losses[0](mesh, gt_mesh, one) + 1e-1 * losses[1](mesh, gt_mesh) + 1e-3 * losses[3](pose, gt_j, one) \
+            + 1e-3 * losses[4](lift, gt_j, one)
+        if edge_loss:
+            loss = loss + 20 * losses[2](mesh, gt_mesh)
+        loss.backward()
+        opt.step()
+    step()                                    # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 3), "unit": "meshes/s", "cores": ncores, "kind": "port",
+            "sample": f"{n} train steps (fwd+bwd+Adam) at batch {B}, same synthetic SMPL-like mesh and losses, "
+                      f"torch {torch.__version__} CPU, {ncores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU (BASELINE.json: 256)")
+    ap.add_argument("--joint-set", default="coco", choices=["coco", "human36", "mano"])
+    ap.add_argument("--no-edge-loss", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = p2m_dist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    step = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timing:
+        ops.TIMER = ops.KernelTimer()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    timer, ops.TIMER = ops.TIMER, None
+
+    if rank == 0:
+        total = args.batch * world * args.steps
+        line = {
+            "metric": "SMPL meshes/sec fwd+bwd at batch 256" if args.joint_set != "mano"
+                      else "MANO meshes/sec fwd+bwd",
+            "value": round(total / dt, 2), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[2]: batch={args.batch}/GPU synthetic {args.joint_set} 2D poses "
+                                   f"(J={step.J}), SMPL-like hull mesh {step.nv} verts (padded {step.V0}), "
+                                   "FlatPose2Mesh fwd + 5 reference losses + bwd + Adam",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if world > 1 else 0},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            g = summ.get("gemm_planes_mfma")
+            if g:
+                ach = g["work"] / (g["ms"] * 1e-3) / 1e12
+                line["roofline"] = {"bound": "mfma", "kernel": "k_gemm_planes (v_mfma_f32_32x32x2_f32)",
+                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                    "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4)}
+            sp_ms = sum(summ[k]["ms"] for k in ("cheb_basis_fwd", "cheb_basis_bwd") if k in summ)
+            sp_b = sum(summ[k]["work"] for k in ("cheb_basis_fwd", "cheb_basis_bwd") if k in summ)
+            if sp_ms > 0:
+                ach = sp_b / (sp_ms * 1e-3) / 1e9
+                line["roofline_sparse"] = {"bound": "hbm", "kernel": "k_basis_fwd + k_basis_bwd",
+                                           "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                           "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None}
+            line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.joint_set, args.cpu_seconds, edge_loss=not args.no_edge_loss)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

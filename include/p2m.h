@@ -151,6 +151,14 @@ int p2m_chebconv_fwd(p2m_graph_t g, const float* X, const float* Wt, const float
                      float* T1, float* T2, float* Y, float* stats,
                      int32_t B, int32_t Fin, int32_t Fout, int32_t in_shift, void* stream);
 
+/* ---- optimizer step over a flat fp32 buffer ------------------------------------------------
+ * torch.optim.Adam semantics (lib/funcs_utils.py:92-96, stepped at lib/core/base.py:148): one fused
+ * launch for the whole model.  grad is multiplied by grad_scale first (1/world_size after a
+ * sum all-reduce).  step counts from 1.                                                         */
+int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+// Fused Adam over one flat fp32 parameter buffer (all 76 M parameters in a single launch).
+// Reference: torch.optim.Adam(model.parameters(), lr) built at lib/funcs_utils.py:92-96 and stepped at
+// lib/core/base.py:148 (defaults betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False).
+// Pure streaming: 16 B read (p,g,m,v) + 12 B written per parameter -> HBM-bound.
+#include "p2m_common.h"
+
+namespace p2m {
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long n4, long n, float lr, float b1, float b2,
+                                               float eps, float bc1, float bc2_sqrt, float grad_scale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+    float* pp = reinterpret_cast<float*>(&P);
+    float* gg = reinterpret_cast<float*>(&G);
+    float* mm = reinterpret_cast<float*>(&M);
+    float* vv = reinterpret_cast<float*>(&V);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float gr = gg[k] * grad_scale;
+      mm[k] = b1 * mm[k] + (1.f - b1) * gr;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gr * gr;
+      float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+      pp[k] -= (lr / bc1) * (mm[k] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  } else if (i == n4) {
+    for (long j = n4 * 4; j < n; j++) {  // tail (< 4 elements)
+      float gr = g[j] * grad_scale;
+      m[j] = b1 * m[j] + (1.f - b1) * gr;
+      v[j] = b2 * v[j] + (1.f - b2) * gr * gr;
+      p[j] -= (lr / bc1) * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+    }
+  }
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+extern "C" int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                             void* stream) {
+  P2M_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "null pointer, empty buffer or step < 1");
+  P2M_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+                "buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_adam, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n4, (long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  return check_launch("adam_step");
+}

@@ -31,6 +31,56 @@ def _req(t, name):
     return t
 
 
+class KernelTimer:
+    """Optional live per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+    Kernels are launched on torch's current stream, so torch.cuda.Event brackets exactly the launch.
+    Usage: ops.TIMER = KernelTimer(); ...; ops.TIMER.summary()."""
+
+    def __init__(self):
+        self.records = {}     # name -> list of (start, end, work)
+
+    def bracket(self, name, work):
+        return _Bracket(self, name, work)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[name] = {"launches": len(recs), "ms": ms, "work": float(sum(w for _, _, w in recs))}
+        return out
+
+
+class _Bracket:
+    def __init__(self, timer, name, work):
+        self.t, self.name, self.work = timer, name, work
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.e = torch.cuda.Event(enable_timing=True)
+        self.s.record()
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.t.records.setdefault(self.name, []).append((self.s, self.e, self.work))
+
+
+class _NoBracket:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOB = _NoBracket()
+TIMER = None
+
+
+def _timed(name, work):
+    return _NOB if TIMER is None else TIMER.bracket(name, work)
+
+
 class DeviceGraph:
     """One coarsening level baked on one GPU: merged CSR of L and 2LL-I (p2m_graph_create).
     Replaces the torch sparse COO tensor + per-forward .cuda() of lib/models/meshnet.py:61-62,81."""
@@ -101,16 +151,19 @@ def cheb_basis_fwd(g, X, B, F, in_shift):
     M = B * g.V
     T1 = torch.empty((M, F), device=X.device, dtype=torch.float32)
     T2 = torch.empty((M, F), device=X.device, dtype=torch.float32)
-    check(_lib.hip().p2m_cheb_basis_fwd(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
-          "p2m_cheb_basis_fwd")
+    with _timed("cheb_basis_fwd", 4.0 * M * F * (2.0 + 1.0 / (1 << in_shift))):     # algorithmic HBM bytes
+        check(_lib.hip().p2m_cheb_basis_fwd(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
+              "p2m_cheb_basis_fwd")
     return T1, T2
 
 
 def cheb_basis_bwd(g, d0, d1, d2, resid, B, F, out_shift):
     dX = torch.empty((B * (g.V >> out_shift), F), device=d0.device, dtype=torch.float32)
-    check(_lib.hip().p2m_cheb_basis_bwd(g.handle, _p(_req(d0, "d0")), _p(_req(d1, "d1")), _p(_req(d2, "d2")),
-                                        _p(resid if resid is None else _req(resid, "resid")), _p(dX), B, F,
-                                        out_shift, _stream()), "p2m_cheb_basis_bwd")
+    nbytes = 4.0 * B * g.V * F * ((4.0 if resid is not None else 3.0) + 1.0 / (1 << out_shift))
+    with _timed("cheb_basis_bwd", nbytes):
+        check(_lib.hip().p2m_cheb_basis_bwd(g.handle, _p(_req(d0, "d0")), _p(_req(d1, "d1")), _p(_req(d2, "d2")),
+                                            _p(resid if resid is None else _req(resid, "resid")), _p(dX), B, F,
+                                            out_shift, _stream()), "p2m_cheb_basis_bwd")
     return dX
 
 
@@ -134,9 +187,11 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
         st = torch.empty((nt, 2, N), device=dev, dtype=torch.float32)
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     c = [_p(t) for t in C] + [None] * (3 - len(C))
-    check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")),
-                                     _p(bias if bias is None else _req(bias, "bias")), c[0], c[1], c[2], nplanesC, Nc,
-                                     M, _p(st), _stream()), "p2m_gemm_planes")
+    mfma = (Ka % 32 == 0) and (Nc % 32 == 0)
+    with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", 2.0 * M * len(A) * Ka * N):   # algorithmic FLOPs
+        check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")),
+                                         _p(bias if bias is None else _req(bias, "bias")), c[0], c[1], c[2],
+                                         nplanesC, Nc, M, _p(st), _stream()), "p2m_gemm_planes")
     return C, st
 
 
@@ -157,8 +212,10 @@ def gemm_tn(A, Ka, a0_shift, G, M, N):
     P = torch.empty((nchunks, Ktot, N), device=G.device, dtype=torch.float32)
     Pdb = torch.empty((nchunks, N), device=G.device, dtype=torch.float32)
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
-    check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(G, "G")), N, M, chunk_rows, _p(P),
-                                 _p(Pdb), _stream()), "p2m_gemm_tn")
+    mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32
+    with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", 2.0 * M * Ktot * N):
+        check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(G, "G")), N, M, chunk_rows,
+                                     _p(P), _p(Pdb), _stream()), "p2m_gemm_tn")
     return P, Pdb, nchunks
 
 
