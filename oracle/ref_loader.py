@@ -34,20 +34,21 @@ class _Cfg:  # attribute bag
 _loaded = {}
 
 
-def load(target_joint_set: str = "human36"):
+def load(target_joint_set=None):
     """Returns a namespace with the reference modules: coarsening, graph_utils, meshnet,
     pose2mesh_net, posenet, cheby (graph_conv_cheby) and the fake cfg."""
     if not available():
         raise RuntimeError("reference tree not present at %s" % REF_ROOT)
     if "ns" in _loaded:
-        _loaded["ns"].cfg.DATASET.target_joint_set = target_joint_set
+        if target_joint_set is not None:
+            _loaded["ns"].cfg.DATASET.target_joint_set = target_joint_set
         return _loaded["ns"]
     lib = os.path.join(REF_ROOT, "lib")
     if lib not in sys.path:
         sys.path.insert(0, lib)
     cfg = _Cfg()
     cfg.DATASET = _Cfg()
-    cfg.DATASET.target_joint_set = target_joint_set
+    cfg.DATASET.target_joint_set = target_joint_set or "human36"
     cfg.MODEL = _Cfg()
     cfg.MODEL.posenet_pretrained = False
     cfg.MODEL.posenet_path = ""

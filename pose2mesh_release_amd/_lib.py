@@ -74,6 +74,9 @@ def hip():
     """The HIP library (loaded on first use)."""
     global _hip
     if _hip is None:
+        # torch ships its own libamdhip64: import it FIRST so that this library binds to the same HIP
+        # runtime instance (two runtimes in one process do not see each other's device memory).
+        import torch  # noqa: F401
         _hip = _load(os.path.join(LIBDIR, "libp2m_hip.so"), HIP_SYMBOLS)
     return _hip
 

@@ -1,0 +1,104 @@
+"""graph_conv_cheby -- drop-in for the reference's functional op
+(lib/models/backbones/cheby_graph_conv.py:5-42), same signature and semantics:
+
+    y = graph_conv_cheby(x, cl, bn, L, Fout, K)
+      x  : (B, V, Fin) fp32 on the GPU
+      cl : nn.Linear(Fin*K, Fout)   (weight column index = fin*K + k, as the reference stacks it)
+      bn : nn.BatchNorm1d(Fout) or None   (statistics over all B*V rows; running stats updated in train())
+      L  : rescaled Laplacian -- scipy sparse, torch sparse (what the reference passes) or an ops.DeviceGraph
+    returns (B, V, Fout); no activation inside (the caller applies ReLU, meshnet.py:100).
+
+Differentiable w.r.t. x, cl.weight, cl.bias, bn.weight, bn.bias.  K = 3 is the native kernel path
+(every Pose2Mesh layer); K = 1, 2 reuse it with zero-padded weight planes; K > 3 is not implemented.
+"""
+import torch
+
+from . import ops
+from ._lib import P2MError
+
+_graph_cache = {}
+
+
+def _device_graph(L, device):
+    if isinstance(L, ops.DeviceGraph):
+        return L
+    key = (id(L), torch.device(device).index)
+    hit = _graph_cache.get(key)
+    if hit is not None and hit[0] is L:
+        return hit[1]
+    g = ops.DeviceGraph(L, device)
+    if len(_graph_cache) > 256:
+        _graph_cache.clear()
+    _graph_cache[key] = (L, g)      # holding L keeps id(L) unique
+    return g
+
+
+class _ChebConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, g, bn, training):
+        B, V, Fin = x.shape
+        Fout = weight.shape[0]
+        if V != g.V:
+            raise P2MError(f"x has {V} vertices but the graph has {g.V}")
+        M = B * V
+        with torch.cuda.device(x.device):
+            xc = x.contiguous().float().view(M, Fin)
+            T1, T2 = ops.cheb_basis_fwd(g, xc, B, Fin, 0)
+            Wt, W2 = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)
+            stats = bn is not None and training
+            (y,), st = ops.gemm_planes([xc, T1, T2], Fin, 0, Wt, bias.contiguous(), M, Fout, 1, stats)
+            co = None
+            out = y
+            if bn is not None:
+                if training:
+                    co = ops.bn_finalize(st, M, gamma.contiguous(), beta.contiguous(),
+                                         bn.running_mean if bn.track_running_stats else None,
+                                         bn.running_var if bn.track_running_stats else None,
+                                         bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+                    if bn.track_running_stats:
+                        bn.num_batches_tracked.add_(1)
+                else:
+                    co = ops.bn_eval_coeffs(gamma.contiguous(), beta.contiguous(), bn.running_mean, bn.running_var,
+                                            bn.eps)
+                out = ops.bn_act_fwd(y, co, False, None, 0, 0, M, Fout)
+        ctx.stuff = (g, xc, T1, T2, y, co, W2, gamma, B, Fin, Fout, training, x.shape)
+        return out.view(B, V, Fout)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, xc, T1, T2, y, co, W2, gamma, B, Fin, Fout, training, xshape = ctx.stuff
+        M = B * g.V
+        with torch.cuda.device(gout.device):
+            gx = gout.contiguous().float().view(M, Fout)
+            dgamma = dbeta = None
+            if co is not None:
+                gy, dgamma, dbeta = ops.bn_relu_bwd(gx, y, co, gamma.contiguous(), False, training, M, Fout)
+            else:
+                gy = gx
+            P, Pdb, nch = ops.gemm_tn([xc, T1, T2], Fin, 0, gy, M, Fout)
+            dW, db = ops.weight_grad_unpack(P, Pdb, nch, Fout, Fin, 3)
+            d, _ = ops.gemm_planes([gy], Fout, 0, W2, None, M, 3 * Fin, 3, False)
+            dX = ops.cheb_basis_bwd(g, d[0], d[1], d[2], None, B, Fin, 0)
+        return dX.view(xshape), dW, db, dgamma, dbeta, None, None, None
+
+
+def graph_conv_cheby(x, cl, bn, L, Fout, K):
+    if not x.is_cuda:
+        raise P2MError("graph_conv_cheby (HIP) needs GPU tensors; this package has no CPU path")
+    B, V, Fin = x.shape
+    if cl.weight.shape != (Fout, Fin * K):
+        raise P2MError(f"cl.weight is {tuple(cl.weight.shape)}, expected {(Fout, Fin * K)}")
+    g = _device_graph(L, x.device)
+    weight = cl.weight
+    if K != 3:
+        if K not in (1, 2):
+            raise NotImplementedError("Chebyshev order K > 3 is not implemented (Pose2Mesh uses K = 3 everywhere)")
+        pad = weight.new_zeros(Fout, Fin, 3)
+        weight = torch.cat((weight.view(Fout, Fin, K), pad[:, :, K:]), dim=2).reshape(Fout, Fin * 3)
+    bias = cl.bias if cl.bias is not None else x.new_zeros(Fout)
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    training = bn.training if bn is not None else False
+    if bn is not None and not bn.training and not bn.track_running_stats:
+        training = True            # nn.BatchNorm semantics: no running stats -> always batch statistics
+    return _ChebConvFn.apply(x, weight, bias, gamma, beta, g, bn, training)

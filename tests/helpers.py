@@ -10,9 +10,10 @@ def numpy_state(sd_like, seed, bn_random=True):
     """Fill a MeshNet-shaped state dict from a numpy Generator (platform independent).
     Conv/fc weights ~ U(-s,s) with the reference's scales; BN affine and running stats randomised
     so eval-mode BN is not a near-identity."""
-    rng = np.random.default_rng(seed)
+    import zlib
     out = {}
     for k, v in sd_like.items():
+        rng = np.random.default_rng([seed, zlib.crc32(k.encode())])   # per-key stream: key order is irrelevant
         shp = tuple(v.shape)
         if k.endswith("num_batches_tracked"):
             out[k] = torch.zeros((), dtype=torch.long)
@@ -20,9 +21,9 @@ def numpy_state(sd_like, seed, bn_random=True):
             out[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shp).astype(np.float32)) if bn_random else torch.ones(shp)
         elif k.endswith("running_mean"):
             out[k] = torch.from_numpy(rng.normal(0, 0.1, shp).astype(np.float32)) if bn_random else torch.zeros(shp)
-        elif ".bn." in "." + k and k.endswith("weight"):
+        elif k.endswith("weight") and len(shp) == 1:          # BatchNorm affine (bn.N.* / batch_normN.*)
             out[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shp).astype(np.float32))
-        elif ".bn." in "." + k and k.endswith("bias"):
+        elif k.endswith("bias") and (".bn." in "." + k or "batch_norm" in k):
             out[k] = torch.from_numpy(rng.normal(0, 0.1, shp).astype(np.float32))
         elif k.endswith("weight"):
             s = np.sqrt(2.0 / (shp[0] + shp[1]))
@@ -64,3 +65,37 @@ def oracle_run(sd, gl_torch, x, mano, training, grad_seed=None):
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad}
     grads["__input__"] = x.grad
     return out.detach(), grads, {k: v.detach() for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# golden fixtures (tests/golden/*.npz, produced by the REAL reference -- see make_golden.py)
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+import scipy.sparse as _sp
+
+GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(_os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_graphs(joint_set):
+    """graph_L exactly as the reference's build_coarse_graphs returned it (list of scipy CSR, float64)."""
+    z = golden(f"graphs_{joint_set}.npz")
+    out = []
+    for i in range(int(z["num_levels"])):
+        n = int(z[f"L{i}_n"])
+        out.append(_sp.csr_matrix((z[f"L{i}_data"], z[f"L{i}_indices"], z[f"L{i}_indptr"]), shape=(n, n)))
+    return out, z["perm0"], z["perm_reverse"]
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_vertex_l2(a, b):
+    """BASELINE.json's parity metric: max over (sample, vertex) of ||v_new - v_ref||_2."""
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).norm(dim=-1).max())

@@ -1,0 +1,84 @@
+"""CPU, gloo, world_size 2: the data-parallel gradient exchange (dist.BucketedAllReduce) averages
+gradients exactly like a single process over the concatenated batch; bench.py's launch contract
+(RANK/WORLD_SIZE/MASTER_* from the environment) initialises correctly."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_setup(model):
+    params = [p for p in model.parameters()]
+    offsets, n = [], 0
+    for p in params:
+        offsets.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(n)
+    for p, o in zip(params, offsets):
+        p.grad = flat[o:o + p.numel()].view_as(p)
+    return params, offsets, flat
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from pose2mesh_release_amd import dist as pd
+    r, w, _ = pd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 33), torch.nn.ReLU(),
+                                torch.nn.Linear(33, 5))
+    params, offsets, flat = _flat_setup(model)
+    red = pd.BucketedAllReduce(params, offsets, flat, bucket_bytes=bucket_bytes)
+    g = torch.Generator().manual_seed(42)
+    X, Y = torch.randn(16, 20, generator=g), torch.randn(16, 5, generator=g)
+    xs, ys = X[rank * 8:(rank + 1) * 8], Y[rank * 8:(rank + 1) * 8]
+    for _ in range(2):                         # two steps: hooks/pending counters must re-arm
+        flat.zero_()
+        ((model(xs) - ys) ** 2).mean().backward()
+        scale = red.finish()
+        flat.mul_(scale)
+    if rank == 0:
+        torch.save({"flat": flat.clone(), "nb": len(red.buckets)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 30, 4096, 64])
+def test_bucketed_allreduce_matches_full_batch(tmp_path, bucket_bytes):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), bucket_bytes, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 33), torch.nn.ReLU(),
+                                torch.nn.Linear(33, 5))
+    params, offsets, flat = _flat_setup(model)
+    g = torch.Generator().manual_seed(42)
+    X, Y = torch.randn(16, 20, generator=g), torch.randn(16, 5, generator=g)
+    ((model(X) - Y) ** 2).mean().backward()       # mean over 16 == average of the two 8-sample means
+    assert (got["flat"] - flat).abs().max() < 1e-6
+    if bucket_bytes == 64:
+        assert got["nb"] > 3                       # really exercised several buckets
+    if bucket_bytes == 1 << 30:
+        assert got["nb"] == 1
+
+
+def test_single_process_is_a_noop():
+    from pose2mesh_release_amd import dist as pd
+    model = torch.nn.Linear(4, 4)
+    params, offsets, flat = _flat_setup(model)
+    red = pd.BucketedAllReduce(params, offsets, flat)
+    model(torch.ones(2, 4)).sum().backward()
+    before = flat.clone()
+    assert red.finish() == 1.0 and torch.equal(flat, before)
