@@ -40,7 +40,8 @@ def build_hip(force=False, verbose=False):
     deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
     if not force and not _stale(HIP_LIB, deps):
         return HIP_LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_LIB] + srcs
+    extra = os.environ.get("P2M_HIPCC_FLAGS", "").split()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", HIP_LIB] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -14,7 +14,11 @@
 
 namespace p2m {
 
-constexpr int ROWS_PER_BLOCK = 64;
+#ifndef P2M_BASIS_ROWS
+#define P2M_BASIS_ROWS 4           // rows per block (one per wave): small tiles keep an XCD's working window in its L2
+                                   // (measured B=256,V=11776,F=128: bwd 1.5 -> 2.6 TB/s going from 16 to 4)
+#endif
+constexpr int ROWS_PER_BLOCK = P2M_BASIS_ROWS;
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
   // observed dispatch: block b runs on XCD b % 8 -> give each XCD a contiguous range of logical ids
@@ -26,41 +30,49 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
   acc.z = fmaf(s, x.z, acc.z); acc.w = fmaf(s, x.w, acc.w);
 }
 
-template <int LPR>  // lanes per row, F = 4*LPR
+// One wave = ONE vertex row x S = 64/LPR samples (LPR = F/4 lanes per sample).  The CSR row (col, a, b) is
+// wave-uniform, so it is fetched with scalar loads and the vector memory pipe only carries the feature
+// gathers; there is no divergence on the row length.
+template <int LPR>
 __global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restrict__ X, float* __restrict__ T1,
-                                                    float* __restrict__ T2, int in_shift, int tiles_per_sample) {
+                                                    float* __restrict__ T2, int B, int in_shift, int tiles_per_group) {
   constexpr int F = LPR * 4;
-  constexpr int RP = 256 / LPR;  // rows per pass
+  constexpr int S = 64 / LPR;
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = lid / tiles_per_sample;
-  const int tile = lid - b * tiles_per_sample;
-  const int t = threadIdx.x;
-  const int rloc = t / LPR, f4 = (t % LPR) * 4;
-  const float* Xb = X + (long)b * (g.V >> in_shift) * F + f4;
-  const long obase = (long)b * g.V * F + f4;
+  const int group = lid / tiles_per_group;
+  const int tile = lid - group * tiles_per_group;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int sample = group * S + lane / LPR;
+  const int f4 = (lane % LPR) * 4;
+  const bool active = sample < B;
+  const float* Xb = X + (long)(active ? sample : 0) * (g.V >> in_shift) * F + f4;
+  const long obase = (long)(active ? sample : 0) * g.V * F + f4;
   int row_end = (tile + 1) * ROWS_PER_BLOCK;
   if (row_end > g.V) row_end = g.V;
-  for (int row = tile * ROWS_PER_BLOCK + rloc; row < row_end; row += RP) {
+  for (int row = tile * ROWS_PER_BLOCK + wave; row < row_end; row += 4) {
     const int s = g.rowptr[row], e = g.rowptr[row + 1];
     float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
     int j = s;
     for (; j + 4 <= e; j += 4) {
-      int c0 = g.col[j], c1 = g.col[j + 1], c2 = g.col[j + 2], c3 = g.col[j + 3];
-      float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(c0 >> in_shift) * F);
-      float4 x1 = *reinterpret_cast<const float4*>(Xb + (long)(c1 >> in_shift) * F);
-      float4 x2 = *reinterpret_cast<const float4*>(Xb + (long)(c2 >> in_shift) * F);
-      float4 x3 = *reinterpret_cast<const float4*>(Xb + (long)(c3 >> in_shift) * F);
+      const int c0 = g.col[j], c1 = g.col[j + 1], c2 = g.col[j + 2], c3 = g.col[j + 3];
+      const float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(c0 >> in_shift) * F);
+      const float4 x1 = *reinterpret_cast<const float4*>(Xb + (long)(c1 >> in_shift) * F);
+      const float4 x2 = *reinterpret_cast<const float4*>(Xb + (long)(c2 >> in_shift) * F);
+      const float4 x3 = *reinterpret_cast<const float4*>(Xb + (long)(c3 >> in_shift) * F);
       fma4(t1, g.a[j], x0); fma4(t2, g.b[j], x0);
       fma4(t1, g.a[j + 1], x1); fma4(t2, g.b[j + 1], x1);
       fma4(t1, g.a[j + 2], x2); fma4(t2, g.b[j + 2], x2);
       fma4(t1, g.a[j + 3], x3); fma4(t2, g.b[j + 3], x3);
     }
     for (; j < e; j++) {
-      float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(g.col[j] >> in_shift) * F);
+      const float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(g.col[j] >> in_shift) * F);
       fma4(t1, g.a[j], x0); fma4(t2, g.b[j], x0);
     }
-    *reinterpret_cast<float4*>(T1 + obase + (long)row * F) = t1;
-    *reinterpret_cast<float4*>(T2 + obase + (long)row * F) = t2;
+    if (active) {
+      *reinterpret_cast<float4*>(T1 + obase + (long)row * F) = t1;
+      *reinterpret_cast<float4*>(T2 + obase + (long)row * F) = t2;
+    }
   }
 }
 
@@ -86,52 +98,56 @@ __global__ void k_basis_fwd_generic(Graph g, const float* __restrict__ X, float*
 }
 
 // dX[p] = sum_{children r of p} ( d0[r] + resid[r] + sum_j a_j d1[col_j] + b_j d2[col_j] )
+// same wave mapping as the forward: one wave = one OUTPUT row x S samples.
 template <int LPR>
 __global__ __launch_bounds__(256) void k_basis_bwd(Graph g, const float* __restrict__ d0, const float* __restrict__ d1,
                                                     const float* __restrict__ d2, const float* __restrict__ resid,
-                                                    float* __restrict__ dX, int out_shift, int tiles_per_sample) {
+                                                    float* __restrict__ dX, int B, int out_shift, int tiles_per_group) {
   constexpr int F = LPR * 4;
-  constexpr int RP = 256 / LPR;
+  constexpr int S = 64 / LPR;
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int b = lid / tiles_per_sample;
-  const int tile = lid - b * tiles_per_sample;
-  const int t = threadIdx.x;
-  const int rloc = t / LPR, f4 = (t % LPR) * 4;
-  const long ibase = (long)b * g.V * F + f4;
+  const int group = lid / tiles_per_group;
+  const int tile = lid - group * tiles_per_group;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int sample = group * S + lane / LPR;
+  const int f4 = (lane % LPR) * 4;
+  const bool active = sample < B;
+  const long ibase = (long)(active ? sample : 0) * g.V * F + f4;
   const int Vout = g.V >> out_shift;
-  const long obase = (long)b * Vout * F + f4;
+  const long obase = (long)(active ? sample : 0) * Vout * F + f4;
   const int nchild = 1 << out_shift;
   int p_end = (tile + 1) * ROWS_PER_BLOCK;
   if (p_end > Vout) p_end = Vout;
-  for (int p = tile * ROWS_PER_BLOCK + rloc; p < p_end; p += RP) {
+  for (int p = tile * ROWS_PER_BLOCK + wave; p < p_end; p += 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ch = 0; ch < nchild; ch++) {
       const int row = (p << out_shift) + ch;
-      float4 v = *reinterpret_cast<const float4*>(d0 + ibase + (long)row * F);
+      const float4 v = *reinterpret_cast<const float4*>(d0 + ibase + (long)row * F);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       if (resid != nullptr) {
-        float4 q = *reinterpret_cast<const float4*>(resid + ibase + (long)row * F);
+        const float4 q = *reinterpret_cast<const float4*>(resid + ibase + (long)row * F);
         acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
       }
       const int s = g.rowptr[row], e = g.rowptr[row + 1];
       int j = s;
       for (; j + 2 <= e; j += 2) {
-        int c0 = g.col[j], c1 = g.col[j + 1];
-        float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
-        float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
-        float4 u1 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c1 * F);
-        float4 w1 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c1 * F);
+        const int c0 = g.col[j], c1 = g.col[j + 1];
+        const float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
+        const float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
+        const float4 u1 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c1 * F);
+        const float4 w1 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c1 * F);
         fma4(acc, g.a[j], u0); fma4(acc, g.b[j], w0);
         fma4(acc, g.a[j + 1], u1); fma4(acc, g.b[j + 1], w1);
       }
       for (; j < e; j++) {
-        int c0 = g.col[j];
-        float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
-        float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
+        const int c0 = g.col[j];
+        const float4 u0 = *reinterpret_cast<const float4*>(d1 + ibase + (long)c0 * F);
+        const float4 w0 = *reinterpret_cast<const float4*>(d2 + ibase + (long)c0 * F);
         fma4(acc, g.a[j], u0); fma4(acc, g.b[j], w0);
       }
     }
-    *reinterpret_cast<float4*>(dX + obase + (long)p * F) = acc;
+    if (active) *reinterpret_cast<float4*>(dX + obase + (long)p * F) = acc;
   }
 }
 
@@ -174,12 +190,12 @@ extern "C" int p2m_cheb_basis_fwd(p2m_graph_t gh, const float* X, float* T1, flo
   P2M_CHECK_ARG(in_shift == 0 || (g.V % 2 == 0), "virtual un-pool needs an even vertex count");
   hipStream_t s = (hipStream_t)stream;
   const int tps = cdiv(g.V, ROWS_PER_BLOCK);
-  const int grid = B * tps;
+  auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_basis_fwd<8>,  dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
-    case 64:  hipLaunchKernelGGL(k_basis_fwd<16>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
-    case 128: hipLaunchKernelGGL(k_basis_fwd<32>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
-    case 256: hipLaunchKernelGGL(k_basis_fwd<64>, dim3(grid), dim3(256), 0, s, g, X, T1, T2, in_shift, tps); break;
+    case 32:  hipLaunchKernelGGL(k_basis_fwd<8>,  grid(8),  dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
+    case 64:  hipLaunchKernelGGL(k_basis_fwd<16>, grid(16), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
+    case 128: hipLaunchKernelGGL(k_basis_fwd<32>, grid(32), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
+    case 256: hipLaunchKernelGGL(k_basis_fwd<64>, grid(64), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
     default: {
       long tot = (long)B * g.V * F;
       hipLaunchKernelGGL(k_basis_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, X, T1, T2, B, F, in_shift);
@@ -199,12 +215,12 @@ extern "C" int p2m_cheb_basis_bwd(p2m_graph_t gh, const float* d0, const float* 
   hipStream_t s = (hipStream_t)stream;
   const int Vout = g.V >> out_shift;
   const int tps = cdiv(Vout, ROWS_PER_BLOCK);
-  const int grid = B * tps;
+  auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_basis_bwd<8>,  dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
-    case 64:  hipLaunchKernelGGL(k_basis_bwd<16>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
-    case 128: hipLaunchKernelGGL(k_basis_bwd<32>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
-    case 256: hipLaunchKernelGGL(k_basis_bwd<64>, dim3(grid), dim3(256), 0, s, g, d0, d1, d2, resid, dX, out_shift, tps); break;
+    case 32:  hipLaunchKernelGGL(k_basis_bwd<8>,  grid(8),  dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, out_shift, tps); break;
+    case 64:  hipLaunchKernelGGL(k_basis_bwd<16>, grid(16), dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, out_shift, tps); break;
+    case 128: hipLaunchKernelGGL(k_basis_bwd<32>, grid(32), dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, out_shift, tps); break;
+    case 256: hipLaunchKernelGGL(k_basis_bwd<64>, grid(64), dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, out_shift, tps); break;
     default: {
       long tot = (long)B * Vout * F;
       hipLaunchKernelGGL(k_basis_bwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, d0, d1, d2, resid, dX, B, F, out_shift);

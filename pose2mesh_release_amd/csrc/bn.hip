@@ -210,33 +210,49 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long
   }
 }
 
+// gy = gamma*invstd*(go - c0 - yhat*c1): each thread owns ONE float4 column group (its coefficients live in
+// registers) and walks rows, so the kernel is three streaming float4 accesses per element.
+constexpr int APPLY_ROWS_PER_BLOCK = 256;
+template <int LPR>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ gx, const float* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ coef,
-                                                       int relu, float* __restrict__ gy, long M, int F) {
-  const int F4 = F >> 2;
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * F4) return;
-  long r = idx / F4;
-  int f = (int)(idx - r * F4) * 4;
-  float g[4], v[4];
-  *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gx + r * F + f);
-  *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(y + r * F + f);
-  float o[4];
+                                                       int relu, float* __restrict__ gy, long M) {
+  constexpr int F = LPR * 4;
+  constexpr int RP = 256 / LPR;
+  const int t = threadIdx.x;
+  const int rloc = t / LPR, f = (t % LPR) * 4;
+  float sc[4], sh[4], k[4], a0[4], a1[4];
+  *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + f);
+  *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + f);
+  float mu[4], is[4], ga[4];
+  *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(mean + f);
+  *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(invstd + f);
+  *reinterpret_cast<float4*>(ga) = *reinterpret_cast<const float4*>(gamma + f);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    float go = g[i];
-    if (relu && fmaf(v[i], scale[f + i], shift[f + i]) <= 0.f) go = 0.f;
-    float k = gamma[f + i] * invstd[f + i];
-    if (coef != nullptr) {
-      float yhat = (v[i] - mean[f + i]) * invstd[f + i];
-      o[i] = k * (go - coef[f + i] - yhat * coef[F + f + i]);
-    } else {
-      o[i] = k * go;
-    }
+    k[i] = ga[i] * is[i];
+    // gy = k*go - k*c0 - k*c1*yhat,  yhat = (v - mu)*is   ->   gy = k*go + a0 + a1*(v - mu)
+    const float c0 = coef ? coef[f + i] : 0.f, c1 = coef ? coef[F + f + i] : 0.f;
+    a1[i] = -k[i] * c1 * is[i];
+    a0[i] = -k[i] * c0;
   }
-  *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+  const long r0 = (long)blockIdx.x * APPLY_ROWS_PER_BLOCK;
+  long r1 = r0 + APPLY_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  for (long r = r0 + rloc; r < r1; r += RP) {
+    float g[4], v[4], o[4];
+    *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gx + r * F + f);
+    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(y + r * F + f);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float go = g[i];
+      if (relu && fmaf(v[i], sc[i], sh[i]) <= 0.f) go = 0.f;
+      o[i] = fmaf(k[i], go, fmaf(a1[i], v[i] - mu[i], a0[i]));
+    }
+    *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F) {
@@ -360,10 +376,17 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
                                 const float* mean, const float* invstd, const float* gamma, const float* coef,
                                 int32_t relu, float* gy, int64_t M, int32_t F, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
-  P2M_CHECK_ARG(F % 4 == 0, "feature width must be a multiple of 4");
-  long tot = M * (F / 4);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, gx, y, scale, shift, mean,
-                     invstd, gamma, coef, relu, gy, (long)M, F);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = cdiv(M, APPLY_ROWS_PER_BLOCK);
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
+    default:
+      set_error("p2m_bn_bwd_apply: unsupported feature width %d (need 32/64/128/256)", F);
+      return P2M_ERR_INVALID;
+  }
   return check_launch("bn_bwd_apply");
 }
 

@@ -454,8 +454,16 @@ __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* _
     int fout = (int)(idx % Fout);
     long kk = idx / Fout;
     int k = (int)(kk / Fin), fin = (int)(kk % Fin);
-    double s = 0.0;
-    for (int c = 0; c < nchunks; c++) s += (double)P[(long)c * tot + idx];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // 4 independent chains: the loop is load-latency bound
+    int c = 0;
+    for (; c + 4 <= nchunks; c += 4) {
+      s0 += (double)P[(long)c * tot + idx];
+      s1 += (double)P[(long)(c + 1) * tot + idx];
+      s2 += (double)P[(long)(c + 2) * tot + idx];
+      s3 += (double)P[(long)(c + 3) * tot + idx];
+    }
+    for (; c < nchunks; c++) s0 += (double)P[(long)c * tot + idx];
+    const double s = (s0 + s1) + (s2 + s3);
     long o = (long)fout * Fin * K + (long)fin * K + k;
     dW[o] = accumulate ? dW[o] + (float)s : (float)s;
   }

@@ -195,7 +195,7 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
     return C, st
 
 
-def pick_chunk_rows(M, ntiles_out, target_blocks=1024, quantum=32):
+def pick_chunk_rows(M, ntiles_out, target_blocks=768, quantum=32):
     """Rows per split for the weight-gradient contraction: enough blocks to fill 256 CUs."""
     nchunks = max(1, min((target_blocks + ntiles_out - 1) // ntiles_out, (M + 255) // 256))
     rows = (M + nchunks - 1) // nchunks

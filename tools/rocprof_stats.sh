@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$REPO/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python "$REPO/bench.py" "$@" > "$REPO/gpurun_out/${TAG}_bench.log" 2>&1
+timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python "$REPO/bench.py" "$@" > "$REPO/gpurun_out/${TAG}_bench.log" 2>&1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} "$REPO/gpurun_out/${TAG}_kernel_stats.csv" \;
 grep '^{' "$REPO/gpurun_out/${TAG}_bench.log" | tail -1
 head -40 "$REPO/gpurun_out/${TAG}_kernel_stats.csv" | cut -c1-200
