@@ -69,6 +69,16 @@ int p2m_cheb_basis_bwd(p2m_graph_t g, const float* d0, const float* d1, const fl
                        const float* resid, float* dX,
                        int32_t B, int32_t F, int32_t out_shift, void* stream);
 
+/* Narrow-output convolution by linearity (the final 64 -> 3 layer, cheby_graph_conv.py:25-37 re-associated):
+ *   y = [x|Lx|L2x] W == P0 + L P1 + L2 P2 with P = x [W0|W1|W2] computed first by p2m_gemm_planes.
+ * combine: Y[r, c] = bias[c] + P[r, c] + sum_j a_j P[col_j, nc+c] + b_j P[col_j, 2nc+c],  c < nc <= 4;
+ *          P rows are ldp floats wide (ldp >= 3 nc), Y is [B*V, nc].
+ * expand (its backward): E[r] = [ G[r] | (L G)[r] | (L2 G)[r] | 0.. ], G: [B*V, nc], E rows lde floats wide. */
+int p2m_cheb_combine_small(p2m_graph_t g, const float* P, int32_t ldp, int32_t nc, const float* bias,
+                           float* Y, int32_t B, void* stream);
+int p2m_cheb_expand_small(p2m_graph_t g, const float* G, int32_t nc, float* E, int32_t lde, int32_t B,
+                          void* stream);
+
 /* ---- weights ------------------------------------------------------------------------------
  * nn.Linear(Fin*K, Fout).weight is [Fout][fin*K + k] (cheby_graph_conv.py:32-37).  Packs it into
  *   Wt [k*Fin + fin][Fout]   (B operand of the forward contraction, K-major)

@@ -27,6 +27,8 @@ HIP_SYMBOLS = {
     "p2m_graph_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 4)]),
     "p2m_cheb_basis_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_cheb_basis_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "p2m_cheb_combine_small": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "p2m_cheb_expand_small": (_c.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "p2m_weight_pack": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,

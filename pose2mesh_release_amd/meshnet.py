@@ -59,6 +59,11 @@ class _Layer:
             setattr(self, k, v)
 
 
+def _narrow(L):
+    """Layers whose 3*Fout output columns fit one 32-wide MFMA tile take the project-then-combine path."""
+    return (not L.has_bn) and K_CHEB * L.Fout <= 32 and L.Fin % 32 == 0 and not L.first_in_block and L.Fout <= 4
+
+
 class _MeshNetFn(torch.autograd.Function):
     """forward/backward of the whole coarse-to-fine stack (lib/models/meshnet.py:80-117)."""
 
@@ -93,6 +98,17 @@ class _MeshNetFn(torch.autograd.Function):
             if L.first_in_block:
                 block_in, block_in_shift, block_in_F = cur, cur_shift, L.Fin
             W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
+            if _narrow(L):
+                # final 64 -> 3 conv by linearity: project to 9 columns on the MFMA first, then combine sparsely
+                Wp = torch.nn.functional.pad(W.view(L.Fout, L.Fin, K_CHEB).permute(1, 2, 0).reshape(L.Fin, -1),
+                                             (0, 32 - K_CHEB * L.Fout)).contiguous()
+                (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False)
+                out = ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
+                del Pm
+                if keep:
+                    saved.append((cur, cur_shift, None, None, None, None, Wp))
+                cur, cur_shift = out, 0
+                continue
             T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
             Wt, W2 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep)
             need_stats = L.has_bn and training
@@ -166,6 +182,19 @@ class _MeshNetFn(torch.autograd.Function):
                     (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False)
                     G = dh.view(B * J, L.Fout)
                 g_cur = G
+            if _narrow(L):
+                Wp = W2
+                E = ops.cheb_expand_small(gph, g_cur, L.Fout, 32, B)
+                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
+                dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1)
+                nco = K_CHEB * L.Fout
+                grads[P[f"cl.{L.ci}.weight"]] = dW32[:nco].view(K_CHEB, L.Fout, L.Fin).permute(1, 2, 0) \
+                    .reshape(L.Fout, L.Fin * K_CHEB).contiguous()
+                grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
+                (dX,), _ = ops.gemm_planes([E], 32, 0, Wp.t().contiguous(), None, M, L.Fin, 1, False)
+                saved[L.ci] = None
+                g_cur = dX
+                continue
             # ---- BN + ReLU backward -> gy
             if L.has_bn:
                 gamma = params[P[f"bn.{L.ci}.weight"]]

@@ -167,6 +167,27 @@ def cheb_basis_bwd(g, d0, d1, d2, resid, B, F, out_shift):
     return dX
 
 
+def cheb_combine_small(g, P, nc, bias, B):
+    """Y = P0 + L P1 + L2 P2 (+bias) on nc <= 4 columns; P: [B*V, ldp]."""
+    M = B * g.V
+    Y = torch.empty((M, nc), device=P.device, dtype=torch.float32)
+    with _timed("cheb_small", 4.0 * M * (P.shape[1] + nc)):
+        check(_lib.hip().p2m_cheb_combine_small(g.handle, _p(_req(P, "P")), P.shape[1], nc,
+                                                _p(bias if bias is None else _req(bias, "bias")), _p(Y), B, _stream()),
+              "p2m_cheb_combine_small")
+    return Y
+
+
+def cheb_expand_small(g, G, nc, lde, B):
+    """E = [G | L G | L2 G | 0] with rows lde wide; G: [B*V, nc]."""
+    M = B * g.V
+    E = torch.empty((M, lde), device=G.device, dtype=torch.float32)
+    with _timed("cheb_small", 4.0 * M * (lde + nc)):
+        check(_lib.hip().p2m_cheb_expand_small(g.handle, _p(_req(G, "G")), nc, _p(E), lde, B, _stream()),
+              "p2m_cheb_expand_small")
+    return E
+
+
 def weight_pack(W, Fin, K, need_w2=True):
     Fout = W.shape[0]
     Wt = torch.empty((K * Fin, Fout), device=W.device, dtype=torch.float32)
