@@ -83,14 +83,17 @@ int p2m_cheb_expand_small(p2m_graph_t g, const float* G, int32_t nc, float* E, i
  * nn.Linear(Fin*K, Fout).weight is [Fout][fin*K + k] (cheby_graph_conv.py:32-37).  Packs it into
  *   Wt [k*Fin + fin][Fout]   (B operand of the forward contraction, K-major)
  *   W2 [Fout][k*Fin + fin]   (B operand of dZ = g W; may be NULL)
+ *   W3 [k*Fout + fout][fin]  (B operand of the fused backward dX = [g|Lg|L2g] W3; may be NULL)
  * K=1 gives a plain transpose (used for fc, meshnet.py:36-37).                                */
-int p2m_weight_pack(const float* W, float* Wt, float* W2, int32_t Fout, int32_t Fin, int32_t K,
+int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, int32_t Fout, int32_t Fin, int32_t K,
                     void* stream);
 /* Sums `nchunks` partial gradients P[chunk][k*Fin+fin][Fout], Pdb[chunk][Fout] produced by
  * p2m_gemm_tn and writes dW in nn.Linear layout [Fout][fin*K+k] and db[Fout].
- * accumulate!=0 adds into dW/db instead of overwriting.                                        */
+ * accumulate!=0 adds into dW/db instead of overwriting.  layout 1: P[chunk][fin][k*Fout+fout] (the
+ * gradient taken as X^T [g|Lg|L2g]).  pdb_stride = row stride of Pdb (the N of the p2m_gemm_tn call).  */
 int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
-                           int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, void* stream);
+                           int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, int32_t layout,
+                           int32_t pdb_stride, void* stream);
 
 /* ---- dense contraction (FP32 MFMA, v_mfma_f32_32x32x2_f32) ---------------------------------
  * C[r, n] = sum_p sum_k A_p[r (>> a0_shift if p==0), k] * Bm[p*Ka + k, n]  + bias[n]
@@ -108,12 +111,13 @@ int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t n
 /* rows per BatchNorm partial tile and the number of tiles for M rows */
 int32_t p2m_stats_tile_rows(void);
 
-/* Weight-gradient contraction: P[chunk][p*Ka + k][n] = sum_{r in chunk} A_p[r][k] * G[r][n],
+/* Weight-gradient contraction (G = [G0|G1|G2], nplanesG column planes of width Gc, N = nplanesG*Gc):
+ *   P[chunk][p*Ka + k][n] = sum_{r in chunk} A_p[r][k] * G[r][n],
  * Pdb[chunk][n] = sum_{r in chunk} G[r][n];  chunk c covers rows [c*chunk_rows, (c+1)*chunk_rows).
  * (autograd of cheby_graph_conv.py:37 / meshnet.py:105.)                                       */
 int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                int32_t a0_shift, const float* G, int32_t N, int64_t M, int64_t chunk_rows,
-                float* P, float* Pdb, void* stream);
+                int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
+                int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, void* stream);
 
 /* ---- BatchNorm1d over B*V rows + ReLU + residual (cheby_graph_conv.py:39, meshnet.py:100,108-115)
  * finalize: reduces the GEMM's partials to batch mean / biased var, writes
@@ -121,7 +125,8 @@ int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplan
  *   running_mean/var (momentum, unbiased var) exactly like nn.BatchNorm1d in train().         */
 int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
-                    float* mean, float* invstd, float* scale, float* shift, int32_t N, void* stream);
+                    float* mean, float* invstd, float* scale, float* shift, int32_t N, int32_t tile_rows,
+                    void* stream);
 /* eval(): scale/shift/invstd from the running statistics. */
 int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* mean, float* invstd, float* scale,
@@ -153,6 +158,23 @@ int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* str
 /* dst[r, i] += sum_j w(j,i) g[r, j]: transpose of the feature-axis resize (meshnet.py:109,114);
  * g: [M, F], dst: [M, Fres].                                                                   */
 int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream);
+
+/* ---- fused Chebyshev convolution: recurrence + contraction in ONE persistent kernel -------------
+ *   C[r, :] = [ A[r] | (L A)[r] | (L2 A)[r] ] * Bm (+ bias) (+ addend[r]),   r = b*V + v, M = B*V rows
+ * A: [B*(V>>a_shift), Ka] (Ka % 32 == 0), Bm: [3*Ka, N] (N in {64,128,256}), C: [M, N] or, with
+ * pair_out, [M/2, N] holding the sum of the two children of every coarse vertex (un-pool backward).
+ * stats (optional, excludes pair_out): BatchNorm partials per T-row tile, T = p2m_fused_stats_tile_rows(N),
+ *   [ceil(M/T) + 4][2][N] (the last tile may write up to 3 phantom rows);
+ * E1/E2 (optional, a_shift == 0): the gathered planes L A and L2 A, [M, Ka] each, written as a by-product
+ * (the backward uses them for dW = X^T [g|Lg|L2g]).
+ * forward: A = x, Bm = Wt  (cheby_graph_conv.py:16-37).  backward: A = dL/dy, Bm = W3 (L symmetric).
+ * Bm must be given FRAGMENT-MAJOR (p2m_frag_pack of the row-major [3*Ka, N] matrix): the MFMA waves then fetch
+ * the B operands of 4 k-steps with one coalesced 16-byte load per lane.                                       */
+int p2m_frag_pack(const float* Bm, float* Bpk, int32_t Ktot, int32_t N, void* stream);
+int p2m_cheb_gemm_fused(p2m_graph_t g, const float* A, int32_t Ka, int32_t a_shift, const float* Bm,
+                        const float* bias, const float* addend, float* C, int32_t N, int32_t pair_out,
+                        float* stats, float* E1, float* E2, int32_t B, void* stream);
+int32_t p2m_fused_stats_tile_rows(int32_t N);   /* rows per BatchNorm partial of the fused kernel (64 for N=128, else 32) */
 
 /* ---- composite: one Chebyshev graph convolution (cheby_graph_conv.py:5-40, K=3) ------------
  * Y = [X|L X|L2 X] Wt + bias, BatchNorm partials in `stats` (may be NULL).  T1/T2 are caller

@@ -29,14 +29,19 @@ HIP_SYMBOLS = {
     "p2m_cheb_basis_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_cheb_combine_small": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "p2m_cheb_expand_small": (_c.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
-    "p2m_weight_pack": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "p2m_weight_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "p2m_cheb_gemm_fused": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32,
+                                       _vp]),
+    "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "p2m_fused_stats_tile_rows": (_i32, [_i32]),
     "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                    _i64, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),
-    "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp,
+                               _vp]),
     "p2m_bn_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
-                                   _i32, _vp]),
+                                   _i32, _i32, _vp]),
     "p2m_bn_eval_coeffs": (_c.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "p2m_bn_bwd_blocks": (_i32, [_i64, _i32]),

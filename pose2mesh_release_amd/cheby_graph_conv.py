@@ -44,7 +44,7 @@ class _ChebConvFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             xc = x.contiguous().float().view(M, Fin)
             T1, T2 = ops.cheb_basis_fwd(g, xc, B, Fin, 0)
-            Wt, W2 = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)
+            Wt, W2, _ = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)
             stats = bn is not None and training
             (y,), st = ops.gemm_planes([xc, T1, T2], Fin, 0, Wt, bias.contiguous(), M, Fout, 1, stats)
             co = None

@@ -299,11 +299,10 @@ using namespace p2m;
 
 extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                               float* invstd, float* scale, float* shift, int32_t N, void* stream) {
+                               float* invstd, float* scale, float* shift, int32_t N, int32_t tile_rows, void* stream) {
   P2M_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift && N > 0 && M > 0, "null pointer or empty shape");
   P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
-  const int tile_rows = p2m_stats_tile_rows();
-  P2M_CHECK_ARG(ntiles == cdiv(M, tile_rows), "ntiles does not match M");
+  P2M_CHECK_ARG(tile_rows > 0 && ntiles == cdiv(M, tile_rows), "ntiles does not match M / tile_rows");
   hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, stats, ntiles,
                      (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift, N);

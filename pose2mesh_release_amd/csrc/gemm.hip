@@ -267,7 +267,8 @@ __global__ void k_naive_tile_stats(const float* __restrict__ Y, float* __restric
 // ---------------------------------------------------------------------------------------------
 struct TnArgs {
   const float* A[3];
-  const float* G;
+  const float* G[3];   // nplanesG column planes of width Gc (N = nplanesG * Gc)
+  int Gc;
   float* P;
   float* Pdb;
   long M, chunk_rows;
@@ -318,6 +319,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
   const int ash = (ap == 0) ? g.a0_shift : 0;
   const int g_r = t / (BN / 4), g_c4 = (t % (BN / 4)) * 4;
   const bool g_ok = (n0 + g_c4) < g.N;
+  const int gq = g_ok ? (n0 + g_c4) / g.Gc : 0;
+  const int gcol = (n0 + g_c4) - gq * g.Gc;
+  const float* Gp = g.G[gq];
 
   float4 ra[4], rg[GPASS];
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
     for (int ps = 0; ps < GPASS; ps++) {
       long r = r0 + ps * GROWS + g_r;
       if (g_ok && r < r_end)
-        rg[ps] = *reinterpret_cast<const float4*>(g.G + r * g.N + n0 + g_c4);
+        rg[ps] = *reinterpret_cast<const float4*>(Gp + r * g.Gc + gcol);
       else
         rg[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
       dbs.x += rg[ps].x; dbs.y += rg[ps].y; dbs.z += rg[ps].z; dbs.w += rg[ps].w;
@@ -418,12 +422,16 @@ __global__ void k_naive_gemm_tn(TnArgs g) {
     const float* Ap = g.A[p];
     int sh = p == 0 ? g.a0_shift : 0;
     float acc = 0.f;
-    for (long r = r_begin; r < r_end; r++) acc = fmaf(Ap[(r >> sh) * g.Ka + k], g.G[r * g.N + n], acc);
+    const int q = n / g.Gc;
+    const float* Gq = g.G[q] + (n - q * g.Gc);
+    for (long r = r_begin; r < r_end; r++) acc = fmaf(Ap[(r >> sh) * g.Ka + k], Gq[r * g.Gc], acc);
     g.P[(long)chunk * nout + o] = acc;
   }
   if (g.Pdb != nullptr && o < g.N) {
     float s = 0.f;
-    for (long r = r_begin; r < r_end; r++) s += g.G[r * g.N + o];
+    const int q = o / g.Gc;
+    const float* Gq = g.G[q] + (o - q * g.Gc);
+    for (long r = r_begin; r < r_end; r++) s += Gq[r * g.Gc];
     g.Pdb[(long)chunk * g.N + o] = s;
   }
 }
@@ -432,7 +440,7 @@ __global__ void k_naive_gemm_tn(TnArgs g) {
 // weight pack / gradient unpack
 // ---------------------------------------------------------------------------------------------
 __global__ void k_weight_pack(const float* __restrict__ W, float* __restrict__ Wt, float* __restrict__ W2,
-                              int Fout, int Fin, int K) {
+                              float* __restrict__ W3, int Fout, int Fin, int K) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)Fout * Fin * K;
   if (idx >= tot) return;
@@ -443,17 +451,25 @@ __global__ void k_weight_pack(const float* __restrict__ W, float* __restrict__ W
   float v = W[(long)fout * Fin * K + (long)fin * K + k];
   Wt[idx] = v;
   if (W2) W2[(long)fout * Fin * K + kk] = v;
+  if (W3) W3[((long)k * Fout + fout) * Fin + fin] = v;     // [k*Fout + fout][fin]: B operand of dX = [g|Lg|L2g] W3
 }
 
 __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks,
                                      float* __restrict__ dW, float* __restrict__ db, int Fout, int Fin, int K,
-                                     int accumulate) {
+                                     int accumulate, int layout, int pdb_stride) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)Fout * Fin * K;
   if (idx < tot) {
-    int fout = (int)(idx % Fout);
-    long kk = idx / Fout;
-    int k = (int)(kk / Fin), fin = (int)(kk % Fin);
+    int fout, k, fin;
+    if (layout == 0) {            // P[chunk][k*Fin + fin][fout]
+      fout = (int)(idx % Fout);
+      long kk = idx / Fout;
+      k = (int)(kk / Fin); fin = (int)(kk % Fin);
+    } else {                      // P[chunk][fin][k*Fout + fout]   (weight gradient taken as X^T [g|Lg|L2g])
+      long nn = idx % ((long)K * Fout);
+      fin = (int)(idx / ((long)K * Fout));
+      k = (int)(nn / Fout); fout = (int)(nn % Fout);
+    }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // 4 independent chains: the loop is load-latency bound
     int c = 0;
     for (; c + 4 <= nchunks; c += 4) {
@@ -469,7 +485,7 @@ __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* _
   }
   if (db != nullptr && Pdb != nullptr && idx < Fout) {
     double s = 0.0;
-    for (int c = 0; c < nchunks; c++) s += (double)Pdb[(long)c * Fout + idx];
+    for (int c = 0; c < nchunks; c++) s += (double)Pdb[(long)c * pdb_stride + idx];
     db[idx] = accumulate ? db[idx] + (float)s : (float)s;
   }
 }
@@ -521,20 +537,23 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
 }
 
 extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                           int32_t a0_shift, const float* G, int32_t N, int64_t M, int64_t chunk_rows, float* P,
-                           float* Pdb, void* stream) {
-  P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
-  P2M_CHECK_ARG(A0 && G && P && Ka > 0 && N > 0 && chunk_rows > 0, "null pointer or empty shape");
+                           int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
+                           int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, void* stream) {
+  P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesG >= 1 && nplanesG <= 3, "plane count must be 1..3");
+  const int N = nplanesG * Gc;
+  P2M_CHECK_ARG(A0 && G0 && P && Ka > 0 && Gc > 0 && chunk_rows > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
   if (M <= 0) return P2M_OK;
   TnArgs g;
   g.A[0] = A0; g.A[1] = A1; g.A[2] = A2;
   for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
-  g.G = G; g.P = P; g.Pdb = Pdb; g.M = M; g.chunk_rows = chunk_rows;
+  g.G[0] = G0; g.G[1] = G1; g.G[2] = G2; g.Gc = Gc;
+  for (int p = 0; p < nplanesG; p++) P2M_CHECK_ARG(g.G[p] != nullptr, "missing G plane");
+  g.P = P; g.Pdb = Pdb; g.M = M; g.chunk_rows = chunk_rows;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = nplanesA * Ka; g.N = N;
   const int nchunks = cdiv(M, chunk_rows);
   hipStream_t s = (hipStream_t)stream;
-  const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (g.Ktot >= 32);
+  const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (Gc % 4 == 0) && (g.Ktot >= 32);
   if (!mfma_ok) {
     g.nkt = g.ntn = 0;
     int nout = g.Ktot * N;
@@ -553,19 +572,20 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   return check_launch("gemm_tn");
 }
 
-extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, int32_t Fout, int32_t Fin, int32_t K,
+extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, int32_t Fout, int32_t Fin, int32_t K,
                                void* stream) {
   P2M_CHECK_ARG(W && Wt && Fout > 0 && Fin > 0 && K > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
-  hipLaunchKernelGGL(k_weight_pack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, W, Wt, W2, Fout, Fin, K);
+  hipLaunchKernelGGL(k_weight_pack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, W, Wt, W2, W3, Fout, Fin, K);
   return check_launch("weight_pack");
 }
 
 extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
-                                      int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, void* stream) {
+                                      int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, int32_t layout,
+                                      int32_t pdb_stride, void* stream) {
   P2M_CHECK_ARG(P && dW && Fout > 0 && Fin > 0 && K > 0 && nchunks > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
   hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
-                     dW, db, Fout, Fin, K, accumulate);
+                     dW, db, Fout, Fin, K, accumulate, layout, pdb_stride);
   return check_launch("weight_grad_unpack");
 }

@@ -109,16 +109,25 @@ class _MeshNetFn(torch.autograd.Function):
                     saved.append((cur, cur_shift, None, None, None, None, Wp))
                 cur, cur_shift = out, 0
                 continue
-            T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
-            Wt, W2 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep)
             need_stats = L.has_bn and training
-            (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats)
+            fwd_fused = ops.fused_supported(L.Fin, L.Fout)
+            bwd_fused = ops.fused_supported(L.Fout, L.Fin)
+            Wt, W2, W3 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep and not bwd_fused, need_w3=keep and bwd_fused)
+            if fwd_fused:          # recurrence + contraction in one kernel: the basis planes never reach HBM
+                T1 = T2 = None
+                y, st, _ = ops.cheb_gemm_fused(g, cur, L.Fin, cur_shift, Wt, bvec, None, L.Fout, B, stats=need_stats)
+                tile_rows = ops.fused_stats_tile_rows(L.Fout)
+            else:
+                T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
+                (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats)
+                tile_rows = None
             co = None
             if L.has_bn:
                 bn = net.bn[L.ci]
                 gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
                 if training:
-                    co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+                    co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                         tile_rows)
                     bn.num_batches_tracked.add_(1)
                 else:
                     co = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
@@ -129,13 +138,13 @@ class _MeshNetFn(torch.autograd.Function):
             else:
                 out = y                                               # final conv: no BN, no ReLU (:52-55,99)
             if keep:
-                saved.append((cur, cur_shift, T1, T2, y, co, W2))
+                saved.append((cur, cur_shift, T1, T2, y, co, W3 if bwd_fused else W2))
             cur, cur_shift = out, 0
             if L.last_in_block:
                 if L.block == 0:                                      # fc lift (:104-106)
                     h = cur.view(B, J * L.Fout)
                     fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
-                    fwt, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
+                    fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
                     (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False)
                     if keep:
                         fc_saved = h
@@ -202,17 +211,27 @@ class _MeshNetFn(torch.autograd.Function):
                 grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = dgamma, dbeta
             else:
                 gy = g_cur
-            # ---- weight gradient
-            Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
-            dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB)
-            grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
-            del Pw, Pb
-            # ---- dZ planes and basis backward
-            d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
             has_res = L.first_in_block and 1 <= L.block <= nblk - 2
             Fblk = net.CL_F[L.block][-1]
             fuse_res = has_res and (L.Fin == Fblk)
-            dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
+            if ops.fused_supported(L.Fout, L.Fin):
+                # dX = [gy | L gy | L2 gy] W3 in one kernel (L symmetric); its gathered planes give
+                # dW = X^T [gy | L gy | L2 gy] without ever forming the basis of X
+                dX, _, (E1, E2) = ops.cheb_gemm_fused(gph, gy, L.Fout, 0, W2, None, G if fuse_res else None, L.Fin, B,
+                                                      pair_out=bool(x_shift), want_planes=True)
+                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
+                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
+                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                del Pw, Pb, E1, E2
+            else:
+                if T1 is None:          # forward was fused: rebuild the (small) basis for this odd-shaped layer
+                    T1, T2 = ops.cheb_basis_fwd(gph, X, B, L.Fin, x_shift)
+                Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
+                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB)
+                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                del Pw, Pb
+                d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
+                dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
             if has_res and not fuse_res:                              # transpose of the feature resize
                 Gs = ops.pair_sum(G, M >> 1, Fblk) if x_shift else G
                 ops.lerp_bwd_add(Gs, dX, M >> x_shift, Fblk, L.Fin)

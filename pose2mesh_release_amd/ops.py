@@ -188,13 +188,50 @@ def cheb_expand_small(g, G, nc, lde, B):
     return E
 
 
-def weight_pack(W, Fin, K, need_w2=True):
+def weight_pack(W, Fin, K, need_w2=True, need_w3=False):
+    """Wt [k*Fin+fin][Fout], W2 [Fout][k*Fin+fin] (optional), W3 [k*Fout+fout][Fin] (optional)."""
     Fout = W.shape[0]
     Wt = torch.empty((K * Fin, Fout), device=W.device, dtype=torch.float32)
     W2 = torch.empty((Fout, K * Fin), device=W.device, dtype=torch.float32) if need_w2 else None
-    check(_lib.hip().p2m_weight_pack(_p(_req(W, "weight")), _p(Wt), _p(W2), Fout, Fin, K, _stream()),
+    W3 = torch.empty((K * Fout, Fin), device=W.device, dtype=torch.float32) if need_w3 else None
+    check(_lib.hip().p2m_weight_pack(_p(_req(W, "weight")), _p(Wt), _p(W2), _p(W3), Fout, Fin, K, _stream()),
           "p2m_weight_pack")
-    return Wt, W2
+    return Wt, W2, W3
+
+
+def cheb_gemm_fused(g, A, Ka, a_shift, Bm, bias, addend, N, B, pair_out=False, stats=False, want_planes=False):
+    """C = [A | L A | L2 A] Bm (+bias)(+addend).  Returns (C, stats or None, (E1, E2) or None)."""
+    M = B * g.V
+    dev = A.device
+    C = torch.empty((M >> 1 if pair_out else M, N), device=dev, dtype=torch.float32)
+    tr = int(_lib.hip().p2m_fused_stats_tile_rows(N))
+    st = torch.empty(((M + tr - 1) // tr + 4, 2, N), device=dev, dtype=torch.float32) if stats else None
+    E1 = torch.empty((M, Ka), device=dev, dtype=torch.float32) if want_planes else None
+    E2 = torch.empty((M, Ka), device=dev, dtype=torch.float32) if want_planes else None
+    Bpk = torch.empty_like(_req(Bm, "B"))                    # fragment-major copy of the (tiny) weight matrix
+    check(_lib.hip().p2m_frag_pack(_p(Bm), _p(Bpk), 3 * Ka, N, _stream()), "p2m_frag_pack")
+    with _timed("cheb_gemm_fused", 2.0 * M * 3 * Ka * N):
+        check(_lib.hip().p2m_cheb_gemm_fused(g.handle, _p(_req(A, "A")), Ka, a_shift, _p(Bpk),
+                                             _p(bias if bias is None else _req(bias, "bias")),
+                                             _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
+                                             int(pair_out), _p(st), _p(E1), _p(E2), B, _stream()),
+              "p2m_cheb_gemm_fused")
+    return C, st, ((E1, E2) if want_planes else None)
+
+
+def fused_stats_tile_rows(N):
+    return int(_lib.hip().p2m_fused_stats_tile_rows(N))
+
+
+# The fused (gather-in-GEMM) kernel is correct and tested, but on the coarsening-tree vertex order its gathers
+# miss L2 35 % of the time and it only breaks even with basis-kernel + plane-GEMM (DESIGN.md section 6), so the
+# network uses it only when asked: P2M_FUSED=1.
+import os as _os
+USE_FUSED = _os.environ.get("P2M_FUSED", "0") == "1"
+
+
+def fused_supported(Ka, N):
+    return USE_FUSED and Ka % 32 == 0 and N in (64, 128, 256)
 
 
 def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
@@ -225,7 +262,11 @@ def pick_chunk_rows(M, ntiles_out, target_blocks=768, quantum=32):
 
 
 def gemm_tn(A, Ka, a0_shift, G, M, N):
-    """Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks)."""
+    """G: one [M, N] tensor or a list of column planes [M, N/len(G)].
+    Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks)."""
+    Gl = list(G) if isinstance(G, (list, tuple)) else [G]
+    G = Gl[0]
+    Gc = N // len(Gl)
     Ktot = len(A) * Ka
     ntiles = ((Ktot + 127) // 128) * ((N + 127) // 128)
     chunk_rows = pick_chunk_rows(M, ntiles)
@@ -233,30 +274,37 @@ def gemm_tn(A, Ka, a0_shift, G, M, N):
     P = torch.empty((nchunks, Ktot, N), device=G.device, dtype=torch.float32)
     Pdb = torch.empty((nchunks, N), device=G.device, dtype=torch.float32)
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
-    mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32
+    mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32 and Gc % 4 == 0
+    gp = [_p(_req(t, "G plane")) for t in Gl] + [None] * (3 - len(Gl))
     with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", 2.0 * M * Ktot * N):
-        check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(G, "G")), N, M, chunk_rows,
-                                     _p(P), _p(Pdb), _stream()), "p2m_gemm_tn")
+        check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, gp[0], gp[1], gp[2], len(Gl), Gc, M,
+                                     chunk_rows, _p(P), _p(Pdb), _stream()), "p2m_gemm_tn")
     return P, Pdb, nchunks
 
 
-def weight_grad_unpack(P, Pdb, nchunks, Fout, Fin, K, dW=None, db=None):
+def weight_grad_unpack(P, Pdb, nchunks, Fout, Fin, K, dW=None, db=None, layout=0):
+    """layout 0: P[c][k*Fin+fin][fout]; layout 1: P[c][fin][k*Fout+fout].  Output in nn.Linear layout."""
     acc = 1 if dW is not None else 0
     if dW is None:
         dW = torch.empty((Fout, Fin * K), device=P.device, dtype=torch.float32)
         db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
-    check(_lib.hip().p2m_weight_grad_unpack(_p(P), _p(Pdb), nchunks, _p(dW), _p(db), Fout, Fin, K, acc, _stream()),
-          "p2m_weight_grad_unpack")
+    check(_lib.hip().p2m_weight_grad_unpack(_p(P), _p(Pdb), nchunks, _p(dW), _p(db), Fout, Fin, K, acc, layout,
+                                            Pdb.shape[1], _stream()), "p2m_weight_grad_unpack")
     return dW, db
 
 
-def bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps):
+def bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps, tile_rows=None):
+    """stats: per-tile partials [>= ceil(M/tile_rows)][2][N] from p2m_gemm_planes (128-row tiles) or
+    p2m_cheb_gemm_fused (64-row tiles)."""
     N = gamma.shape[0]
+    if tile_rows is None:
+        tile_rows = stats_tile_rows()
+    ntiles = (M + tile_rows - 1) // tile_rows
     co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)  # mean, invstd, scale, shift
-    check(_lib.hip().p2m_bn_finalize(_p(stats), stats.shape[0], M, _p(_req(gamma, "bn.weight")),
+    check(_lib.hip().p2m_bn_finalize(_p(stats), ntiles, M, _p(_req(gamma, "bn.weight")),
                                      _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
                                      float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
-                                     _stream()), "p2m_bn_finalize")
+                                     tile_rows, _stream()), "p2m_bn_finalize")
     return co
 
 

@@ -115,10 +115,11 @@ def test_gemm_tn_and_unpack(ops, M, Ka, N, planes, shift):
 def test_weight_pack(ops):
     Fout, Fin, K = 64, 32, 3
     W = torch.randn(Fout, Fin * K)
-    Wt, W2 = ops.weight_pack(W.cuda(), Fin, K)
+    Wt, W2, W3 = ops.weight_pack(W.cuda(), Fin, K, need_w2=True, need_w3=True)
     ref = W.view(Fout, Fin, K).permute(2, 1, 0).reshape(K * Fin, Fout)
     assert torch.equal(Wt.cpu(), ref)
     assert torch.equal(W2.cpu(), ref.t().contiguous())
+    assert torch.equal(W3.cpu(), W.view(Fout, Fin, K).permute(2, 0, 1).reshape(K * Fout, Fin))
 
 
 @pytest.mark.parametrize("M,Fd,Fres,rshift,training", [(1000, 64, 64, 0, True), (2048, 256, 64, 0, True),
@@ -178,3 +179,61 @@ def test_bn_relu_residual_fwd_bwd(ops, M, Fd, Fres, rshift, training):
         else:
             ops.lerp_bwd_add(Gs, dst, Mr, Fd, Fres)
         assert (dst.cpu() - rd.grad[:Mr]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("V,Ka,N,shift,pair,B", [(96, 64, 128, 0, False, 5), (184, 256, 256, 1, False, 3),
+                                                 (1472, 128, 128, 1, True, 2), (736, 128, 64, 0, False, 3),
+                                                 (368, 32, 64, 0, True, 4), (17, 64, 64, 0, False, 9),
+                                                 (1472, 256, 128, 0, True, 2)])
+def test_cheb_gemm_fused(ops, V, Ka, N, shift, pair, B):
+    """C = [A | L A | L2 A] Bm + bias (+addend) with BatchNorm partials / gathered planes / pair-sum output,
+    against fp64 dense algebra (cheby_graph_conv.py:16-37 and its backward form)."""
+    L = _rand_graph(V, V + 1)
+    g = ops.DeviceGraph(L, "cuda:0")
+    Ld = torch.from_numpy(L.toarray())
+    L2 = 2 * Ld @ Ld - torch.eye(V, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(V + Ka + N)
+    As = torch.randn(B, V >> shift, Ka, generator=gen)
+    A = As.repeat_interleave(1 << shift, dim=1).double()
+    Bm = torch.randn(3 * Ka, N, generator=gen) / np.sqrt(3 * Ka)
+    bias = torch.randn(N, generator=gen)
+    add = torch.randn(B * V, N, generator=gen)
+    Z = torch.cat([A, torch.einsum("vw,bwf->bvf", Ld, A), torch.einsum("vw,bwf->bvf", L2, A)], dim=2)
+    ref = (Z.reshape(B * V, 3 * Ka) @ Bm.double()) + bias.double() + add.double()
+    M = B * V
+    want_planes = (shift == 0)
+    C, st, planes = ops.cheb_gemm_fused(g, As.cuda().view(-1, Ka).contiguous(), Ka, shift, Bm.cuda(), bias.cuda(),
+                                        add.cuda(), N, B, pair_out=pair, stats=not pair, want_planes=want_planes)
+    torch.cuda.synchronize()
+    if pair:
+        refp = ref.view(M // 2, 2, N).sum(1)
+        assert (C.cpu() - refp).abs().max() < 5e-5
+    else:
+        assert (C.cpu() - ref).abs().max() < 3e-5
+        tr = ops.fused_stats_tile_rows(N)
+        nt = (M + tr - 1) // tr
+        for t in range(nt):
+            blk = ref[t * tr:(t + 1) * tr]
+            assert (st[t, 0].cpu() - blk.sum(0)).abs().max() < 1e-3
+            assert (st[t, 1].cpu() - ((blk - blk.mean(0)) ** 2).sum(0)).abs().max() < 2e-3
+        # the finalize kernel digests these partials
+        gamma, beta = torch.ones(N).cuda(), torch.zeros(N).cuda()
+        co = ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5, tr)
+        assert (co[0].cpu() - ref.mean(0)).abs().max() < 1e-5
+        assert (co[1].cpu() - 1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-4
+    if want_planes:
+        assert (planes[0].cpu().view(B, V, Ka) - Z[..., Ka:2 * Ka]).abs().max() < 5e-6
+        assert (planes[1].cpu().view(B, V, Ka) - Z[..., 2 * Ka:]).abs().max() < 1e-5
+
+
+def test_gemm_tn_with_planes_and_layout1(ops):
+    """dW = X^T [g | E1 | E2] unpacked to nn.Linear layout (the fused backward's weight gradient)."""
+    M, Fin, Fout = 1500, 64, 128
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(M, Fin, generator=gen)
+    G = [torch.randn(M, Fout, generator=gen) for _ in range(3)]
+    P, Pdb, nch = ops.gemm_tn([X.cuda()], Fin, 0, [t.cuda() for t in G], M, 3 * Fout)
+    dW, db = ops.weight_grad_unpack(P, Pdb, nch, Fout, Fin, 3, layout=1)
+    ref = torch.stack([G[k].double().t() @ X.double() for k in range(3)], dim=2)      # [Fout][Fin][k]
+    assert (dW.cpu() - ref.reshape(Fout, Fin * 3)).abs().max() < 2e-4
+    assert (db.cpu() - G[0].double().sum(0)).abs().max() < 1e-3
