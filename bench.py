@@ -51,7 +51,7 @@ def synthetic_regressor(J, nv, seed=5):
 class TrainStep:
     """The reference train step (lib/core/base.py:122-148) on resident synthetic data."""
 
-    def __init__(self, device, B, joint_set, world, edge_loss=True, seed=123):
+    def __init__(self, device, B, joint_set, world, edge_loss=True, seed=123, stock_losses=False):
         self.device, self.B = device, B
         faces, graph_L, perm_rev, J = synth.make_graphs(joint_set)
         self.J, self.nv = J, int(faces.max()) + 1
@@ -62,6 +62,9 @@ class TrainStep:
             if world > 1 else None
         self.losses = p2m_loss.get_loss(faces)
         self.edge_loss = edge_loss
+        self.stock_losses = stock_losses
+        self.mesh_loss = p2m_loss.FusedMeshLoss(faces, perm_rev, synthetic_regressor(J, int(faces.max()) + 1),
+                                                w_normal=1e-1, w_edge=20.0 if edge_loss else 0.0, w_joint=1e-3)
         self.perm = torch.as_tensor(np.asarray(perm_rev)[:self.nv], dtype=torch.long, device=device)
         self.Jreg = torch.from_numpy(synthetic_regressor(J, self.nv)).to(device)
         g = torch.Generator().manual_seed(seed + int(os.environ.get("RANK", "0")))
@@ -78,6 +81,14 @@ class TrainStep:
         m = self.model
         self.opt.zero_grad()
         pred_mesh, lift_pose = m(self.pose2d)
+        if not self.stock_losses:
+            # base.py:130-143 (gather, J-regression, vertex/normal/edge/joint losses) in one fused HIP call
+            mesh_total, _ = self.mesh_loss(pred_mesh, self.gt_mesh, self.gt_reg, self.one, self.one)
+            loss = mesh_total + 1e-3 * self.losses[4](lift_pose, self.gt_lift, self.one)
+            loss.backward()
+            scale = self.reducer.finish() if self.reducer is not None else 1.0
+            self.opt.step(scale)
+            return loss
         pred_mesh = pred_mesh[:, self.perm, :]                                        # base.py:130
         pred_pose = torch.matmul(self.Jreg[None, :, :], pred_mesh * 1000)             # base.py:131
         L = self.losses
@@ -152,6 +163,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--stock-losses", action="store_true", help="use the stock-torch loss modules instead of p2m_mesh_loss")
     args = ap.parse_args()
 
     rank, world, local = p2m_dist.init_from_env()
@@ -160,7 +172,8 @@ def main():
             print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    step = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss)
+    step = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss,
+                     stock_losses=args.stock_losses)
 
     def barrier():
         if world > 1:

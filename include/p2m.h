@@ -183,6 +183,19 @@ int p2m_chebconv_fwd(p2m_graph_t g, const float* X, const float* Wt, const float
                      float* T1, float* T2, float* Y, float* stats,
                      int32_t B, int32_t Fin, int32_t Fout, int32_t in_shift, void* stream);
 
+/* ---- mesh losses of the train step, value AND gradient (lib/core/base.py:130-143, lib/core/loss.py) --------
+ * losses[0..3] = L1(pred_mesh, gt_mesh)*w_vertex, normal-vector loss*w_normal, edge-length loss*w_edge,
+ * L1(J_regressor @ (pred_mesh*1000), gt_pose)*w_joint, where pred_mesh[b, v] = cam_mesh[b, perm[v]] (the
+ * perm-reverse gather of base.py:130).  grad_cam (optional) receives d(sum of the four)/d cam_mesh, [B, V0, 3],
+ * zero on fake vertices.  faces: [F,3] int32; vf_ptr/vf_idx: CSR vertex -> (face*3 + corner); jreg: dense
+ * [J, nv]; valid_*: per-sample masks [B] or NULL.  workspace: p2m_mesh_loss_workspace(...) floats.           */
+int64_t p2m_mesh_loss_workspace(int32_t B, int32_t nv, int32_t F, int32_t J);
+int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_t nv, const float* gt_mesh,
+                  const float* valid_mesh, const int32_t* faces, int32_t F, const int32_t* vf_ptr,
+                  const int32_t* vf_idx, const float* jreg, int32_t J, const float* gt_pose,
+                  const float* valid_pose, float w_vertex, float w_normal, float w_edge, float w_joint,
+                  float* workspace, float* losses, float* grad_cam, int32_t B, void* stream);
+
 /* ---- optimizer step over a flat fp32 buffer ------------------------------------------------
  * torch.optim.Adam semantics (lib/funcs_utils.py:92-96, stepped at lib/core/base.py:148): one fused
  * launch for the whole model.  grad is multiplied by grad_scale first (1/world_size after a

@@ -66,3 +66,87 @@ def get_loss(faces):
     """loss.py:117-120: (vertex L1, normal, edge, regressed-joint L1, lifted-joint L1)."""
     return (CoordLoss(has_valid=True), NormalVectorLoss(faces), EdgeLengthLoss(faces), CoordLoss(has_valid=True),
             CoordLoss(has_valid=True))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused HIP path: the four mesh-side losses of the train step + their gradient in one C-ABI call
+# ---------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+import numpy as _np
+
+from . import _lib as _libmod
+
+
+class _MeshLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam_mesh, mod, gt_mesh, valid_mesh, gt_pose, valid_pose):
+        B, V0, _ = cam_mesh.shape
+        dev = cam_mesh.device
+        t = mod._tensors(dev)
+        cam = cam_mesh.contiguous().float()
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(cam) if need_grad else None
+        losses = torch.empty(4, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(_libmod.hip().p2m_mesh_loss_workspace(B, mod.nv, mod.nf, mod.J)), device=dev,
+                         dtype=torch.float32)
+
+        def p(x):
+            return None if x is None else _ct.c_void_p(x.data_ptr())
+
+        def flat(v):
+            return None if v is None else v.reshape(B).contiguous().float()
+        vm, vp = flat(valid_mesh), flat(valid_pose)
+        with torch.cuda.device(dev):
+            _libmod.check(_libmod.hip().p2m_mesh_loss(
+                p(cam), V0, p(t["perm"]), mod.nv, p(gt_mesh.contiguous().float()), p(vm), p(t["faces"]), mod.nf,
+                p(t["vf_ptr"]), p(t["vf_idx"]), p(t["jreg"]), mod.J, p(gt_pose.contiguous().float()), p(vp),
+                mod.w_vertex, mod.w_normal, mod.w_edge, mod.w_joint, p(ws), p(losses), p(grad), B,
+                _ct.c_void_p(torch.cuda.current_stream().cuda_stream)), "p2m_mesh_loss")
+        ctx.grad = grad
+        ctx.mark_non_differentiable(losses)
+        return losses.sum(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        return ctx.grad * g_total, None, None, None, None, None
+
+
+class FusedMeshLoss(nn.Module):
+    """loss = CoordLoss(pred_mesh, gt_mesh, valid) + w_normal*NormalVectorLoss + w_edge*EdgeLengthLoss
+            + w_joint*CoordLoss(J_regressor @ (pred_mesh*1000), gt_pose, valid)
+    with pred_mesh = cam_mesh[:, graph_perm_reverse[:nv]] -- i.e. lib/core/base.py:130-143 minus the PoseNet
+    term -- computed (value and gradient) by p2m_mesh_loss.  Returns (total, components[4]).
+    Set w_edge=0 before cfg.TRAIN.edge_loss_start, as the reference's epoch switch does."""
+
+    def __init__(self, faces, perm_reverse, joint_regressor, w_normal=1e-1, w_edge=20.0, w_joint=1e-3, w_vertex=1.0):
+        super().__init__()
+        faces = _np.asarray(faces, dtype=_np.int64)
+        self.nf = int(faces.shape[0])
+        self.nv = int(faces.max()) + 1
+        jr = _np.asarray(joint_regressor, dtype=_np.float32)
+        self.J = int(jr.shape[0])
+        assert jr.shape[1] == self.nv
+        corner = _np.arange(self.nf * 3)
+        vert = faces.reshape(-1)
+        order = _np.argsort(vert, kind="stable")
+        self._host = {
+            "perm": _np.ascontiguousarray(_np.asarray(perm_reverse)[:self.nv], dtype=_np.int32),
+            "faces": _np.ascontiguousarray(faces, dtype=_np.int32),
+            "vf_ptr": _np.concatenate([[0], _np.cumsum(_np.bincount(vert, minlength=self.nv))]).astype(_np.int32),
+            "vf_idx": _np.ascontiguousarray(corner[order], dtype=_np.int32),
+            "jreg": _np.ascontiguousarray(jr),
+        }
+        self.w_vertex, self.w_normal, self.w_edge, self.w_joint = float(w_vertex), float(w_normal), float(w_edge), \
+            float(w_joint)
+        self._dev = {}
+
+    def _tensors(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = {k: torch.from_numpy(v).to(device) for k, v in self._host.items()}
+            self._dev[device] = t
+        return t
+
+    def forward(self, cam_mesh, gt_mesh, gt_pose, valid_mesh=None, valid_pose=None):
+        return _MeshLossFn.apply(cam_mesh, self, gt_mesh, valid_mesh, gt_pose, valid_pose)

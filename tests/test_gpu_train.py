@@ -38,3 +38,39 @@ def test_train_step_runs_and_learns(hip_libs):
     for bn in step.model.pose2mesh.bn:
         if bn is not None:
             assert int(bn.num_batches_tracked) == 8
+
+
+def test_fused_mesh_loss_matches_stock_losses(hip_libs):
+    """p2m_mesh_loss (value + gradient) against the stock-torch losses that mirror lib/core/loss.py and
+    lib/core/base.py:130-143."""
+    import numpy as np
+    from pose2mesh_release_amd import loss as L, synth
+    import bench
+    _, faces = synth.hull_mesh(500, 3)
+    nv, V0, J, B = 500, 736, 17, 6
+    rng = np.random.default_rng(0)
+    perm_rev = rng.permutation(V0)
+    jreg = bench.synthetic_regressor(J, nv)
+    g = torch.Generator().manual_seed(1)
+    cam = (torch.randn(B, V0, 3, generator=g) * 0.3).cuda().requires_grad_(True)
+    gt_mesh = (torch.randn(B, nv, 3, generator=g) * 0.3).cuda()
+    gt_pose = (torch.randn(B, J, 3, generator=g) * 300).cuda()
+    vm = (torch.rand(B, 1, 1, generator=g) > 0.3).float().cuda()
+    vp = (torch.rand(B, 1, 1, generator=g) > 0.3).float().cuda()
+    stock = L.get_loss(faces)
+    perm = torch.as_tensor(perm_rev[:nv], dtype=torch.long, device="cuda")
+    pm = cam[:, perm, :]
+    pose = torch.matmul(torch.from_numpy(jreg).cuda()[None], pm * 1000)
+    parts = [stock[0](pm, gt_mesh, vm), 0.1 * stock[1](pm, gt_mesh), 20 * stock[2](pm, gt_mesh),
+             1e-3 * stock[3](pose, gt_pose, vp)]
+    sum(parts).backward()
+    ref_grad = cam.grad.clone()
+    cam2 = cam.detach().clone().requires_grad_(True)
+    fused = L.FusedMeshLoss(faces, perm_rev, jreg)
+    total, comp = fused(cam2, gt_mesh, gt_pose, vm, vp)
+    total.backward()
+    for a, b in zip(comp.tolist(), [float(p) for p in parts]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b))
+    assert (cam2.grad - ref_grad).abs().max() <= 2e-5 * ref_grad.abs().max()
+    fake = np.setdiff1d(np.arange(V0), perm_rev[:nv])
+    assert float(cam2.grad[:, torch.as_tensor(fake, device="cuda")].abs().max()) == 0.0
