@@ -12,6 +12,8 @@
 // (BN = 128 or 64), K chunk 32; each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles.
 // A 32x32x2 f32 MFMA takes 64 cycles, so the 4 LDS reads that feed 4 MFMAs are noise; what matters
 // is keeping 4+ independent accumulators in flight and double-buffering the HBM->LDS staging.
+#include <cstdlib>
+
 #include "p2m_common.h"
 
 namespace p2m {
@@ -45,15 +47,19 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
   return mt < ntm;
 }
 
-template <int BN>
+template <int BN, int KB>   // KB = K chunk staged per barrier (16: 34 KB LDS -> 3 blocks/CU; 32: 67 KB -> 2 blocks/CU)
 __global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
   constexpr int WTN = BN / 2;    // wave tile N
   constexpr int TN = WTN / 32;   // MFMA tiles along N per wave
   constexpr int TM = 2;          // wave tile M = 64
-  constexpr int BPASS = BN / 32; // float4 B loads per thread per chunk (32 x BN tile)
-  __shared__ float smem[2 * BM * AS_LD + 2 * BK * BN];
+  constexpr int LDA = KB + 1;    // [m][k] row stride: bank = (m + k) % 32 -> conflict-free fragment reads
+  constexpr int APASS = BM * KB / 4 / 256;        // float4 A loads per thread per chunk
+  constexpr int AROWS = 256 / (KB / 4);           // rows of A covered per pass
+  constexpr int BPASS = KB * BN / 4 / 256;        // float4 B loads per thread per chunk
+  constexpr int BROWS = 256 / (BN / 4);           // rows of B covered per pass
+  __shared__ float smem[2 * BM * LDA + 2 * KB * BN];
   float* As = smem;
-  float* Bs = smem + 2 * BM * AS_LD;
+  float* Bs = smem + 2 * BM * LDA;
 
   int mt, nt;
   if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
@@ -72,24 +78,23 @@ __global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int cpp = g.Ka / BK;              // chunks per plane
+  const int cpp = g.Ka / KB;              // chunks per plane
   const int nchunks = g.nplanesA * cpp;
 
   // staging registers
-  float4 ra[4];
+  float4 ra[APASS];
   float4 rb[BPASS];
-  const int a_row = t >> 3, a_k4 = (t & 7) * 4;
+  const int a_row = t / (KB / 4), a_k4 = (t % (KB / 4)) * 4;
   const int b_row = t / (BN / 4), b_c4 = (t % (BN / 4)) * 4;
-  constexpr int BROWS = 256 / (BN / 4);   // rows of B covered per pass (8 for BN=128, 16 for BN=64)
 
   auto load_chunk = [&](int kc) {
     const int p = kc / cpp;
-    const int k0 = (kc - p * cpp) * BK;
+    const int k0 = (kc - p * cpp) * KB;
     const float* Ap = g.A[p];
     const int sh = (p == 0) ? g.a0_shift : 0;
 #pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-      long r = m0 + ps * 32 + a_row;
+    for (int ps = 0; ps < APASS; ps++) {
+      long r = m0 + ps * AROWS + a_row;
       if (r < g.M)
         ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
       else
@@ -107,13 +112,13 @@ __global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
     }
   };
   auto store_chunk = [&](int buf) {
-    float* as = As + buf * BM * AS_LD;
+    float* as = As + buf * BM * LDA;
 #pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-      float* d = as + (ps * 32 + a_row) * AS_LD + a_k4;
+    for (int ps = 0; ps < APASS; ps++) {
+      float* d = as + (ps * AROWS + a_row) * LDA + a_k4;
       d[0] = ra[ps].x; d[1] = ra[ps].y; d[2] = ra[ps].z; d[3] = ra[ps].w;
     }
-    float* bs = Bs + buf * BK * BN;
+    float* bs = Bs + buf * KB * BN;
 #pragma unroll
     for (int ps = 0; ps < BPASS; ps++)
       *reinterpret_cast<float4*>(bs + (ps * BROWS + b_row) * BN + b_c4) = rb[ps];
@@ -126,13 +131,13 @@ __global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
   for (int kc = 0; kc < nchunks; kc++) {
     const int cur = kc & 1;
     if (kc + 1 < nchunks) load_chunk(kc + 1);
-    const float* as = As + cur * BM * AS_LD + (wm * 64 + l31) * AS_LD + lhi;
-    const float* bs = Bs + cur * BK * BN + lhi * BN + wn * WTN + l31;
+    const float* as = As + cur * BM * LDA + (wm * 64 + l31) * LDA + lhi;
+    const float* bs = Bs + cur * KB * BN + lhi * BN + wn * WTN + l31;
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ks++) {
+    for (int ks = 0; ks < KB / 2; ks++) {
       float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = as[i * 32 * AS_LD + 2 * ks];
+      for (int i = 0; i < TM; i++) a[i] = as[i * 32 * LDA + 2 * ks];
 #pragma unroll
       for (int j = 0; j < TN; j++) b[j] = bs[2 * ks * BN + j * 32];
 #pragma unroll
@@ -496,6 +501,14 @@ using namespace p2m;
 
 extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
 
+static int gemm_kb() {          // K chunk per barrier of k_gemm_planes (tuning knob, P2M_GEMM_KB=16|32)
+  static int kb = [] {
+    const char* e = getenv("P2M_GEMM_KB");
+    return (e && atoi(e) == 16) ? 16 : 32;
+  }();
+  return kb;
+}
+
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                                int32_t a0_shift, const float* Bm, const float* bias, float* C0, float* C1,
                                float* C2, int32_t nplanesC, int32_t Nc, int64_t M, float* stats, void* stream) {
@@ -527,11 +540,17 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   if (g.N % 128 == 0) {
     g.ntn = g.N / 128;
     int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    hipLaunchKernelGGL(k_gemm_planes<128>, dim3(grid), dim3(256), 0, s, g);
+    if (gemm_kb() == 16)
+      hipLaunchKernelGGL((k_gemm_planes<128, 16>), dim3(grid), dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((k_gemm_planes<128, 32>), dim3(grid), dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(g.N, 64);
     int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    hipLaunchKernelGGL(k_gemm_planes<64>, dim3(grid), dim3(256), 0, s, g);
+    if (gemm_kb() == 16)
+      hipLaunchKernelGGL((k_gemm_planes<64, 16>), dim3(grid), dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL((k_gemm_planes<64, 32>), dim3(grid), dim3(256), 0, s, g);
   }
   return check_launch("gemm_planes");
 }
