@@ -103,10 +103,14 @@ int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, fl
  * autograd dZ = g W.  If stats != NULL it receives per-row-tile BatchNorm partials
  * stats[tile][0][n] = sum_r y, stats[tile][1][n] = sum_r (y - tile_mean)^2, tile = 128 rows
  * (cheby_graph_conv.py:39 batch statistics; fake vertices included).
- * Shapes with Ka%32!=0 or N%32!=0 take a scalar (VALU) path.                                    */
+ * Shapes with Ka%32!=0 or N%32!=0 take a scalar (VALU) path.
+ * addend (optional, single output plane): [M, N] added to the result (the block residual's gradient);
+ * pair_out (single output plane): C is [M/2, N] and receives the sum of the two children rows of every
+ * coarse vertex -- backward of nn.Upsample (meshnet.py:74) in the epilogue.  The backward uses this entry
+ * point in "forward form": dX = [g | L g | L2 g] W3 with the planes from p2m_cheb_basis_fwd(g).      */
 int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                    int32_t a0_shift, const float* Bm, const float* bias,
-                    float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc,
+                    int32_t a0_shift, const float* Bm, const float* bias, const float* addend,
+                    float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out,
                     int64_t M, float* stats, void* stream);
 /* rows per BatchNorm partial tile and the number of tiles for M rows */
 int32_t p2m_stats_tile_rows(void);

@@ -35,8 +35,8 @@ HIP_SYMBOLS = {
                                        _vp]),
     "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "p2m_fused_stats_tile_rows": (_i32, [_i32]),
-    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                                   _i64, _vp, _vp]),
+    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                   _i32, _i64, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),
     "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp,
                                _vp]),

@@ -28,6 +28,8 @@ struct GemmArgs {
   const float* A[3];
   const float* Bm;
   const float* bias;
+  const float* addend;   // optional [M, N] added to the result (single output plane)
+  int pair_out;          // write C[(row>>1)] = v(row) + v(row^1): backward of the x2 un-pool (single output plane)
   float* C[3];
   float* stats;
   long M;
@@ -47,8 +49,10 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
   return mt < ntm;
 }
 
-template <int BN, int KB>   // KB = K chunk staged per barrier (16: 34 KB LDS -> 3 blocks/CU; 32: 67 KB -> 2 blocks/CU)
-__global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
+// KB = K chunk staged per barrier (16: 34 KB LDS -> 3 blocks/CU; 32: 67 KB -> 2 blocks/CU);
+// EXTRA compiles in the addend / pair-sum epilogue (kept out of the plain variant: it costs registers -> occupancy)
+template <int BN, int KB, bool EXTRA>
+__global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   constexpr int WTN = BN / 2;    // wave tile N
   constexpr int TN = WTN / 32;   // MFMA tiles along N per wave
   constexpr int TM = 2;          // wave tile M = 64
@@ -174,10 +178,18 @@ __global__ __launch_bounds__(256) void k_gemm_planes(GemmArgs g) {
       for (int r = 0; r < 16; r++) {
         long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         float v = acc[i][j][r] + bias_v[j];
+        if (EXTRA && g.addend != nullptr && row < g.M && Cq != nullptr) v += g.addend[row * g.N + n];
         acc[i][j][r] = v;
-        if (row < g.M && Cq != nullptr) {
+        if (!(EXTRA && g.pair_out) && row < g.M && Cq != nullptr) {
           Cq[row * g.Nc + c] = v;
           csum[j] += v;
+        }
+      }
+      if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < g.M) Cq[(row >> 1) * g.Nc + c] = acc[i][j][r] + acc[i][j][r + 1];
         }
       }
     }
@@ -244,6 +256,7 @@ __global__ void k_naive_gemm_planes(GemmArgs g) {
     for (int k = 0; k < g.Ka; k++) acc = fmaf(a[k], b[(long)k * g.N], acc);
   }
   if (g.bias) acc += g.bias[n];
+  if (g.addend) acc += g.addend[r * g.N + n];
   int q = n / g.Nc;
   g.C[q][r * g.Nc + (n - q * g.Nc)] = acc;
 }
@@ -510,8 +523,9 @@ static int gemm_kb() {          // K chunk per barrier of k_gemm_planes (tuning 
 }
 
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                               int32_t a0_shift, const float* Bm, const float* bias, float* C0, float* C1,
-                               float* C2, int32_t nplanesC, int32_t Nc, int64_t M, float* stats, void* stream) {
+                               int32_t a0_shift, const float* Bm, const float* bias, const float* addend, float* C0,
+                               float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out, int64_t M,
+                               float* stats, void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesC >= 1 && nplanesC <= 3, "plane count must be 1..3");
   P2M_CHECK_ARG(A0 && Bm && C0 && Ka > 0 && Nc > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
@@ -521,12 +535,15 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.C[0] = C0; g.C[1] = C1; g.C[2] = C2;
   for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
   for (int p = 0; p < nplanesC; p++) P2M_CHECK_ARG(g.C[p] != nullptr, "missing C plane");
-  g.Bm = Bm; g.bias = bias; g.stats = stats; g.M = M;
+  P2M_CHECK_ARG((addend == nullptr && !pair_out) || nplanesC == 1, "addend / pair_out need a single output plane");
+  P2M_CHECK_ARG(!(pair_out && stats), "pair_out and stats are mutually exclusive");
+  g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = pair_out; g.stats = stats; g.M = M;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
   if (!mfma_ok) {
+    P2M_CHECK_ARG(!pair_out, "pair_out needs the MFMA path (Ka % 32 == 0, N % 32 == 0)");
     long tot = M * g.N;
     g.ntm = g.ntn = 0;
     hipLaunchKernelGGL(k_naive_gemm_planes, dim3(cdiv(tot, 256)), dim3(256), 0, s, g);
@@ -540,17 +557,23 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   if (g.N % 128 == 0) {
     g.ntn = g.N / 128;
     int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    if (gemm_kb() == 16)
-      hipLaunchKernelGGL((k_gemm_planes<128, 16>), dim3(grid), dim3(256), 0, s, g);
+    const bool extra = addend != nullptr || pair_out;
+    if (extra)
+      hipLaunchKernelGGL((k_gemm_planes<128, 32, true>), dim3(grid), dim3(256), 0, s, g);
+    else if (gemm_kb() == 16)
+      hipLaunchKernelGGL((k_gemm_planes<128, 16, false>), dim3(grid), dim3(256), 0, s, g);
     else
-      hipLaunchKernelGGL((k_gemm_planes<128, 32>), dim3(grid), dim3(256), 0, s, g);
+      hipLaunchKernelGGL((k_gemm_planes<128, 32, false>), dim3(grid), dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(g.N, 64);
     int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    if (gemm_kb() == 16)
-      hipLaunchKernelGGL((k_gemm_planes<64, 16>), dim3(grid), dim3(256), 0, s, g);
+    const bool extra = addend != nullptr || pair_out;
+    if (extra)
+      hipLaunchKernelGGL((k_gemm_planes<64, 32, true>), dim3(grid), dim3(256), 0, s, g);
+    else if (gemm_kb() == 16)
+      hipLaunchKernelGGL((k_gemm_planes<64, 16, false>), dim3(grid), dim3(256), 0, s, g);
     else
-      hipLaunchKernelGGL((k_gemm_planes<64, 32>), dim3(grid), dim3(256), 0, s, g);
+      hipLaunchKernelGGL((k_gemm_planes<64, 32, false>), dim3(grid), dim3(256), 0, s, g);
   }
   return check_launch("gemm_planes");
 }

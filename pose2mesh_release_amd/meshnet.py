@@ -59,6 +59,11 @@ class _Layer:
             setattr(self, k, v)
 
 
+def _bwd_forward_form(L):
+    """Layers whose backward runs as dX = [g|Lg|L2g] W3 on the plane GEMM (MFMA path needs 32-multiples)."""
+    return L.Fout % 32 == 0 and L.Fin % 32 == 0
+
+
 def _narrow(L):
     """Layers whose 3*Fout output columns fit one 32-wide MFMA tile take the project-then-combine path."""
     return (not L.has_bn) and K_CHEB * L.Fout <= 32 and L.Fin % 32 == 0 and not L.first_in_block and L.Fout <= 4
@@ -112,7 +117,9 @@ class _MeshNetFn(torch.autograd.Function):
             need_stats = L.has_bn and training
             fwd_fused = ops.fused_supported(L.Fin, L.Fout)
             bwd_fused = ops.fused_supported(L.Fout, L.Fin)
-            Wt, W2, W3 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep and not bwd_fused, need_w3=keep and bwd_fused)
+            bwd_fwdform = _bwd_forward_form(L)
+            Wt, W2, W3 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep and not (bwd_fused or bwd_fwdform),
+                                         need_w3=keep and (bwd_fused or bwd_fwdform))
             if fwd_fused:          # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
                 y, st, _ = ops.cheb_gemm_fused(g, cur, L.Fin, cur_shift, Wt, bvec, None, L.Fout, B, stats=need_stats)
@@ -138,7 +145,9 @@ class _MeshNetFn(torch.autograd.Function):
             else:
                 out = y                                               # final conv: no BN, no ReLU (:52-55,99)
             if keep:
-                saved.append((cur, cur_shift, T1, T2, y, co, W3 if bwd_fused else W2))
+                if bwd_fused or bwd_fwdform:
+                    T1 = T2 = None          # the backward never needs the basis of X (dW = X^T [g|Lg|L2g])
+                saved.append((cur, cur_shift, T1, T2, y, co, W3 if (bwd_fused or bwd_fwdform) else W2))
             cur, cur_shift = out, 0
             if L.last_in_block:
                 if L.block == 0:                                      # fc lift (:104-106)
@@ -219,6 +228,17 @@ class _MeshNetFn(torch.autograd.Function):
                 # dW = X^T [gy | L gy | L2 gy] without ever forming the basis of X
                 dX, _, (E1, E2) = ops.cheb_gemm_fused(gph, gy, L.Fout, 0, W2, None, G if fuse_res else None, L.Fin, B,
                                                       pair_out=bool(x_shift), want_planes=True)
+                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
+                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
+                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                del Pw, Pb, E1, E2
+            elif _bwd_forward_form(L):
+                # backward in FORWARD form (L symmetric): E = basis(gy), dX = [gy|E1|E2] W3 with the residual
+                # gradient and the un-pool pair-sum in the GEMM epilogue, dW = X^T [gy|E1|E2].  One single-source
+                # gather (12.5 rows/row) replaces the two-source gather of p2m_cheb_basis_bwd (25 rows/row).
+                E1, E2 = ops.cheb_basis_fwd(gph, gy, B, L.Fout, 0)
+                (dX,), _ = ops.gemm_planes([gy, E1, E2], L.Fout, 0, W2, None, M, L.Fin, 1, False,
+                                           addend=G if fuse_res else None, pair_out=bool(x_shift))
                 Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
                 dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db

@@ -234,11 +234,12 @@ def fused_supported(Ka, N):
     return USE_FUSED and Ka % 32 == 0 and N in (64, 128, 256)
 
 
-def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
-    """A: list of 1..3 plane tensors.  Returns (list of C planes, stats or None)."""
+def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend=None, pair_out=False):
+    """A: list of 1..3 plane tensors.  Returns (list of C planes, stats or None).
+    addend: [M, N] added in the epilogue; pair_out: the (single) output has M/2 rows = sums of row pairs."""
     dev = A[0].device
     Nc = N // nplanesC
-    C = [torch.empty((M, Nc), device=dev, dtype=torch.float32) for _ in range(nplanesC)]
+    C = [torch.empty((M >> 1 if pair_out else M, Nc), device=dev, dtype=torch.float32) for _ in range(nplanesC)]
     st = None
     if stats:
         nt = (M + stats_tile_rows() - 1) // stats_tile_rows()
@@ -248,8 +249,9 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False):
     mfma = (Ka % 32 == 0) and (Nc % 32 == 0)
     with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", 2.0 * M * len(A) * Ka * N):   # algorithmic FLOPs
         check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")),
-                                         _p(bias if bias is None else _req(bias, "bias")), c[0], c[1], c[2],
-                                         nplanesC, Nc, M, _p(st), _stream()), "p2m_gemm_planes")
+                                         _p(bias if bias is None else _req(bias, "bias")),
+                                         _p(addend if addend is None else _req(addend, "addend")), c[0], c[1], c[2],
+                                         nplanesC, Nc, int(pair_out), M, _p(st), _stream()), "p2m_gemm_planes")
     return C, st
 
 

@@ -237,3 +237,19 @@ def test_gemm_tn_with_planes_and_layout1(ops):
     ref = torch.stack([G[k].double().t() @ X.double() for k in range(3)], dim=2)      # [Fout][Fin][k]
     assert (dW.cpu() - ref.reshape(Fout, Fin * 3)).abs().max() < 2e-4
     assert (db.cpu() - G[0].double().sum(0)).abs().max() < 1e-3
+
+
+def test_gemm_planes_addend_and_pair_out(ops):
+    """Epilogue extras used by the forward-form backward: + addend, and the un-pool pair-sum output."""
+    M, K, N = 1000, 64, 128
+    gen = torch.Generator().manual_seed(3)
+    A = [torch.randn(M, K, generator=gen) for _ in range(3)]
+    Bm = torch.randn(3 * K, N, generator=gen) / 14
+    add = torch.randn(M, N, generator=gen)
+    ref = torch.cat(A, 1).double() @ Bm.double() + add.double()
+    (C,), _ = ops.gemm_planes([a.cuda() for a in A], K, 0, Bm.cuda(), None, M, N, 1, False, addend=add.cuda())
+    assert (C.cpu() - ref).abs().max() < 2e-5
+    (Cp,), _ = ops.gemm_planes([a.cuda() for a in A], K, 0, Bm.cuda(), None, M, N, 1, False, addend=add.cuda(),
+                               pair_out=True)
+    assert Cp.shape == (M // 2, N)
+    assert (Cp.cpu() - ref.view(M // 2, 2, N).sum(1)).abs().max() < 4e-5
