@@ -54,6 +54,16 @@ __global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restr
     const int s = g.rowptr[row], e = g.rowptr[row + 1];
     float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
     int j = s;
+    for (; j + 8 <= e; j += 8) {       // 8 gathers in flight per lane: the kernel is bound by memory-level parallelism
+      float4 x[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) x[i] = *reinterpret_cast<const float4*>(Xb + (long)(g.col[j + i] >> in_shift) * F);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        fma4(t1, g.a[j + i], x[i]);
+        fma4(t2, g.b[j + i], x[i]);
+      }
+    }
     for (; j + 4 <= e; j += 4) {
       const int c0 = g.col[j], c1 = g.col[j + 1], c2 = g.col[j + 2], c3 = g.col[j + 3];
       const float4 x0 = *reinterpret_cast<const float4*>(Xb + (long)(c0 >> in_shift) * F);

@@ -22,8 +22,14 @@ def init_from_env(backend=None):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
-    if backend == "nccl":
+        backend = os.environ.get("P2M_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            if backend == "nccl":                                      # "nccl" IS RCCL on ROCm
+                raise RuntimeError(f"LOCAL_RANK {local} but only {ndev} GPU(s): RCCL needs one GPU per rank "
+                                   "(P2M_DIST_BACKEND=gloo allows several ranks per GPU for functional tests)")
+            local = local % ndev
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

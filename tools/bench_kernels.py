@@ -74,3 +74,18 @@ if "fused" in which:
             ms2 = timeit(lambda: ops.cheb_gemm_fused(g, X, Fin, 0, W, None, None, Fout, B, want_planes=True))
         print(f"fused V={V:6d} {Fin}->{Fout} sh={sh}: fwd {ms:7.3f} ms {fl/ms/1e9:6.1f} TF | +planes {ms2:7.3f} ms", flush=True)
         del X
+if "rcm" in which:
+    import numpy as np, scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    for V, F in [(11776, 128), (5888, 128), (1472, 256)]:
+        L = [l for l in gL if l.shape[0] == V][0].tocsr()
+        perm = reverse_cuthill_mckee(sp.csr_matrix(L != 0), symmetric_mode=True)
+        Lp = L[perm][:, perm]
+        coo = Lp.tocoo(); print("V", V, "bandwidth tree", np.abs(L.tocoo().row - L.tocoo().col).max(), "rcm", np.abs(coo.row - coo.col).max(), "mean", np.abs(L.tocoo().row - L.tocoo().col).mean(), np.abs(coo.row - coo.col).mean())
+        for name, mat in (("tree", L), ("rcm", Lp)):
+            g = ops.DeviceGraph(mat, dev)
+            X = torch.randn(B * V, F, device=dev)
+            ms = timeit(lambda: ops.cheb_basis_fwd(g, X, B, F, 0))
+            by = 4.0 * B * V * F * 3
+            print(f"  {name}: basis fwd V={V} F={F}: {ms:7.3f} ms {by/ms/1e6:7.1f} GB/s", flush=True)
+            del X
