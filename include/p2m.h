@@ -163,6 +163,41 @@ int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* str
  * g: [M, F], dst: [M, Fres].                                                                   */
 int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream);
 
+/* ---- fake-vertex split (row-set launches) ----------------------------------------------------------------
+ * Padding ("fake") vertices of the coarsening tree are isolated (lib/coarsening.py:236-245): their merged
+ * CSR row is the diagonal alone and identical for the whole level, so T1 = a x, T2 = b x and the contraction of
+ * cheby_graph_conv.py:37 needs only K = Fin with W_eff = W0 + a W1 + b W2 -- 2/3 of the MFMA work on 30-40 % of the
+ * rows disappears, and the basis planes are only formed (compactly, [B*n_real, F]) for real vertices.
+ * Rows are selected by row_set: 1 = real vertices, 2 = fake vertices (sorted id lists baked in the handle); tensors
+ * keep their (B, V, F) layout, only the launches iterate over the subset.  BatchNorm statistics still cover ALL
+ * rows (the reference includes fake vertices, cheby_graph_conv.py:39): p2m_bn_finalize_rows merges both launches. */
+int p2m_graph_split_info(p2m_graph_t g, int32_t counts[2] /* n_real, n_fake */, float coef[2] /* a, b */);
+int p2m_cheb_basis_fwd_real(p2m_graph_t g, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
+                            int32_t in_shift, void* stream);
+/* C[b*V + ids[i], :] = [A0[..] | A1 | A2] Bm + bias (+ addend): A0 is read at the actual row (>> a0_shift), A1/A2 at
+ * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.                  */
+int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                         const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
+                         const float* Bm, const float* bias, const float* addend, float* C, int32_t N,
+                         float* stats, void* stream);
+int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
+/* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
+ * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
+int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
+                     const float* G0, const float* G1, const float* G2, int32_t nplanesG, int32_t Gc,
+                     int32_t planes_compact, int32_t splits, float* P, float* Pdb, void* stream);
+/* We[k][n] = Wt[k][n] + a Wt[Ka+k][n] + b Wt[2Ka+k][n]  (Wt = [3Ka, N]) */
+int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream);
+/* dW (nn.Linear layout) from the real-vertex partials P[c][fin][k*Fout+fo] plus the fake-vertex partials
+ * P2[c][fin][fo] entering plane k with factor (1, s1, s2)[k]; db from both.                                       */
+int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t nchunks, const float* P2, const float* Pdb2,
+                            int32_t nchunks2, float s1, float s2, float* dW, float* db, int32_t Fout, int32_t Fin,
+                            int32_t K, void* stream);
+int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b, int32_t tps_b,
+                         int32_t rows_b, int32_t B, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                         float* shift, int32_t N, void* stream);
+
 /* ---- fused Chebyshev convolution: recurrence + contraction in ONE persistent kernel -------------
  *   C[r, :] = [ A[r] | (L A)[r] | (L2 A)[r] ] * Bm (+ bias) (+ addend[r]),   r = b*V + v, M = B*V rows
  * A: [B*(V>>a_shift), Ka] (Ka % 32 == 0), Bm: [3*Ka, N] (N in {64,128,256}), C: [M, N] or, with

@@ -35,7 +35,8 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
 // gathers; there is no divergence on the row length.
 template <int LPR>
 __global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restrict__ X, float* __restrict__ T1,
-                                                    float* __restrict__ T2, int B, int in_shift, int tiles_per_group) {
+                                                    float* __restrict__ T2, int B, int in_shift, int tiles_per_group,
+                                                    const int* __restrict__ ids, int nset) {
   constexpr int F = LPR * 4;
   constexpr int S = 64 / LPR;
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -47,10 +48,12 @@ __global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restr
   const int f4 = (lane % LPR) * 4;
   const bool active = sample < B;
   const float* Xb = X + (long)(active ? sample : 0) * (g.V >> in_shift) * F + f4;
-  const long obase = (long)(active ? sample : 0) * g.V * F + f4;
+  // ids != nullptr: only the listed (real) vertices are computed and the planes are written COMPACT, [B*nset, F]
+  const long obase = (long)(active ? sample : 0) * nset * F + f4;
   int row_end = (tile + 1) * ROWS_PER_BLOCK;
-  if (row_end > g.V) row_end = g.V;
-  for (int row = tile * ROWS_PER_BLOCK + wave; row < row_end; row += 4) {
+  if (row_end > nset) row_end = nset;
+  for (int lrow = tile * ROWS_PER_BLOCK + wave; lrow < row_end; lrow += 4) {
+    const int row = ids ? ids[lrow] : lrow;
     const int s = g.rowptr[row], e = g.rowptr[row + 1];
     float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
     int j = s;
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(256) void k_basis_fwd(Graph g, const float* __restr
       fma4(t1, g.a[j], x0); fma4(t2, g.b[j], x0);
     }
     if (active) {
-      *reinterpret_cast<float4*>(T1 + obase + (long)row * F) = t1;
-      *reinterpret_cast<float4*>(T2 + obase + (long)row * F) = t2;
+      *reinterpret_cast<float4*>(T1 + obase + (long)lrow * F) = t1;
+      *reinterpret_cast<float4*>(T2 + obase + (long)lrow * F) = t2;
     }
   }
 }
@@ -280,6 +283,35 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
 }
 
 
+static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
+                            int32_t in_shift, int real_only, void* stream) {
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  hipStream_t s = (hipStream_t)stream;
+  const int* ids = real_only ? g.real_ids : nullptr;
+  const int nset = real_only ? g.n_real : g.V;
+  if (nset == 0) return P2M_OK;
+  const int tps = cdiv(nset, ROWS_PER_BLOCK);
+  auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_basis_fwd<8>,  grid(8),  dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps, ids, nset); break;
+    case 64:  hipLaunchKernelGGL(k_basis_fwd<16>, grid(16), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps, ids, nset); break;
+    case 128: hipLaunchKernelGGL(k_basis_fwd<32>, grid(32), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps, ids, nset); break;
+    case 256: hipLaunchKernelGGL(k_basis_fwd<64>, grid(64), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps, ids, nset); break;
+    default:
+      set_error("p2m_cheb_basis_fwd_real: feature width %d is not 32/64/128/256", F);
+      return P2M_ERR_INVALID;
+  }
+  return check_launch("cheb_basis_fwd");
+}
+
+extern "C" int p2m_cheb_basis_fwd_real(p2m_graph_t gh, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
+                                       int32_t in_shift, void* stream) {
+  P2M_CHECK_ARG(gh && X && T1c && T2c && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(in_shift == 0 || in_shift == 1, "in_shift must be 0 or 1");
+  if (B <= 0) return P2M_OK;
+  return basis_fwd_launch(gh, X, T1c, T2c, B, F, in_shift, 1, stream);
+}
+
 extern "C" int p2m_cheb_basis_fwd(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
                                   int32_t in_shift, void* stream) {
   P2M_CHECK_ARG(gh && X && T1 && T2 && F > 0, "null pointer or empty shape");
@@ -288,13 +320,9 @@ extern "C" int p2m_cheb_basis_fwd(p2m_graph_t gh, const float* X, float* T1, flo
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
   P2M_CHECK_ARG(in_shift == 0 || (g.V % 2 == 0), "virtual un-pool needs an even vertex count");
   hipStream_t s = (hipStream_t)stream;
-  const int tps = cdiv(g.V, ROWS_PER_BLOCK);
-  auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_basis_fwd<8>,  grid(8),  dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
-    case 64:  hipLaunchKernelGGL(k_basis_fwd<16>, grid(16), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
-    case 128: hipLaunchKernelGGL(k_basis_fwd<32>, grid(32), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
-    case 256: hipLaunchKernelGGL(k_basis_fwd<64>, grid(64), dim3(256), 0, s, g, X, T1, T2, B, in_shift, tps); break;
+    case 32: case 64: case 128: case 256:
+      return basis_fwd_launch(gh, X, T1, T2, B, F, in_shift, 0, stream);
     default: {
       long tot = (long)B * g.V * F;
       hipLaunchKernelGGL(k_basis_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, X, T1, T2, B, F, in_shift);

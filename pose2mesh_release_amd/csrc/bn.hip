@@ -14,7 +14,14 @@ namespace p2m {
 // M2 + sum^2/n; tile-centred partials make the double-precision E[y^2]-E[y]^2 benign.
 constexpr int FIN_CG = 8;     // columns per block
 constexpr int FIN_RG = 128;   // tile groups per block
-__global__ __launch_bounds__(FIN_CG * FIN_RG) void k_bn_finalize(const float* __restrict__ stats, int ntiles, long M,
+// Up to two segments of partials (e.g. the real-vertex and the fake-vertex launch of one conv); inside a segment the
+// tiles repeat with period `tps` over `seg_rows` rows (row-set launches tile every sample separately).
+struct StatSeg {
+  const float* stats;
+  int ntiles, tps;
+  long seg_rows;
+};
+__global__ __launch_bounds__(FIN_CG * FIN_RG) void k_bn_finalize(StatSeg sg0, StatSeg sg1, long M,
                                                                   int tile_rows, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* running_mean,
                                                                   float* running_var, float momentum, float eps,
@@ -26,13 +33,17 @@ __global__ __launch_bounds__(FIN_CG * FIN_RG) void k_bn_finalize(const float* __
   const int n = blockIdx.x * FIN_CG + cg;
   double a1 = 0.0, a2 = 0.0;
   if (n < N) {
-    for (int i = rg; i < ntiles; i += FIN_RG) {
-      long left = M - (long)i * tile_rows;
-      double cnt = (double)(left < tile_rows ? left : tile_rows);
-      double s = (double)stats[(long)i * 2 * N + n];
-      double m2 = (double)stats[(long)i * 2 * N + N + n];
-      a1 += s;
-      a2 += m2 + s * s / cnt;
+    for (int sgi = 0; sgi < 2; sgi++) {
+      const StatSeg sg = sgi == 0 ? sg0 : sg1;
+      if (sg.stats == nullptr) continue;
+      for (int i = rg; i < sg.ntiles; i += FIN_RG) {
+        long left = sg.seg_rows - (long)(i % sg.tps) * tile_rows;
+        double cnt = (double)(left < tile_rows ? left : tile_rows);
+        double s = (double)sg.stats[(long)i * 2 * N + n];
+        double m2 = (double)sg.stats[(long)i * 2 * N + N + n];
+        a1 += s;
+        a2 += m2 + s * s / cnt;
+      }
     }
   }
   s1[rg][cg] = a1;
@@ -303,10 +314,26 @@ extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, co
   P2M_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift && N > 0 && M > 0, "null pointer or empty shape");
   P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
   P2M_CHECK_ARG(tile_rows > 0 && ntiles == cdiv(M, tile_rows), "ntiles does not match M / tile_rows");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, stats, ntiles,
+  StatSeg a{stats, ntiles, ntiles, (long)M}, b{nullptr, 0, 1, 0};
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, a, b,
                      (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift, N);
   return check_launch("bn_finalize");
+}
+
+extern "C" int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b,
+                                    int32_t tps_b, int32_t rows_b, int32_t B, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                    float* invstd, float* scale, float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(stats_a && gamma && beta && mean && invstd && scale && shift && N > 0 && B > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+  const int tile_rows = p2m_stats_tile_rows();
+  StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a};
+  StatSeg b{stats_b, stats_b ? B * tps_b : 0, tps_b > 0 ? tps_b : 1, (long)rows_b};
+  const long M = (long)B * ((long)rows_a + (stats_b ? (long)rows_b : 0));
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, a, b, M,
+                     tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N);
+  return check_launch("bn_finalize_rows");
 }
 
 extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,

@@ -1,6 +1,8 @@
 // Graph handles, error plumbing and the composite ChebConv entry point of libp2m_hip.so.
 #include <algorithm>
 #include <cstdarg>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "p2m_common.h"
@@ -92,8 +94,27 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
     rp[i + 1] = (int)mc.size();
     max_row = std::max(max_row, rp[i + 1] - rp[i]);
   }
+  // fake (isolated) vertices: single-entry rows sharing the most common (a, b) pair
+  std::vector<int> real_ids, fake_ids;
+  float fa = 0.f, fb = 0.f;
+  {
+    std::map<std::pair<float, float>, int> count;
+    for (int i = 0; i < V; i++)
+      if (rp[i + 1] - rp[i] == 1 && mc[rp[i]] == i) count[{ma[rp[i]], mb[rp[i]]}]++;
+    int best = 0;
+    for (const auto& kv : count)
+      if (kv.second > best) { best = kv.second; fa = kv.first.first; fb = kv.first.second; }
+    for (int i = 0; i < V; i++) {
+      const bool fake = best > 0 && rp[i + 1] - rp[i] == 1 && mc[rp[i]] == i && ma[rp[i]] == fa && mb[rp[i]] == fb;
+      (fake ? fake_ids : real_ids).push_back(i);
+    }
+  }
   Graph* g = new Graph();
   g->V = V;
+  g->n_real = (int)real_ids.size();
+  g->n_fake = (int)fake_ids.size();
+  g->fake_a = fa;
+  g->fake_b = fb;
   g->nnz = (int)mc.size();
   g->nnz_L = nnz;
   g->max_row = max_row;
@@ -101,7 +122,9 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   if ((rc = upload(rp.data(), sizeof(int) * (V + 1), (void**)&g->rowptr)) != P2M_OK ||
       (rc = upload(mc.data(), sizeof(int) * mc.size(), (void**)&g->col)) != P2M_OK ||
       (rc = upload(ma.data(), sizeof(float) * ma.size(), (void**)&g->a)) != P2M_OK ||
-      (rc = upload(mb.data(), sizeof(float) * mb.size(), (void**)&g->b)) != P2M_OK) {
+      (rc = upload(mb.data(), sizeof(float) * mb.size(), (void**)&g->b)) != P2M_OK ||
+      (rc = upload(real_ids.data(), sizeof(int) * real_ids.size(), (void**)&g->real_ids)) != P2M_OK ||
+      (rc = upload(fake_ids.data(), sizeof(int) * fake_ids.size(), (void**)&g->fake_ids)) != P2M_OK) {
     p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
     return rc;
   }
@@ -116,6 +139,8 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->col) (void)hipFree(g->col);
   if (g->a) (void)hipFree(g->a);
   if (g->b) (void)hipFree(g->b);
+  if (g->real_ids) (void)hipFree(g->real_ids);
+  if (g->fake_ids) (void)hipFree(g->fake_ids);
   delete g;
   return P2M_OK;
 }
@@ -127,6 +152,16 @@ extern "C" int p2m_graph_info(p2m_graph_t gh, int32_t info[4]) {
   info[1] = g->nnz_L;
   info[2] = g->nnz;
   info[3] = g->max_row;
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_split_info(p2m_graph_t gh, int32_t counts[2], float coef[2]) {
+  P2M_CHECK_ARG(gh && counts && coef, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  counts[0] = g->n_real;
+  counts[1] = g->n_fake;
+  coef[0] = g->fake_a;
+  coef[1] = g->fake_b;
   return P2M_OK;
 }
 

@@ -36,6 +36,10 @@ struct GemmArgs {
   int nplanesA, Ka, a0_shift;
   int N, Nc;
   int ntm, ntn;
+  // row-set mode (ROWS kernels): logical row (b, i), i < nset -> actual row b*V + ids[i]; tiles do not cross samples
+  // (tps tiles per sample); planes 1,2 of A are COMPACT ([B*nset, Ka]) when `compact`
+  const int* ids;
+  int nset, V, tps, compact;
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -51,7 +55,7 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
 
 // KB = K chunk staged per barrier (16: 34 KB LDS -> 3 blocks/CU; 32: 67 KB -> 2 blocks/CU);
 // EXTRA compiles in the addend / pair-sum epilogue (kept out of the plain variant: it costs registers -> occupancy)
-template <int BN, int KB, bool EXTRA>
+template <int BN, int KB, bool EXTRA, bool ROWS = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   constexpr int WTN = BN / 2;    // wave tile N
   constexpr int TN = WTN / 32;   // MFMA tiles along N per wave
@@ -61,15 +65,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   constexpr int AROWS = 256 / (KB / 4);           // rows of A covered per pass
   constexpr int BPASS = KB * BN / 4 / 256;        // float4 B loads per thread per chunk
   constexpr int BROWS = 256 / (BN / 4);           // rows of B covered per pass
-  __shared__ float smem[2 * BM * LDA + 2 * KB * BN];
+  __shared__ float smem[2 * BM * LDA + 2 * KB * BN + (ROWS ? BM : 0)];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDA;
+  int* rowtab = reinterpret_cast<int*>(smem + 2 * BM * LDA + 2 * KB * BN);   // ROWS: actual row of each tile row, -1 = none
 
   int mt, nt;
   if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
-  const long m0 = (long)mt * BM;
+  const long m0 = (long)mt * BM;      // flat mode: first row of the tile; ROWS mode: unused for addressing
   const int n0 = nt * BN;
   const int t = threadIdx.x;
+  // ROWS mode: tile -> (sample, tile within the sample's row set)
+  const int rs_b = ROWS ? mt / g.tps : 0;
+  const int rs_i0 = ROWS ? (mt - rs_b * g.tps) * BM : 0;
+  if (ROWS && t < BM) {
+    const int i = rs_i0 + t;
+    rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
+  }
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -90,6 +102,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   float4 rb[BPASS];
   const int a_row = t / (KB / 4), a_k4 = (t % (KB / 4)) * 4;
   const int b_row = t / (BN / 4), b_c4 = (t % (BN / 4)) * 4;
+  // ROWS mode: per-thread source rows of its APASS tile rows (plane 0: full layout, planes 1,2: compact)
+  long rs_full[ROWS ? APASS : 1], rs_comp[ROWS ? APASS : 1];
+  if (ROWS) {
+#pragma unroll
+    for (int ps = 0; ps < APASS; ps++) {
+      const int i = rs_i0 + ps * AROWS + a_row;
+      if (i < g.nset) {
+        rs_full[ps] = (long)rs_b * g.V + g.ids[i];
+        rs_comp[ps] = (long)rs_b * g.nset + i;
+      } else {
+        rs_full[ps] = -1;
+        rs_comp[ps] = -1;
+      }
+    }
+  }
 
   auto load_chunk = [&](int kc) {
     const int p = kc / cpp;
@@ -98,11 +125,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
     const int sh = (p == 0) ? g.a0_shift : 0;
 #pragma unroll
     for (int ps = 0; ps < APASS; ps++) {
-      long r = m0 + ps * AROWS + a_row;
-      if (r < g.M)
-        ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
-      else
-        ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ROWS) {
+        const long r = (p == 0 || !g.compact) ? rs_full[ps] : rs_comp[ps];
+        if (r >= 0)
+          ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
+        else
+          ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        long r = m0 + ps * AROWS + a_row;
+        if (r < g.M)
+          ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
+        else
+          ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     const float* Bp = g.Bm + (long)(p * g.Ka + k0) * g.N;
 #pragma unroll
@@ -176,11 +211,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
       float* Cq = (n < g.N) ? g.C[q] : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        long row = ROWS ? (long)rowtab[ml] : m0 + ml;
+        const bool rok = ROWS ? (row >= 0) : (row < g.M);
         float v = acc[i][j][r] + bias_v[j];
-        if (EXTRA && g.addend != nullptr && row < g.M && Cq != nullptr) v += g.addend[row * g.N + n];
-        acc[i][j][r] = v;
-        if (!(EXTRA && g.pair_out) && row < g.M && Cq != nullptr) {
+        if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
+        acc[i][j][r] = rok ? v : 0.f;
+        if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
           Cq[row * g.Nc + c] = v;
           csum[j] += v;
         }
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
 
   // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
   float* red = smem;  // [2 (wm)][BN]   (safe: all waves passed the last __syncthreads of the k loop)
-  long rows_valid = g.M - m0;
+  long rows_valid = ROWS ? (long)(g.nset - rs_i0) : g.M - m0;
   if (rows_valid > BM) rows_valid = BM;
 #pragma unroll
   for (int j = 0; j < TN; j++) {
@@ -216,9 +253,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         float d = acc[i][j][r] - mean;
-        if (row < g.M) m2 += d * d;
+        if (ROWS ? (rowtab[ml] >= 0) : (m0 + ml < g.M)) m2 += d * d;
       }
     m2 += __shfl_xor(m2, 32);
     cm2[j] = m2;
@@ -292,9 +329,13 @@ struct TnArgs {
   long M, chunk_rows;
   int nplanesA, Ka, a0_shift, Ktot, N;
   int nkt, ntn;
+  // row-set mode: chunk = (sample b, split s) over logical rows i < nset; A and G plane 0 are read at the actual row
+  // b*V + ids[i], G planes 1,2 at the compact row b*nset + i when `compact`
+  const int* ids;
+  int nset, V, splits, compact;
 };
 
-template <int BN>
+template <int BN, bool ROWS = false>
 __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
   constexpr int WTN = BN / 2;
   constexpr int TN = WTN / 32;
@@ -310,9 +351,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
   const int kt = tile / g.ntn, nt = tile % g.ntn;
   const int chunk = blockIdx.y;
   const int kk0 = kt * BM, n0 = nt * BN;
-  const long r_begin = (long)chunk * g.chunk_rows;
+  // flat mode: rows [r_begin, r_end) of the flattened (B*V) dimension; ROWS mode: logical rows of one sample
+  const int rs_b = ROWS ? chunk / g.splits : 0;
+  const long r_begin = ROWS ? (long)(chunk - rs_b * g.splits) * g.chunk_rows : (long)chunk * g.chunk_rows;
   long r_end = r_begin + g.chunk_rows;
-  if (r_end > g.M) r_end = g.M;
+  if (r_end > (ROWS ? (long)g.nset : g.M)) r_end = ROWS ? (long)g.nset : g.M;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -343,24 +386,44 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
 
   float4 ra[4], rg[GPASS];
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ROWS: vertex ids of the rows this thread loads, fetched ONE STAGE AHEAD of the data loads that depend on them
+  int ida[ROWS ? 4 : 1], idg[ROWS ? GPASS : 1];
+  auto load_ids = [&](long r0) {
+    if (!ROWS) return;
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      const long r = r0 + ps * 8 + a_r;
+      ida[ps] = (r < r_end) ? g.ids[r] : 0;
+    }
+#pragma unroll
+    for (int ps = 0; ps < GPASS; ps++) {
+      const long r = r0 + ps * GROWS + g_r;
+      idg[ps] = (r < r_end) ? g.ids[r] : 0;
+    }
+  };
   auto load_stage = [&](long r0) {
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
       long r = r0 + ps * 8 + a_r;
-      if (a_ok && r < r_end)
+      if (a_ok && r < r_end) {
+        if (ROWS) r = (long)rs_b * g.V + ida[ps];
         ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> ash) * g.Ka + ak);
-      else
+      } else {
         ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int ps = 0; ps < GPASS; ps++) {
       long r = r0 + ps * GROWS + g_r;
-      if (g_ok && r < r_end)
+      if (g_ok && r < r_end) {
+        if (ROWS) r = (gq == 0 || !g.compact) ? (long)rs_b * g.V + idg[ps] : (long)rs_b * g.nset + r;
         rg[ps] = *reinterpret_cast<const float4*>(Gp + r * g.Gc + gcol);
-      else
+      } else {
         rg[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       dbs.x += rg[ps].x; dbs.y += rg[ps].y; dbs.z += rg[ps].z; dbs.w += rg[ps].w;
     }
+    load_ids(r0 + RK);
   };
   auto store_stage = [&](int buf) {
     float* as = As + buf * RK * BM;
@@ -373,6 +436,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
       *reinterpret_cast<float4*>(gs + (ps * GROWS + g_r) * BN + g_c4) = rg[ps];
   };
 
+  load_ids(r_begin);
   load_stage(r_begin);
   store_stage(0);
   __syncthreads();
@@ -472,9 +536,18 @@ __global__ void k_weight_pack(const float* __restrict__ W, float* __restrict__ W
   if (W3) W3[((long)k * Fout + fout) * Fin + fin] = v;     // [k*Fout + fout][fin]: B operand of dX = [g|Lg|L2g] W3
 }
 
+// Weff[k][n] = Wt[k][n] + a * Wt[Ka + k][n] + b * Wt[2 Ka + k][n]: the K = Fin weight seen by fake vertices
+__global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ We, int Ka, int N, float a, float b) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Ka * N) return;
+  const long plane = (long)Ka * N;
+  We[idx] = Wt[idx] + a * Wt[plane + idx] + b * Wt[2 * plane + idx];
+}
+
 __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks,
                                      float* __restrict__ dW, float* __restrict__ db, int Fout, int Fin, int K,
-                                     int accumulate, int layout, int pdb_stride) {
+                                     int accumulate, int layout, int pdb_stride, const float* __restrict__ P2,
+                                     const float* __restrict__ Pdb2, int nchunks2, float fake_a, float fake_b) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)Fout * Fin * K;
   if (idx < tot) {
@@ -497,13 +570,20 @@ __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* _
       s3 += (double)P[(long)(c + 3) * tot + idx];
     }
     for (; c < nchunks; c++) s0 += (double)P[(long)c * tot + idx];
-    const double s = (s0 + s1) + (s2 + s3);
+    double s = (s0 + s1) + (s2 + s3);
+    if (P2 != nullptr) {        // fake-vertex partials P2[chunk][fin][fout] enter plane k scaled by (1, a, b)[k]
+      double q = 0.0;
+      for (int c2 = 0; c2 < nchunks2; c2++) q += (double)P2[((long)c2 * Fin + fin) * Fout + fout];
+      s += q * (k == 0 ? 1.0 : (k == 1 ? (double)fake_a : (double)fake_b));
+    }
     long o = (long)fout * Fin * K + (long)fin * K + k;
     dW[o] = accumulate ? dW[o] + (float)s : (float)s;
   }
   if (db != nullptr && Pdb != nullptr && idx < Fout) {
     double s = 0.0;
     for (int c = 0; c < nchunks; c++) s += (double)Pdb[(long)c * pdb_stride + idx];
+    if (Pdb2 != nullptr)
+      for (int c2 = 0; c2 < nchunks2; c2++) s += (double)Pdb2[(long)c2 * Fout + idx];
     db[idx] = accumulate ? db[idx] + (float)s : (float)s;
   }
 }
@@ -540,6 +620,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = pair_out; g.stats = stats; g.M = M;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
+  g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
   if (!mfma_ok) {
@@ -578,6 +659,50 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   return check_launch("gemm_planes");
 }
 
+extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                                    const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
+                                    int32_t planes_compact, const float* Bm, const float* bias, const float* addend,
+                                    float* C, int32_t N, float* stats, void* stream) {
+  P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
+  P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
+  P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
+  P2M_CHECK_ARG(Ka > 0 && Ka % BK == 0 && N > 0 && N % 32 == 0, "Ka and N must be positive multiples of 32");
+  P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
+  const Graph& gr = *reinterpret_cast<const Graph*>(gh);
+  const RowSet rs = row_set_of(gr, row_set);
+  if (B <= 0 || rs.n == 0) return P2M_OK;
+  GemmArgs g;
+  g.A[0] = A0; g.A[1] = A1; g.A[2] = A2;
+  for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
+  g.C[0] = C; g.C[1] = nullptr; g.C[2] = nullptr;
+  g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = 0; g.stats = stats;
+  g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.N = N; g.Nc = N;
+  g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.tps = cdiv(rs.n, BM); g.compact = planes_compact;
+  g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
+  g.ntm = B * g.tps;
+  hipStream_t s = (hipStream_t)stream;
+  const bool extra = addend != nullptr;
+  if (N % 128 == 0) {
+    g.ntn = N / 128;
+    const int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
+    if (extra) hipLaunchKernelGGL((k_gemm_planes<128, 32, true, true>), dim3(grid), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_planes<128, 32, false, true>), dim3(grid), dim3(256), 0, s, g);
+  } else {
+    g.ntn = cdiv(N, 64);
+    const int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
+    if (extra) hipLaunchKernelGGL((k_gemm_planes<64, 32, true, true>), dim3(grid), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_planes<64, 32, false, true>), dim3(grid), dim3(256), 0, s, g);
+  }
+  return check_launch("gemm_planes_rows");
+}
+
+// rows per sample tile count of a row set (for the BatchNorm finalize): tiles_per_sample = ceil(n / 128)
+extern "C" int32_t p2m_rows_tiles_per_sample(p2m_graph_t gh, int32_t row_set) {
+  if (!gh || (row_set != 1 && row_set != 2)) return 0;
+  const Graph& gr = *reinterpret_cast<const Graph*>(gh);
+  return cdiv(row_set_of(gr, row_set).n, BM);
+}
+
 extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                            int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
                            int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, void* stream) {
@@ -593,6 +718,7 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   for (int p = 0; p < nplanesG; p++) P2M_CHECK_ARG(g.G[p] != nullptr, "missing G plane");
   g.P = P; g.Pdb = Pdb; g.M = M; g.chunk_rows = chunk_rows;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = nplanesA * Ka; g.N = N;
+  g.ids = nullptr; g.nset = 0; g.V = 0; g.splits = 1; g.compact = 0;
   const int nchunks = cdiv(M, chunk_rows);
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (Gc % 4 == 0) && (g.Ktot >= 32);
@@ -606,12 +732,46 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   g.nkt = cdiv(g.Ktot, BM);
   if (N % 128 == 0) {
     g.ntn = N / 128;
-    hipLaunchKernelGGL(k_gemm_tn<128>, dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_tn<128, false>), dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
-    hipLaunchKernelGGL(k_gemm_tn<64>, dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_tn<64, false>), dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn");
+}
+
+extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A, int32_t Ka,
+                                int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
+                                int32_t Gc, int32_t planes_compact, int32_t splits, float* P, float* Pdb,
+                                void* stream) {
+  P2M_CHECK_ARG(gh && A && G0 && P, "null pointer");
+  P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
+  P2M_CHECK_ARG(nplanesG >= 1 && nplanesG <= 3 && splits >= 1, "plane count must be 1..3, splits >= 1");
+  P2M_CHECK_ARG(Ka % 32 == 0 && Gc % 32 == 0, "Ka and Gc must be multiples of 32");
+  P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
+  const Graph& gr = *reinterpret_cast<const Graph*>(gh);
+  const RowSet rs = row_set_of(gr, row_set);
+  if (B <= 0 || rs.n == 0) return P2M_OK;
+  TnArgs g;
+  g.A[0] = A; g.A[1] = nullptr; g.A[2] = nullptr;
+  g.G[0] = G0; g.G[1] = G1; g.G[2] = G2; g.Gc = Gc;
+  for (int p = 0; p < nplanesG; p++) P2M_CHECK_ARG(g.G[p] != nullptr, "missing G plane");
+  const int N = nplanesG * Gc;
+  g.P = P; g.Pdb = Pdb; g.M = (long)B * rs.n;
+  g.chunk_rows = cdiv(rs.n, splits);
+  g.nplanesA = 1; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = Ka; g.N = N;
+  g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.splits = splits; g.compact = planes_compact;
+  const int nchunks = B * splits;
+  hipStream_t s = (hipStream_t)stream;
+  g.nkt = cdiv(g.Ktot, BM);
+  if (N % 128 == 0) {
+    g.ntn = N / 128;
+    hipLaunchKernelGGL((k_gemm_tn<128, true>), dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+  } else {
+    g.ntn = cdiv(N, 64);
+    hipLaunchKernelGGL((k_gemm_tn<64, true>), dim3(g.nkt * g.ntn, nchunks), dim3(256), 0, s, g);
+  }
+  return check_launch("gemm_tn_rows");
 }
 
 extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, int32_t Fout, int32_t Fin, int32_t K,
@@ -622,12 +782,28 @@ extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, 
   return check_launch("weight_pack");
 }
 
+extern "C" int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream) {
+  P2M_CHECK_ARG(Wt && We && Ka > 0 && N > 0, "null pointer or empty shape");
+  hipLaunchKernelGGL(k_weight_eff, dim3(cdiv((long)Ka * N, 256)), dim3(256), 0, (hipStream_t)stream, Wt, We, Ka, N, a, b);
+  return check_launch("weight_eff");
+}
+
+extern "C" int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t nchunks, const float* P2,
+                                       const float* Pdb2, int32_t nchunks2, float s1, float s2, float* dW, float* db,
+                                       int32_t Fout, int32_t Fin, int32_t K, void* stream) {
+  P2M_CHECK_ARG(P && P2 && dW && Fout > 0 && Fin > 0 && K == 3 && nchunks > 0 && nchunks2 > 0, "null pointer or bad shape");
+  long tot = (long)Fout * Fin * K;
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+                     dW, db, Fout, Fin, K, 0, 1, K * Fout, P2, Pdb2, nchunks2, s1, s2);
+  return check_launch("weight_grad_unpack2");
+}
+
 extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
                                       int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, int32_t layout,
                                       int32_t pdb_stride, void* stream) {
   P2M_CHECK_ARG(P && dW && Fout > 0 && Fin > 0 && K > 0 && nchunks > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
   hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
-                     dW, db, Fout, Fin, K, accumulate, layout, pdb_stride);
+                     dW, db, Fout, Fin, K, accumulate, layout, pdb_stride, nullptr, nullptr, 0, 0.f, 0.f);
   return check_launch("weight_grad_unpack");
 }

@@ -23,7 +23,28 @@ struct Graph {
   int* col = nullptr;      // [nnz]
   float* a = nullptr;      // [nnz]  coefficients of L
   float* b = nullptr;      // [nnz]  coefficients of 2*L*L - I
+  // Fake (padding) vertices are isolated: their merged row is the diagonal alone, with the SAME (fake_a, fake_b)
+  // for the whole level.  For them T1 = fake_a*x and T2 = fake_b*x, so the contraction needs only K = Fin with
+  // W0 + fake_a*W1 + fake_b*W2.  real_ids / fake_ids list the two vertex sets (sorted) for the row-set kernels.
+  int n_real = 0, n_fake = 0;
+  int* real_ids = nullptr;   // [n_real]
+  int* fake_ids = nullptr;   // [n_fake]
+  float fake_a = 0.f, fake_b = 0.f;
 };
+
+// Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)
+struct RowSet {
+  const int* ids = nullptr;
+  int n = 0;
+  int V = 0;
+};
+static inline RowSet row_set_of(const Graph& g, int which) {   // 1 = real vertices, 2 = fake vertices
+  RowSet r;
+  r.V = g.V;
+  if (which == 1) { r.ids = g.real_ids; r.n = g.n_real; }
+  else { r.ids = g.fake_ids; r.n = g.n_fake; }
+  return r;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -120,7 +120,19 @@ class _MeshNetFn(torch.autograd.Function):
             bwd_fwdform = _bwd_forward_form(L)
             Wt, W2, W3 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep and not (bwd_fused or bwd_fwdform),
                                          need_w3=keep and (bwd_fused or bwd_fwdform))
-            if fwd_fused:          # recurrence + contraction in one kernel: the basis planes never reach HBM
+            split = g.split and bwd_fwdform and not fwd_fused
+            if split:
+                # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
+                # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
+                T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
+                y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
+                st = ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout,
+                                          need_stats)
+                We = ops.weight_eff(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b)
+                st2 = ops.gemm_planes_rows(g, 2, B, [cur], L.Fin, cur_shift, False, We, bvec, None, y, L.Fout,
+                                           need_stats)
+                tile_rows = "rows"
+            elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
                 y, st, _ = ops.cheb_gemm_fused(g, cur, L.Fin, cur_shift, Wt, bvec, None, L.Fout, B, stats=need_stats)
                 tile_rows = ops.fused_stats_tile_rows(L.Fout)
@@ -132,7 +144,11 @@ class _MeshNetFn(torch.autograd.Function):
             if L.has_bn:
                 bn = net.bn[L.ci]
                 gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
-                if training:
+                if training and tile_rows == "rows":
+                    co = ops.bn_finalize_rows(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
+                                              bn.momentum, bn.eps)
+                    bn.num_batches_tracked.add_(1)
+                elif training:
                     co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                          tile_rows)
                     bn.num_batches_tracked.add_(1)
@@ -232,6 +248,20 @@ class _MeshNetFn(torch.autograd.Function):
                 dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
+            elif _bwd_forward_form(L) and gph.split:
+                # forward-form backward, split into real / fake vertex launches (see the forward)
+                E1, E2 = ops.cheb_basis_fwd_real(gph, gy, B, L.Fout, 0)
+                dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)
+                add = G if fuse_res else None
+                ops.gemm_planes_rows(gph, 1, B, [gy, E1, E2], L.Fout, 0, True, W2, None, add, dXf, L.Fin)
+                W3e = ops.weight_eff(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b)
+                ops.gemm_planes_rows(gph, 2, B, [gy], L.Fout, 0, False, W3e, None, add, dXf, L.Fin)
+                dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
+                Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
+                Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
+                dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout, L.Fin)
+                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                del Pw, Pb, Pw2, Pb2, E1, E2, dXf
             elif _bwd_forward_form(L):
                 # backward in FORWARD form (L symmetric): E = basis(gy), dX = [gy|E1|E2] W3 with the residual
                 # gradient and the un-pool pair-sum in the GEMM epilogue, dW = X^T [gy|E1|E2].  One single-source

@@ -4,6 +4,7 @@ torch is plumbing here (device memory, streams); every arithmetic step of the ho
 libp2m_hip.so.  There is no fallback: CPU tensors or a missing library raise.
 """
 import ctypes
+import os as _os
 import threading
 
 import numpy as np
@@ -81,6 +82,9 @@ def _timed(name, work):
     return _NOB if TIMER is None else TIMER.bracket(name, work)
 
 
+SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
+
+
 class DeviceGraph:
     """One coarsening level baked on one GPU: merged CSR of L and 2LL-I (p2m_graph_create).
     Replaces the torch sparse COO tensor + per-forward .cuda() of lib/models/meshnet.py:61-62,81."""
@@ -109,6 +113,12 @@ class DeviceGraph:
         info = (ctypes.c_int32 * 4)()
         check(_lib.hip().p2m_graph_info(self.handle, ctypes.byref(info)), "p2m_graph_info")
         self.nnz_L, self.nnz_merged, self.max_row = int(info[1]), int(info[2]), int(info[3])
+        cnt, coef = (ctypes.c_int32 * 2)(), (ctypes.c_float * 2)()
+        check(_lib.hip().p2m_graph_split_info(self.handle, ctypes.byref(cnt), ctypes.byref(coef)), "p2m_graph_split_info")
+        self.n_real, self.n_fake = int(cnt[0]), int(cnt[1])
+        self.fake_a, self.fake_b = float(coef[0]), float(coef[1])
+        # split the launches into real / fake vertices when it pays (big levels with many padding vertices)
+        self.split = SPLIT_FAKE and self.V >= 512 and self.n_fake >= 0.15 * self.V
 
     def __del__(self):
         try:
@@ -188,6 +198,77 @@ def cheb_expand_small(g, G, nc, lde, B):
     return E
 
 
+# ---- fake-vertex split (row-set launches) ---------------------------------------------------
+def cheb_basis_fwd_real(g, X, B, F, in_shift):
+    """Basis planes of the REAL vertices only, compact [B*n_real, F]."""
+    T1 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
+    T2 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
+    with _timed("cheb_basis_fwd", 4.0 * B * g.n_real * F * (2.0 + 1.0 / (1 << in_shift))):
+        check(_lib.hip().p2m_cheb_basis_fwd_real(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
+              "p2m_cheb_basis_fwd_real")
+    return T1, T2
+
+
+def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False):
+    """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None."""
+    n = g.n_real if row_set == 1 else g.n_fake
+    st = None
+    if stats:
+        tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, row_set))
+        st = torch.empty((B * tps, 2, N), device=C.device, dtype=torch.float32)
+    a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
+    with _timed("gemm_planes_mfma", 2.0 * B * n * len(A) * Ka * N):
+        check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
+                                              int(compact), _p(_req(Bm, "B")),
+                                              _p(bias if bias is None else _req(bias, "bias")),
+                                              _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
+                                              _p(st), _stream()), "p2m_gemm_planes_rows")
+    return st
+
+
+def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
+    """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks)."""
+    n = g.n_real if row_set == 1 else g.n_fake
+    N = len(G) * Gc
+    ntiles = ((Ka + 127) // 128) * ((N + 127) // 128)
+    splits = max(1, -(-768 // (B * ntiles)))
+    nch = B * splits
+    P = torch.empty((nch, Ka, N), device=A.device, dtype=torch.float32)
+    Pdb = torch.empty((nch, N), device=A.device, dtype=torch.float32)
+    gp = [_p(_req(t, "G plane")) for t in G] + [None] * (3 - len(G))
+    with _timed("gemm_tn_mfma", 2.0 * B * n * Ka * N):
+        check(_lib.hip().p2m_gemm_tn_rows(g.handle, row_set, B, _p(_req(A, "A")), Ka, a0_shift, gp[0], gp[1], gp[2],
+                                          len(G), Gc, int(compact), splits, _p(P), _p(Pdb), _stream()),
+              "p2m_gemm_tn_rows")
+    return P, Pdb, nch
+
+
+def weight_eff(Wt, Ka, N, a, b):
+    We = torch.empty((Ka, N), device=Wt.device, dtype=torch.float32)
+    check(_lib.hip().p2m_weight_eff(_p(_req(Wt, "Wt")), _p(We), Ka, N, float(a), float(b), _stream()), "p2m_weight_eff")
+    return We
+
+
+def weight_grad_unpack2(P, Pdb, nch, P2, Pdb2, nch2, s1, s2, Fout, Fin):
+    dW = torch.empty((Fout, Fin * 3), device=P.device, dtype=torch.float32)
+    db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
+    check(_lib.hip().p2m_weight_grad_unpack2(_p(P), _p(Pdb), nch, _p(P2), _p(Pdb2), nch2, float(s1), float(s2), _p(dW),
+                                             _p(db), Fout, Fin, 3, _stream()), "p2m_weight_grad_unpack2")
+    return dW, db
+
+
+def bn_finalize_rows(g, B, st_real, st_fake, gamma, beta, running_mean, running_var, momentum, eps):
+    N = gamma.shape[0]
+    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
+    lib = _lib.hip()
+    check(lib.p2m_bn_finalize_rows(_p(st_real), int(lib.p2m_rows_tiles_per_sample(g.handle, 1)), g.n_real,
+                                   _p(st_fake), int(lib.p2m_rows_tiles_per_sample(g.handle, 2)), g.n_fake, B,
+                                   _p(_req(gamma, "bn.weight")), _p(_req(beta, "bn.bias")), _p(running_mean),
+                                   _p(running_var), float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]),
+                                   _p(co[3]), N, _stream()), "p2m_bn_finalize_rows")
+    return co
+
+
 def weight_pack(W, Fin, K, need_w2=True, need_w3=False):
     """Wt [k*Fin+fin][Fout], W2 [Fout][k*Fin+fin] (optional), W3 [k*Fout+fout][Fin] (optional)."""
     Fout = W.shape[0]
@@ -226,7 +307,6 @@ def fused_stats_tile_rows(N):
 # The fused (gather-in-GEMM) kernel is correct and tested, but on the coarsening-tree vertex order its gathers
 # miss L2 35 % of the time and it only breaks even with basis-kernel + plane-GEMM, so the
 # network uses it only when asked: P2M_FUSED=1.
-import os as _os
 USE_FUSED = _os.environ.get("P2M_FUSED", "0") == "1"
 
 

@@ -253,3 +253,43 @@ def test_gemm_planes_addend_and_pair_out(ops):
                                pair_out=True)
     assert Cp.shape == (M // 2, N)
     assert (Cp.cpu() - ref.view(M // 2, 2, N).sum(1)).abs().max() < 4e-5
+
+
+def test_fake_vertex_split_matches_unsplit(ops):
+    """Row-set launches (real: 3-plane K, fake: K=Fin with W0 + a W1 + b W2) reproduce the plain conv, its
+    BatchNorm statistics, and the weight gradient (fake vertices are isolated)."""
+    V, Fin, Fout, B = 736, 64, 128, 3
+    L = _rand_graph(V, 11, fake_frac=0.4)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert g.n_real + g.n_fake == V and g.n_fake >= int(0.39 * V)
+    gen = torch.Generator().manual_seed(2)
+    M = B * V
+    X = torch.randn(M, Fin, generator=gen).cuda()
+    Wt = (torch.randn(3 * Fin, Fout, generator=gen) / 14).cuda()
+    bias = torch.randn(Fout, generator=gen).cuda()
+    # reference: full basis + plain GEMM
+    T1, T2 = ops.cheb_basis_fwd(g, X, B, Fin, 0)
+    (yref,), stref = ops.gemm_planes([X, T1, T2], Fin, 0, Wt, bias, M, Fout, 1, True)
+    # split
+    T1c, T2c = ops.cheb_basis_fwd_real(g, X, B, Fin, 0)
+    y = torch.full((M, Fout), float("nan"), device="cuda")
+    st1 = ops.gemm_planes_rows(g, 1, B, [X, T1c, T2c], Fin, 0, True, Wt, bias, None, y, Fout, True)
+    We = ops.weight_eff(Wt, Fin, Fout, g.fake_a, g.fake_b)
+    st2 = ops.gemm_planes_rows(g, 2, B, [X], Fin, 0, False, We, bias, None, y, Fout, True)
+    assert torch.isfinite(y).all()
+    assert (y - yref).abs().max() < 2e-5
+    gamma, beta = torch.ones(Fout).cuda(), torch.zeros(Fout).cuda()
+    co_ref = ops.bn_finalize(stref, M, gamma, beta, None, None, 0.1, 1e-5)
+    co = ops.bn_finalize_rows(g, B, st1, st2, gamma, beta, None, None, 0.1, 1e-5)
+    assert (co - co_ref).abs().max() < 1e-5
+    # weight gradient: X^T [gy | L gy | L2 gy]
+    gy = torch.randn(M, Fout, generator=gen).cuda()
+    E1, E2 = ops.cheb_basis_fwd(g, gy, B, Fout, 0)
+    P, Pdb, nch = ops.gemm_tn([X], Fin, 0, [gy, E1, E2], M, 3 * Fout)
+    dWref, dbref = ops.weight_grad_unpack(P, Pdb, nch, Fout, Fin, 3, layout=1)
+    E1c, E2c = ops.cheb_basis_fwd_real(g, gy, B, Fout, 0)
+    P1, Pb1, n1 = ops.gemm_tn_rows(g, 1, B, X, Fin, 0, [gy, E1c, E2c], Fout, True)
+    P2, Pb2, n2 = ops.gemm_tn_rows(g, 2, B, X, Fin, 0, [gy], Fout, False)
+    dW, db = ops.weight_grad_unpack2(P1, Pb1, n1, P2, Pb2, n2, g.fake_a, g.fake_b, Fout, Fin)
+    assert (dW - dWref).abs().max() < 1e-4 * max(1.0, dWref.abs().max().item())
+    assert (db - dbref).abs().max() < 1e-3
