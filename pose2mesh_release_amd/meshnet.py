@@ -126,11 +126,9 @@ class _MeshNetFn(torch.autograd.Function):
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
-                st = ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout,
-                                          need_stats)
                 We = ops.weight_eff(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b)
-                st2 = ops.gemm_planes_rows(g, 2, B, [cur], L.Fin, cur_shift, False, We, bvec, None, y, L.Fout,
-                                           need_stats)
+                st, st2 = ops.gemm_planes_split(g, B, cur, T1, T2, L.Fin, cur_shift, Wt, We, bvec, None, y, L.Fout,
+                                                need_stats)
                 tile_rows = "rows"
             elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
@@ -253,9 +251,8 @@ class _MeshNetFn(torch.autograd.Function):
                 E1, E2 = ops.cheb_basis_fwd_real(gph, gy, B, L.Fout, 0)
                 dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)
                 add = G if fuse_res else None
-                ops.gemm_planes_rows(gph, 1, B, [gy, E1, E2], L.Fout, 0, True, W2, None, add, dXf, L.Fin)
                 W3e = ops.weight_eff(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b)
-                ops.gemm_planes_rows(gph, 2, B, [gy], L.Fout, 0, False, W3e, None, add, dXf, L.Fin)
+                ops.gemm_planes_split(gph, B, gy, E1, E2, L.Fout, 0, W2, W3e, None, add, dXf, L.Fin)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
                 Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)

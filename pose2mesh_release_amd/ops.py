@@ -83,6 +83,7 @@ def _timed(name, work):
 
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
+SPLIT_CONCURRENT = _os.environ.get("P2M_SPLIT_CONCURRENT", "0") == "1"   # measured: no gain (2950 vs 2978 meshes/s)
 
 
 class DeviceGraph:
@@ -224,6 +225,39 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
                                               _p(st), _stream()), "p2m_gemm_planes_rows")
     return st
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """One helper stream per device for the fake-vertex launches (forked/joined inside the C call)."""
+    key = torch.device(device).index
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+def gemm_planes_split(g, B, A0, A1c, A2c, Ka, a0_shift, Bm, Bm_eff, bias, addend, C, N, stats=False):
+    """Real + fake vertex launches of one contraction, the fake one on the side stream.  Returns (st_real, st_fake)."""
+    lib = _lib.hip()
+    st1 = st2 = None
+    if stats:
+        st1 = torch.empty((B * int(lib.p2m_rows_tiles_per_sample(g.handle, 1)), 2, N), device=C.device, dtype=torch.float32)
+        st2 = torch.empty((B * max(1, int(lib.p2m_rows_tiles_per_sample(g.handle, 2))), 2, N), device=C.device,
+                          dtype=torch.float32)
+    flops = 2.0 * B * (g.n_real * 3 + g.n_fake) * Ka * N
+    side = side_stream(C.device) if SPLIT_CONCURRENT else None
+    with _timed("gemm_planes_mfma", flops):
+        check(lib.p2m_gemm_planes_split(g.handle, B, _p(_req(A0, "A0")), _p(_req(A1c, "A1")), _p(_req(A2c, "A2")), Ka,
+                                        a0_shift, _p(_req(Bm, "B")), _p(_req(Bm_eff, "Beff")),
+                                        _p(bias if bias is None else _req(bias, "bias")),
+                                        _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
+                                        _p(st1), _p(st2), None if side is None else _vp(side.cuda_stream), _stream()),
+              "p2m_gemm_planes_split")
+    return st1, st2
 
 
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
