@@ -544,14 +544,21 @@ __global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ W
   We[idx] = Wt[idx] + a * Wt[plane + idx] + b * Wt[2 * plane + idx];
 }
 
-__global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks,
-                                     float* __restrict__ dW, float* __restrict__ db, int Fout, int Fin, int K,
-                                     int accumulate, int layout, int pdb_stride, const float* __restrict__ P2,
-                                     const float* __restrict__ Pdb2, int nchunks2, float fake_a, float fake_b) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long tot = (long)Fout * Fin * K;
+// 256 threads = 32 consecutive output elements x 8 chunk groups: the partial buffers hold hundreds of chunks
+// (one per sample in row-set mode), so the chunk loop is split 8 ways and reduced through LDS.
+__global__ __launch_bounds__(256) void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb,
+                                                             int nchunks, float* __restrict__ dW, float* __restrict__ db,
+                                                             int Fout, int Fin, int K, int accumulate, int layout,
+                                                             int pdb_stride, const float* __restrict__ P2,
+                                                             const float* __restrict__ Pdb2, int nchunks2, float fake_a,
+                                                             float fake_b) {
+  __shared__ double red[8][32];
+  const int e = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + e;
+  const long tot = (long)Fout * Fin * K;
+  int fout = 0, k = 0, fin = 0;
+  double s = 0.0;
   if (idx < tot) {
-    int fout, k, fin;
     if (layout == 0) {            // P[chunk][k*Fin + fin][fout]
       fout = (int)(idx % Fout);
       long kk = idx / Fout;
@@ -561,30 +568,36 @@ __global__ void k_weight_grad_unpack(const float* __restrict__ P, const float* _
       fin = (int)(idx / ((long)K * Fout));
       k = (int)(nn / Fout); fout = (int)(nn % Fout);
     }
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // 4 independent chains: the loop is load-latency bound
-    int c = 0;
-    for (; c + 4 <= nchunks; c += 4) {
+    double s0 = 0.0, s1 = 0.0;
+    int c = cg;
+    for (; c + 8 < nchunks; c += 16) {
       s0 += (double)P[(long)c * tot + idx];
-      s1 += (double)P[(long)(c + 1) * tot + idx];
-      s2 += (double)P[(long)(c + 2) * tot + idx];
-      s3 += (double)P[(long)(c + 3) * tot + idx];
+      s1 += (double)P[(long)(c + 8) * tot + idx];
     }
-    for (; c < nchunks; c++) s0 += (double)P[(long)c * tot + idx];
-    double s = (s0 + s1) + (s2 + s3);
-    if (P2 != nullptr) {        // fake-vertex partials P2[chunk][fin][fout] enter plane k scaled by (1, a, b)[k]
+    for (; c < nchunks; c += 8) s0 += (double)P[(long)c * tot + idx];
+    s = s0 + s1;
+    if (P2 != nullptr) {          // fake-vertex partials P2[chunk][fin][fout] enter plane k scaled by (1, a, b)[k]
       double q = 0.0;
-      for (int c2 = 0; c2 < nchunks2; c2++) q += (double)P2[((long)c2 * Fin + fin) * Fout + fout];
+      for (int c2 = cg; c2 < nchunks2; c2 += 8) q += (double)P2[((long)c2 * Fin + fin) * Fout + fout];
       s += q * (k == 0 ? 1.0 : (k == 1 ? (double)fake_a : (double)fake_b));
     }
-    long o = (long)fout * Fin * K + (long)fin * K + k;
-    dW[o] = accumulate ? dW[o] + (float)s : (float)s;
   }
-  if (db != nullptr && Pdb != nullptr && idx < Fout) {
-    double s = 0.0;
-    for (int c = 0; c < nchunks; c++) s += (double)Pdb[(long)c * pdb_stride + idx];
+  red[cg][e] = s;
+  __syncthreads();
+  if (cg == 0 && idx < tot) {
+    double r = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) r += red[q][e];
+    const long o = (long)fout * Fin * K + (long)fin * K + k;
+    dW[o] = accumulate ? dW[o] + (float)r : (float)r;
+  }
+  // bias gradient: the first blocks also reduce Pdb (one thread per output feature)
+  if (db != nullptr && Pdb != nullptr && cg == 0 && idx < Fout) {
+    double r = 0.0;
+    for (int c = 0; c < nchunks; c++) r += (double)Pdb[(long)c * pdb_stride + idx];
     if (Pdb2 != nullptr)
-      for (int c2 = 0; c2 < nchunks2; c2++) s += (double)Pdb2[(long)c2 * Fout + idx];
-    db[idx] = accumulate ? db[idx] + (float)s : (float)s;
+      for (int c2 = 0; c2 < nchunks2; c2++) r += (double)Pdb2[(long)c2 * Fout + idx];
+    db[idx] = accumulate ? db[idx] + (float)r : (float)r;
   }
 }
 
@@ -824,7 +837,7 @@ extern "C" int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t
                                        int32_t Fout, int32_t Fin, int32_t K, void* stream) {
   P2M_CHECK_ARG(P && P2 && dW && Fout > 0 && Fin > 0 && K == 3 && nchunks > 0 && nchunks2 > 0, "null pointer or bad shape");
   long tot = (long)Fout * Fin * K;
-  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
                      dW, db, Fout, Fin, K, 0, 1, K * Fout, P2, Pdb2, nchunks2, s1, s2);
   return check_launch("weight_grad_unpack2");
 }
@@ -834,7 +847,7 @@ extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t 
                                       int32_t pdb_stride, void* stream) {
   P2M_CHECK_ARG(P && dW && Fout > 0 && Fin > 0 && K > 0 && nchunks > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
-  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
                      dW, db, Fout, Fin, K, accumulate, layout, pdb_stride, nullptr, nullptr, 0, 0.f, 0.f);
   return check_launch("weight_grad_unpack");
 }
