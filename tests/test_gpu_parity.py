@@ -186,3 +186,31 @@ def test_edge_cases(hip_libs):
     # state dict round trip with the reference's key set
     keys = set(net.state_dict().keys())
     assert "fc.weight" in keys and "cl.14.weight" in keys and "bn.13.running_var" in keys and "bn.14.weight" not in keys
+
+
+def test_fake_vertex_split_network_equivalence(hip_libs):
+    """The real/fake row-set launches (ops.SPLIT_FAKE) give the same network output and gradients as the unsplit
+    kernels (SMPL-like levels: 41 % padding vertices at the finest level)."""
+    from pose2mesh_release_amd import ops
+    gL, _, _ = helpers.golden_graphs("human36")
+    x = helpers.meshnet_input(2, 17, seed=5)
+    outs, grads = [], []
+    old = ops.SPLIT_FAKE
+    try:
+        for flag in (True, False):
+            ops.SPLIT_FAKE = flag
+            net = _net("human36", gL, seed=4).train()
+            assert any(g.split for g in net._graph_cache.on(torch.device("cuda", 0))) == flag
+            xg = x.cuda().requires_grad_(True)
+            y = net(xg)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
+            (y * w).sum().backward()
+            outs.append(y.detach())
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        ops.SPLIT_FAKE = old
+    assert helpers.max_vertex_l2(outs[0].cpu(), outs[1].cpu()) <= 2e-5
+    for k in grads[0]:
+        if k.startswith("cl.") and k.endswith("bias") and k != "cl.20.bias":
+            continue                      # exactly-zero gradients in front of train-mode BatchNorm (round-off only)
+        assert helpers.rel_l2(grads[0][k].cpu(), grads[1][k].cpu()) < 2e-2, k

@@ -1,5 +1,5 @@
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R]
 import torch
 from pose2mesh_release_amd import ops
