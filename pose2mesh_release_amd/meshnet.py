@@ -198,6 +198,26 @@ class _MeshNetFn(torch.autograd.Function):
         J = net.num_joint
         G = grad_out.contiguous().float().view(-1, net.num_mesh_output_chan)   # grad wrt current block output
         g_cur = G
+        keep = []          # tensors read by the side stream: kept alive until the join at the end of backward
+        main_stream = torch.cuda.current_stream()
+        side = ops.side_stream(grad_out.device) if ops.DW_SIDE_STREAM else None
+
+        class side_ctx:
+            """Runs the enclosed launches on the side stream, ordered after everything issued so far on main."""
+
+            def __init__(self, keep_list, *tensors):
+                keep_list.extend(tensors)
+
+            def __enter__(self):
+                if side is not None:
+                    side.wait_stream(main_stream)
+                    self.cm = torch.cuda.stream(side)
+                    self.cm.__enter__()
+
+            def __exit__(self, *a):
+                if side is not None:
+                    self.cm.__exit__(*a)
+                return False
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
@@ -254,9 +274,14 @@ class _MeshNetFn(torch.autograd.Function):
                 W3e = ops.weight_eff(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b)
                 ops.gemm_planes_split(gph, B, gy, E1, E2, L.Fout, 0, W2, W3e, None, add, dXf, L.Fin)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
-                Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
-                Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
-                dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout, L.Fin)
+                # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
+                # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
+                with side_ctx(keep, X, gy, E1, E2):
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
+                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
+                    dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
+                                                     L.Fin)
+                    keep.extend((Pw, Pb, Pw2, Pb2))
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, Pw2, Pb2, E1, E2, dXf
             elif _bwd_forward_form(L):
@@ -266,8 +291,10 @@ class _MeshNetFn(torch.autograd.Function):
                 E1, E2 = ops.cheb_basis_fwd(gph, gy, B, L.Fout, 0)
                 (dX,), _ = ops.gemm_planes([gy, E1, E2], L.Fout, 0, W2, None, M, L.Fin, 1, False,
                                            addend=G if fuse_res else None, pair_out=bool(x_shift))
-                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
-                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
+                with side_ctx(keep, X, gy, E1, E2):
+                    Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
+                    dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
+                    keep.extend((Pw, Pb))
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
             else:
@@ -286,6 +313,9 @@ class _MeshNetFn(torch.autograd.Function):
             g_cur = dX
             if L.first_in_block:
                 G = dX
+        if side is not None:
+            main_stream.wait_stream(side)      # join: all weight gradients are complete before autograd consumes them
+        keep.clear()
         ctx.saved = None
         gx = None
         if ctx.needs_input_grad[1]:

@@ -83,6 +83,7 @@ def _timed(name, work):
 
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
+DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
 SPLIT_CONCURRENT = _os.environ.get("P2M_SPLIT_CONCURRENT", "0") == "1"   # measured: no gain (2950 vs 2978 meshes/s)
 
 
