@@ -183,7 +183,11 @@ class _MeshNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         with torch.cuda.device(grad_out.device):
-            return _MeshNetFn._backward(ctx, grad_out)
+            ops.PHASE = "_bwd"
+            try:
+                return _MeshNetFn._backward(ctx, grad_out)
+            finally:
+                ops.PHASE = ""
 
     @staticmethod
     def _backward(ctx, grad_out):

@@ -76,10 +76,11 @@ class _NoBracket:
 
 _NOB = _NoBracket()
 TIMER = None
+PHASE = ""          # "" in forward, "_bwd" in backward: backward launches share the GPU with the side-stream dW GEMMs
 
 
 def _timed(name, work):
-    return _NOB if TIMER is None else TIMER.bracket(name, work)
+    return _NOB if TIMER is None else TIMER.bracket(name + PHASE, work)
 
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
