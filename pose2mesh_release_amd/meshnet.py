@@ -124,11 +124,9 @@ class _MeshNetFn(torch.autograd.Function):
             if split:
                 # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
-                T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
-                We = ops.weight_eff(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b)
-                st, st2 = ops.gemm_planes_split(g, B, cur, T1, T2, L.Fin, cur_shift, Wt, We, bvec, None, y, L.Fout,
-                                                need_stats)
+                T1, T2, st, st2 = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
+                                                 g.fake_b, need_stats)
                 tile_rows = "rows"
             elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
@@ -272,11 +270,9 @@ class _MeshNetFn(torch.autograd.Function):
                 del Pw, Pb, E1, E2
             elif _bwd_forward_form(L) and gph.split:
                 # forward-form backward, split into real / fake vertex launches (see the forward)
-                E1, E2 = ops.cheb_basis_fwd_real(gph, gy, B, L.Fout, 0)
                 dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)
                 add = G if fuse_res else None
-                W3e = ops.weight_eff(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b)
-                ops.gemm_planes_split(gph, B, gy, E1, E2, L.Fout, 0, W2, W3e, None, add, dXf, L.Fin)
+                E1, E2, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a, gph.fake_b)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers

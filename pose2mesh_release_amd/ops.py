@@ -232,14 +232,38 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
 _side_streams = {}
 
 
-def side_stream(device):
-    """One helper stream per device for the fake-vertex launches (forked/joined inside the C call)."""
-    key = torch.device(device).index
+def side_stream(device, which=0):
+    """Helper streams per device: 0 = weight-gradient GEMMs of the backward, 1 = fake-vertex GEMMs."""
+    key = (torch.device(device).index, which)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
         _side_streams[key] = st
     return st
+
+
+FAKE_SIDE_STREAM = _os.environ.get("P2M_FAKE_SIDE_STREAM", "0") == "1"   # measured: no gain (3410 vs 3421 meshes/s)
+
+
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False):
+    """One split contraction: basis of the real vertices (HBM-bound) on the current stream while the fake-vertex
+    GEMM (MFMA-bound, needs no basis planes) runs beside it on a side stream; then the real-vertex GEMM.
+    Returns (T1c, T2c, st_real, st_fake)."""
+    main = torch.cuda.current_stream()
+    side = side_stream(C.device, 1) if FAKE_SIDE_STREAM else None
+    if side is not None:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            We = weight_eff(Bm, Ka, N, fake_a, fake_b)
+            st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
+    T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
+    st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats)
+    if side is not None:
+        main.wait_stream(side)
+    else:
+        We = weight_eff(Bm, Ka, N, fake_a, fake_b)
+        st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
+    return T1c, T2c, st1, st2
 
 
 def gemm_planes_split(g, B, A0, A1c, A2c, Ka, a0_shift, Bm, Bm_eff, bias, addend, C, N, stats=False):
