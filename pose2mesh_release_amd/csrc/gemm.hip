@@ -544,15 +544,14 @@ __global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ W
   We[idx] = Wt[idx] + a * Wt[plane + idx] + b * Wt[2 * plane + idx];
 }
 
-// 256 threads = 32 consecutive output elements x 8 chunk groups: the partial buffers hold hundreds of chunks
-// (one per sample in row-set mode), so the chunk loop is split 8 ways and reduced through LDS.
-__global__ __launch_bounds__(256) void k_weight_grad_unpack(const float* __restrict__ P, const float* __restrict__ Pdb,
-                                                             int nchunks, float* __restrict__ dW, float* __restrict__ db,
-                                                             int Fout, int Fin, int K, int accumulate, int layout,
-                                                             int pdb_stride, const float* __restrict__ P2,
-                                                             const float* __restrict__ Pdb2, int nchunks2, float fake_a,
-                                                             float fake_b) {
-  __shared__ double red[8][32];
+// 1024 threads = 32 consecutive output elements x 32 chunk groups: the partial buffers hold hundreds of chunks
+// (one per sample in row-set mode), so the chunk loop is split 32 ways (4 loads in flight each) and reduced through LDS.
+constexpr int UNP_CG = 32;
+__global__ __launch_bounds__(32 * UNP_CG) void k_weight_grad_unpack(
+    const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks, float* __restrict__ dW,
+    float* __restrict__ db, int Fout, int Fin, int K, int accumulate, int layout, int pdb_stride,
+    const float* __restrict__ P2, const float* __restrict__ Pdb2, int nchunks2, float fake_a, float fake_b) {
+  __shared__ double red[UNP_CG][32];
   const int e = threadIdx.x & 31, cg = threadIdx.x >> 5;
   const long idx = (long)blockIdx.x * 32 + e;
   const long tot = (long)Fout * Fin * K;
@@ -568,18 +567,26 @@ __global__ __launch_bounds__(256) void k_weight_grad_unpack(const float* __restr
       fin = (int)(idx / ((long)K * Fout));
       k = (int)(nn / Fout); fout = (int)(nn % Fout);
     }
-    double s0 = 0.0, s1 = 0.0;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     int c = cg;
-    for (; c + 8 < nchunks; c += 16) {
-      s0 += (double)P[(long)c * tot + idx];
-      s1 += (double)P[(long)(c + 8) * tot + idx];
+    for (; c + 3 * UNP_CG < nchunks; c += 4 * UNP_CG) {
+      t0 += P[(long)c * tot + idx];
+      t1 += P[(long)(c + UNP_CG) * tot + idx];
+      t2 += P[(long)(c + 2 * UNP_CG) * tot + idx];
+      t3 += P[(long)(c + 3 * UNP_CG) * tot + idx];
     }
-    for (; c < nchunks; c += 8) s0 += (double)P[(long)c * tot + idx];
-    s = s0 + s1;
+    for (; c < nchunks; c += UNP_CG) t0 += P[(long)c * tot + idx];
+    s = ((double)t0 + (double)t1) + ((double)t2 + (double)t3);
     if (P2 != nullptr) {          // fake-vertex partials P2[chunk][fin][fout] enter plane k scaled by (1, a, b)[k]
-      double q = 0.0;
-      for (int c2 = cg; c2 < nchunks2; c2 += 8) q += (double)P2[((long)c2 * Fin + fin) * Fout + fout];
-      s += q * (k == 0 ? 1.0 : (k == 1 ? (double)fake_a : (double)fake_b));
+      const long o2 = (long)fin * Fout + fout, st2 = (long)Fin * Fout;
+      float q0 = 0.f, q1 = 0.f;
+      int c2 = cg;
+      for (; c2 + UNP_CG < nchunks2; c2 += 2 * UNP_CG) {
+        q0 += P2[(long)c2 * st2 + o2];
+        q1 += P2[(long)(c2 + UNP_CG) * st2 + o2];
+      }
+      for (; c2 < nchunks2; c2 += UNP_CG) q0 += P2[(long)c2 * st2 + o2];
+      s += ((double)q0 + (double)q1) * (k == 0 ? 1.0 : (k == 1 ? (double)fake_a : (double)fake_b));
     }
   }
   red[cg][e] = s;
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256) void k_weight_grad_unpack(const float* __restr
   if (cg == 0 && idx < tot) {
     double r = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) r += red[q][e];
+    for (int q = 0; q < UNP_CG; q++) r += red[q][e];
     const long o = (long)fout * Fin * K + (long)fin * K + k;
     dW[o] = accumulate ? dW[o] + (float)r : (float)r;
   }
@@ -837,7 +844,7 @@ extern "C" int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t
                                        int32_t Fout, int32_t Fin, int32_t K, void* stream) {
   P2M_CHECK_ARG(P && P2 && dW && Fout > 0 && Fin > 0 && K == 3 && nchunks > 0 && nchunks2 > 0, "null pointer or bad shape");
   long tot = (long)Fout * Fin * K;
-  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(32 * UNP_CG), 0, (hipStream_t)stream, P, Pdb, nchunks,
                      dW, db, Fout, Fin, K, 0, 1, K * Fout, P2, Pdb2, nchunks2, s1, s2);
   return check_launch("weight_grad_unpack2");
 }
@@ -847,7 +854,7 @@ extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t 
                                       int32_t pdb_stride, void* stream) {
   P2M_CHECK_ARG(P && dW && Fout > 0 && Fin > 0 && K > 0 && nchunks > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
-  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(256), 0, (hipStream_t)stream, P, Pdb, nchunks,
+  hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(32 * UNP_CG), 0, (hipStream_t)stream, P, Pdb, nchunks,
                      dW, db, Fout, Fin, K, accumulate, layout, pdb_stride, nullptr, nullptr, 0, 0.f, 0.f);
   return check_launch("weight_grad_unpack");
 }
