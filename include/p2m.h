@@ -181,12 +181,6 @@ int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float*
                          const float* Bm, const float* bias, const float* addend, float* C, int32_t N,
                          float* stats, void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
-/* Both launches of one conv: real vertices ([A0|A1c|A2c] Bm, planes 1,2 compact) on `stream` and fake vertices
- * (A0 Bm_eff) on `side_stream`, forked/joined with events owned by the handle (NULL side_stream: sequential).  */
-int p2m_gemm_planes_split(p2m_graph_t g, int32_t B, const float* A0, const float* A1c, const float* A2c, int32_t Ka,
-                          int32_t a0_shift, const float* Bm, const float* Bm_eff, const float* bias,
-                          const float* addend, float* C, int32_t N, float* stats_real, float* stats_fake,
-                          void* side_stream, void* stream);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,

@@ -35,8 +35,6 @@ HIP_SYMBOLS = {
     "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                         _i32, _vp, _vp]),
-    "p2m_gemm_planes_split": (_c.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
-                                         _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                     _vp]),

@@ -128,12 +128,6 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
     p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
     return rc;
   }
-  if (hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess) {
-    set_error("hipEventCreate failed");
-    p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
-    return P2M_ERR_HIP;
-  }
   *out = reinterpret_cast<p2m_graph_t>(g);
   return P2M_OK;
 }
@@ -145,8 +139,6 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->col) (void)hipFree(g->col);
   if (g->a) (void)hipFree(g->a);
   if (g->b) (void)hipFree(g->b);
-  if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-  if (g->ev_join) (void)hipEventDestroy(g->ev_join);
   if (g->real_ids) (void)hipFree(g->real_ids);
   if (g->fake_ids) (void)hipFree(g->fake_ids);
   delete g;

@@ -716,37 +716,6 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   return check_launch("gemm_planes_rows");
 }
 
-// Real-vertex launch on `stream`, fake-vertex launch on `side_stream` (fork/join with the handle's events): the
-// fake launch is short (K = Fin: a few chunks per tile) and mostly tile-overhead; running it BESIDE the real launch
-// fills its bubbles.  After the call everything is ordered on `stream` again.  side_stream == NULL: sequential.
-extern "C" int p2m_gemm_planes_split(p2m_graph_t gh, int32_t B, const float* A0, const float* A1c, const float* A2c,
-                                     int32_t Ka, int32_t a0_shift, const float* Bm, const float* Bm_eff,
-                                     const float* bias, const float* addend, float* C, int32_t N, float* stats_real,
-                                     float* stats_fake, void* side_stream, void* stream) {
-  P2M_CHECK_ARG(gh && A0 && A1c && A2c && Bm && Bm_eff && C, "null pointer");
-  Graph& gr = *reinterpret_cast<Graph*>(gh);
-  hipStream_t main = (hipStream_t)stream, side = (hipStream_t)side_stream;
-  const bool fork = side != nullptr && side != main && gr.n_fake > 0;
-  if (fork) {
-    if (hipEventRecord(gr.ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, gr.ev_fork, 0) != hipSuccess) {
-      set_error("p2m_gemm_planes_split: fork failed");
-      return P2M_ERR_HIP;
-    }
-  }
-  int rc = p2m_gemm_planes_rows(gh, 2, B, A0, nullptr, nullptr, 1, Ka, a0_shift, 0, Bm_eff, bias, addend, C, N,
-                                stats_fake, fork ? side_stream : stream);
-  if (rc != P2M_OK) return rc;
-  rc = p2m_gemm_planes_rows(gh, 1, B, A0, A1c, A2c, 3, Ka, a0_shift, 1, Bm, bias, addend, C, N, stats_real, stream);
-  if (rc != P2M_OK) return rc;
-  if (fork) {
-    if (hipEventRecord(gr.ev_join, side) != hipSuccess || hipStreamWaitEvent(main, gr.ev_join, 0) != hipSuccess) {
-      set_error("p2m_gemm_planes_split: join failed");
-      return P2M_ERR_HIP;
-    }
-  }
-  return P2M_OK;
-}
-
 // rows per sample tile count of a row set (for the BatchNorm finalize): tiles_per_sample = ceil(n / 128)
 extern "C" int32_t p2m_rows_tiles_per_sample(p2m_graph_t gh, int32_t row_set) {
   if (!gh || (row_set != 1 && row_set != 2)) return 0;

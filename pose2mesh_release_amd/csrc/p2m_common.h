@@ -30,8 +30,6 @@ struct Graph {
   int* real_ids = nullptr;   // [n_real]
   int* fake_ids = nullptr;   // [n_fake]
   float fake_a = 0.f, fake_b = 0.f;
-  // fork/join events for running the (short) fake-vertex launch beside the real-vertex launch on a side stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)

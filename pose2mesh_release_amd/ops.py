@@ -85,7 +85,6 @@ def _timed(name, work):
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
 DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
-SPLIT_CONCURRENT = _os.environ.get("P2M_SPLIT_CONCURRENT", "0") == "1"   # measured: no gain (2950 vs 2978 meshes/s)
 
 
 class DeviceGraph:
@@ -233,7 +232,7 @@ _side_streams = {}
 
 
 def side_stream(device, which=0):
-    """Helper streams per device: 0 = weight-gradient GEMMs of the backward, 1 = fake-vertex GEMMs."""
+    """Helper streams per device (0 = weight-gradient GEMMs of the backward)."""
     key = (torch.device(device).index, which)
     st = _side_streams.get(key)
     if st is None:
@@ -242,48 +241,15 @@ def side_stream(device, which=0):
     return st
 
 
-FAKE_SIDE_STREAM = _os.environ.get("P2M_FAKE_SIDE_STREAM", "0") == "1"   # measured: no gain (3410 vs 3421 meshes/s)
-
-
 def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False):
-    """One split contraction: basis of the real vertices (HBM-bound) on the current stream while the fake-vertex
-    GEMM (MFMA-bound, needs no basis planes) runs beside it on a side stream; then the real-vertex GEMM.
-    Returns (T1c, T2c, st_real, st_fake)."""
-    main = torch.cuda.current_stream()
-    side = side_stream(C.device, 1) if FAKE_SIDE_STREAM else None
-    if side is not None:
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            We = weight_eff(Bm, Ka, N, fake_a, fake_b)
-            st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
+    """One split contraction: basis planes of the real vertices, the real-vertex GEMM (K = 3*Ka), then the fake-vertex
+    GEMM (K = Ka, W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's
+    basis on a side stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake)."""
     T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
     st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats)
-    if side is not None:
-        main.wait_stream(side)
-    else:
-        We = weight_eff(Bm, Ka, N, fake_a, fake_b)
-        st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
+    We = weight_eff(Bm, Ka, N, fake_a, fake_b)
+    st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
     return T1c, T2c, st1, st2
-
-
-def gemm_planes_split(g, B, A0, A1c, A2c, Ka, a0_shift, Bm, Bm_eff, bias, addend, C, N, stats=False):
-    """Real + fake vertex launches of one contraction, the fake one on the side stream.  Returns (st_real, st_fake)."""
-    lib = _lib.hip()
-    st1 = st2 = None
-    if stats:
-        st1 = torch.empty((B * int(lib.p2m_rows_tiles_per_sample(g.handle, 1)), 2, N), device=C.device, dtype=torch.float32)
-        st2 = torch.empty((B * max(1, int(lib.p2m_rows_tiles_per_sample(g.handle, 2))), 2, N), device=C.device,
-                          dtype=torch.float32)
-    flops = 2.0 * B * (g.n_real * 3 + g.n_fake) * Ka * N
-    side = side_stream(C.device) if SPLIT_CONCURRENT else None
-    with _timed("gemm_planes_mfma", flops):
-        check(lib.p2m_gemm_planes_split(g.handle, B, _p(_req(A0, "A0")), _p(_req(A1c, "A1")), _p(_req(A2c, "A2")), Ka,
-                                        a0_shift, _p(_req(Bm, "B")), _p(_req(Bm_eff, "Beff")),
-                                        _p(bias if bias is None else _req(bias, "bias")),
-                                        _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
-                                        _p(st1), _p(st2), None if side is None else _vp(side.cuda_stream), _stream()),
-              "p2m_gemm_planes_split")
-    return st1, st2
 
 
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
