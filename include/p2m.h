@@ -107,11 +107,20 @@ int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, fl
  * addend (optional, single output plane): [M, N] added to the result (the block residual's gradient);
  * pair_out (single output plane): C is [M/2, N] and receives the sum of the two children rows of every
  * coarse vertex -- backward of nn.Upsample (meshnet.py:74) in the epilogue.  The backward uses this entry
- * point in "forward form": dX = [g | L g | L2 g] W3 with the planes from p2m_cheb_basis_fwd(g).      */
+ * point in "forward form": dX = [g | L g | L2 g] W3 with the planes from p2m_cheb_basis_fwd(g).
+ *
+ * Arithmetic.  Bsplit == NULL: native f32 MFMA (bitwise an fmaf chain).  Bsplit != NULL (made from the same Bm by
+ * p2m_weight_split): the same fp32 contraction on the BF16 matrix pipe - both operands are cut EXACTLY into three
+ * bf16 slices (8+8+8 significand bits) and the six slice products of weight >= 2^-16 are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |a b|, i.e. fp32-level error at 6/16 of the MFMA cost.   */
 int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                    int32_t a0_shift, const float* Bm, const float* bias, const float* addend,
+                    int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias, const float* addend,
                     float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out,
                     int64_t M, float* stats, void* stream);
+/* Bx[s][n][k] (uint16 bf16 bit patterns; s < 3; n < ceil(N/128)*128, zero padded; k < K) = s-th slice of Bm[k][n],
+ * Bm = Bx[0] + Bx[1] + Bx[2] exactly.  p2m_weight_split_elems(K, N) = number of uint16 elements of Bx.              */
+int64_t p2m_weight_split_elems(int32_t K, int32_t N);
+int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream);
 /* rows per BatchNorm partial tile and the number of tiles for M rows */
 int32_t p2m_stats_tile_rows(void);
 
@@ -178,8 +187,8 @@ int p2m_cheb_basis_fwd_real(p2m_graph_t g, const float* X, float* T1c, float* T2
  * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.                  */
 int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
-                         const float* Bm, const float* bias, const float* addend, float* C, int32_t N,
-                         float* stats, void* stream);
+                         const float* Bm, const void* Bsplit, const float* bias, const float* addend, float* C,
+                         int32_t N, float* stats, void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */

@@ -34,7 +34,7 @@ HIP_SYMBOLS = {
     "p2m_graph_split_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2), _c.POINTER(_f32 * 2)]),
     "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                        _i32, _vp, _vp]),
+                                        _vp, _i32, _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                     _vp]),
@@ -47,8 +47,10 @@ HIP_SYMBOLS = {
                                        _vp]),
     "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "p2m_fused_stats_tile_rows": (_i32, [_i32]),
-    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i64, _vp, _vp]),
+    "p2m_weight_split_elems": (_i64, [_i32, _i32]),
+    "p2m_weight_split": (_c.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),
     "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp,
                                _vp]),

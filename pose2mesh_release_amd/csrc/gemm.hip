@@ -19,6 +19,9 @@
 namespace p2m {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -40,6 +43,9 @@ struct GemmArgs {
   // (tps tiles per sample); planes 1,2 of A are COMPACT ([B*nset, Ka]) when `compact`
   const int* ids;
   int nset, V, tps, compact;
+  // split-bf16 mode (k_gemm_planes_bx): Bx[s][n][k], s < 3, n < Npad, k < Ktot = nplanesA * Ka  (p2m_weight_split)
+  const unsigned short* Bx;
+  int Npad, Ktot;
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -51,6 +57,105 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
   nt = slot % ntn;
   mt = (slot / ntn) * 8 + xcd;
   return mt < ntm;
+}
+
+// Epilogue shared by the native-fp32 and the split-bf16 kernels: bias (+ addend), store (or pair-sum store), and the
+// per-tile BatchNorm partials (sum, centred M2).  `red` is block LDS that is free once the k loop is over.
+template <int BN, bool EXTRA, bool ROWS>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][BN / 64], float* smem,
+                                              const int* rowtab, int mt, long m0, int n0, int rs_i0, int wm, int wn,
+                                              int l31, int lhi) {
+  constexpr int WTN = BN / 2;
+  constexpr int TN = WTN / 32;
+  constexpr int TM = 2;
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float bias_v[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    ncol[j] = n0 + wn * WTN + j * 32 + l31;
+    bias_v[j] = (g.bias != nullptr && ncol[j] < g.N) ? g.bias[ncol[j]] : 0.f;
+  }
+  float csum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) csum[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = ncol[j];
+      const int q = n / g.Nc;
+      const int c = n - q * g.Nc;
+      float* Cq = (n < g.N) ? g.C[q] : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        long row = ROWS ? (long)rowtab[ml] : m0 + ml;
+        const bool rok = ROWS ? (row >= 0) : (row < g.M);
+        float v = acc[i][j][r] + bias_v[j];
+        if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
+        acc[i][j][r] = rok ? v : 0.f;
+        if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
+          Cq[row * g.Nc + c] = v;
+          csum[j] += v;
+        }
+      }
+      if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < g.M) Cq[(row >> 1) * g.Nc + c] = acc[i][j][r] + acc[i][j][r + 1];
+        }
+      }
+    }
+  if (g.stats == nullptr) return;
+
+  // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
+  float* red = smem;  // [2 (wm)][BN]   (safe: all waves passed the last __syncthreads of the k loop)
+  long rows_valid = ROWS ? (long)(g.nset - rs_i0) : g.M - m0;
+  if (rows_valid > BM) rows_valid = BM;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    csum[j] += __shfl_xor(csum[j], 32);
+    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = csum[j];
+  }
+  __syncthreads();
+  float cm2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int cl = wn * WTN + j * 32 + l31;
+    const float tot = red[cl] + red[BN + cl];
+    const float mean = tot / (float)rows_valid;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float d = acc[i][j][r] - mean;
+        if (ROWS ? (rowtab[ml] >= 0) : (m0 + ml < g.M)) m2 += d * d;
+      }
+    m2 += __shfl_xor(m2, 32);
+    cm2[j] = m2;
+    csum[j] = tot;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = cm2[j];
+  __syncthreads();
+  if (wm == 0 && lhi == 0) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int cl = wn * WTN + j * 32 + l31;
+      const int n = n0 + cl;
+      if (n < g.N) {
+        float* st = g.stats + (long)mt * 2 * g.N;
+        st[n] = csum[j];
+        st[g.N + n] = red[cl] + red[BN + cl];
+      }
+    }
+  }
 }
 
 // KB = K chunk staged per barrier (16: 34 KB LDS -> 3 blocks/CU; 32: 67 KB -> 2 blocks/CU);
@@ -189,95 +294,206 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias, store, BatchNorm partials ------------------------------------------
-  // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float bias_v[TN];
-  int ncol[TN];
-#pragma unroll
-  for (int j = 0; j < TN; j++) {
-    ncol[j] = n0 + wn * WTN + j * 32 + l31;
-    bias_v[j] = (g.bias != nullptr && ncol[j] < g.N) ? g.bias[ncol[j]] : 0.f;
+  gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 contraction on the BF16 matrix pipe (16x the rate of the f32 MFMA on gfx950).
+//
+// Every fp32 operand is cut into three bf16 slices by TRUNCATION: x = h + m + l exactly (8 + 8 + 8 significand bits;
+// each remainder x - h, x - h - m is exact in fp32).  The product keeps the six slice pairs of weight >= 2^-16,
+//     x*y ~= h h' + (h m' + m h') + (h l' + l h' + m m'),
+// each pair exact inside v_mfma_f32_32x32x16_bf16 (8b x 8b significands) and accumulated in fp32; the dropped pairs
+// (m l', l m', l l') are <= 2^-23 |x y| together - one fp32 rounding.  tests/test_gpu_ops.py checks the result against
+// float64 with the same bound as the native f32 MFMA kernel.  Six bf16 MFMAs cost 6/16 of one f32 MFMA per flop.
+//
+// Same block/wave tiling, row addressing, staging pipeline and epilogue as k_gemm_planes.  A is split while it is
+// staged (fp32 global -> 3 bf16 planes in LDS); the weights arrive pre-split and k-contiguous (p2m_weight_split), so
+// their staging is a straight 16-byte copy.  LDS rows hold KB bf16 + 8 pad: the 48 / 80-byte row stride makes the
+// 16-lane groups of ds_read_b128 hit all 64 banks once.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {   // slices in the HIGH halves
+  h = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | hi_elem; }
+
+template <int BN, int KB, bool EXTRA, bool ROWS = false>
+__global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
+  constexpr int NS = 3;          // slices per operand
+  static_assert(BN * (KB / 8) % 256 == 0 || BN * (KB / 8) < 256, "B staging");
+  constexpr int WTN = BN / 2;
+  constexpr int TN = WTN / 32;
+  constexpr int TM = 2;
+  constexpr int LDX = KB + 8;                     // bf16 elements per LDS row
+  constexpr int APASS = BM * KB / 4 / 256;        // float4 A loads per thread per chunk
+  constexpr int AROWS = 256 / (KB / 4);
+  constexpr int BSEG = BN * (KB / 8);             // 16-byte segments of one B slice per chunk
+  constexpr int BPASS = (BSEG + 255) / 256;
+  constexpr int A_BUF = NS * BM * LDX;            // bf16 elements of one A buffer
+  constexpr int B_BUF = NS * BN * LDX;
+  constexpr int SM_WORDS = (2 * A_BUF + 2 * B_BUF) / 2 + (ROWS ? BM : 0);
+  static_assert(SM_WORDS >= 2 * BN, "epilogue scratch");
+  __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bs = As + 2 * A_BUF;
+  int* rowtab = reinterpret_cast<int*>(smem + (2 * A_BUF + 2 * B_BUF) / 2);
+
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
+  const long m0 = (long)mt * BM;
+  const int n0 = nt * BN;
+  const int t = threadIdx.x;
+  const int rs_b = ROWS ? mt / g.tps : 0;
+  const int rs_i0 = ROWS ? (mt - rs_b * g.tps) * BM : 0;
+  if (ROWS && t < BM) {
+    const int i = rs_i0 + t;
+    rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
   }
-  float csum[TN];
-#pragma unroll
-  for (int j = 0; j < TN; j++) csum[j] = 0.f;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int n = ncol[j];
-      const int q = n / g.Nc;
-      const int c = n - q * g.Nc;
-      float* Cq = (n < g.N) ? g.C[q] : nullptr;
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        long row = ROWS ? (long)rowtab[ml] : m0 + ml;
-        const bool rok = ROWS ? (row >= 0) : (row < g.M);
-        float v = acc[i][j][r] + bias_v[j];
-        if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
-        acc[i][j][r] = rok ? v : 0.f;
-        if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
-          Cq[row * g.Nc + c] = v;
-          csum[j] += v;
-        }
-      }
-      if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < g.M) Cq[(row >> 1) * g.Nc + c] = acc[i][j][r] + acc[i][j][r + 1];
-        }
-      }
-    }
-  if (g.stats == nullptr) return;
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
-  float* red = smem;  // [2 (wm)][BN]   (safe: all waves passed the last __syncthreads of the k loop)
-  long rows_valid = ROWS ? (long)(g.nset - rs_i0) : g.M - m0;
-  if (rows_valid > BM) rows_valid = BM;
+  const int cpp = g.Ka / KB;
+  const int nchunks = g.nplanesA * cpp;
+
+  float4 ra[APASS];
+  u32x4 rb[BPASS * NS];   // native vector type (HIP's struct vector type kept this array in scratch)
+  const int a_row = t / (KB / 4), a_k4 = (t % (KB / 4)) * 4;
+  long rs_full[ROWS ? APASS : 1], rs_comp[ROWS ? APASS : 1];
+  if (ROWS) {
 #pragma unroll
-  for (int j = 0; j < TN; j++) {
-    csum[j] += __shfl_xor(csum[j], 32);
-    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = csum[j];
-  }
-  __syncthreads();
-  float cm2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; j++) {
-    const int cl = wn * WTN + j * 32 + l31;
-    const float tot = red[cl] + red[BN + cl];
-    const float mean = tot / (float)rows_valid;
-    float m2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        float d = acc[i][j][r] - mean;
-        if (ROWS ? (rowtab[ml] >= 0) : (m0 + ml < g.M)) m2 += d * d;
-      }
-    m2 += __shfl_xor(m2, 32);
-    cm2[j] = m2;
-    csum[j] = tot;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < TN; j++)
-    if (lhi == 0) red[wm * BN + wn * WTN + j * 32 + l31] = cm2[j];
-  __syncthreads();
-  if (wm == 0 && lhi == 0) {
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int cl = wn * WTN + j * 32 + l31;
-      const int n = n0 + cl;
-      if (n < g.N) {
-        float* st = g.stats + (long)mt * 2 * g.N;
-        st[n] = csum[j];
-        st[g.N + n] = red[cl] + red[BN + cl];
+    for (int ps = 0; ps < APASS; ps++) {
+      const int i = rs_i0 + ps * AROWS + a_row;
+      if (i < g.nset) {
+        rs_full[ps] = (long)rs_b * g.V + g.ids[i];
+        rs_comp[ps] = (long)rs_b * g.nset + i;
+      } else {
+        rs_full[ps] = -1;
+        rs_comp[ps] = -1;
       }
     }
   }
+  const long bx_slice = (long)g.Npad * g.Ktot;    // elements between two slices of Bx
+
+  auto load_chunk = [&](int kc) {
+    const int p = kc / cpp;
+    const int k0 = (kc - p * cpp) * KB;
+    const float* Ap = g.A[p];
+    const int sh = (p == 0) ? g.a0_shift : 0;
+#pragma unroll
+    for (int ps = 0; ps < APASS; ps++) {
+      long r;
+      if (ROWS) r = (p == 0 || !g.compact) ? rs_full[ps] : rs_comp[ps];
+      else { r = m0 + ps * AROWS + a_row; if (r >= g.M) r = -1; }
+      if (r >= 0)
+        ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
+      else
+        ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ps++) {
+      const int seg = (ps * 256 + t) % BSEG;     // BSEG < 256 (BN = 64): the upper threads duplicate the lower ones
+      const int n = seg / (KB / 8), ks = (seg % (KB / 8)) * 8;
+      const unsigned short* src = g.Bx + (long)(n0 + n) * g.Ktot + p * g.Ka + k0 + ks;   // n0 + n < Npad always
+      rb[ps * NS + 0] = *reinterpret_cast<const u32x4*>(src);
+      rb[ps * NS + 1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
+      rb[ps * NS + 2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned short* as = As + buf * A_BUF;
+#pragma unroll
+    for (int ps = 0; ps < APASS; ps++) {
+      unsigned h[4], m[4], l[4];
+      split3(ra[ps].x, h[0], m[0], l[0]);
+      split3(ra[ps].y, h[1], m[1], l[1]);
+      split3(ra[ps].z, h[2], m[2], l[2]);
+      split3(ra[ps].w, h[3], m[3], l[3]);
+      unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
+      *reinterpret_cast<u32x2*>(d) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
+      *reinterpret_cast<u32x2*>(d + BM * LDX) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
+      *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+    }
+    unsigned short* bs = Bs + buf * B_BUF;
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ps++) {
+      const int seg = (ps * 256 + t) % BSEG;
+      const int n = seg / (KB / 8), ks = (seg % (KB / 8)) * 8;
+      unsigned short* d = bs + n * LDX + ks;
+      *reinterpret_cast<u32x4*>(d) = rb[ps * NS + 0];
+      *reinterpret_cast<u32x4*>(d + BN * LDX) = rb[ps * NS + 1];
+      *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = rb[ps * NS + 2];
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int kc = 0; kc < nchunks; kc++) {
+    const int cur = kc & 1;
+    if (kc + 1 < nchunks) load_chunk(kc + 1);
+    const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
+    const unsigned short* bs = Bs + cur * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ks++) {
+      // explicit slice registers (an indexed [slice][tile] array gets demoted to LDS by the compiler)
+      bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const unsigned short* q = as + i * 32 * LDX + ks * 16;
+        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
+        am[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BM * LDX));
+        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BM * LDX));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const unsigned short* q = bs + j * 32 * LDX + ks * 16;
+        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
+        bm[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BN * LDX));
+        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BN * LDX));
+      }
+      // smallest pairs first; the TM*TN accumulators are independent, so consecutive MFMAs never chain
+#define P2M_PAIR(XA, XB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA[i], XB[j], acc[i][j], 0, 0, 0);
+      P2M_PAIR(al, bh)
+      P2M_PAIR(ah, bl)
+      P2M_PAIR(am, bm)
+      P2M_PAIR(am, bh)
+      P2M_PAIR(ah, bm)
+      P2M_PAIR(ah, bh)
+#undef P2M_PAIR
+    }
+    if (kc + 1 < nchunks) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+  gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
+}
+
+// Bx[s][n][k] = s-th bf16 slice of Bm[k][n] (zero for N <= n < Npad): the k-contiguous, pre-split weight operand
+__global__ void k_weight_split(const float* __restrict__ Bm, unsigned short* __restrict__ Bx, int K, int N, int Npad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Npad * K) return;
+  const int n = (int)(i / K), k = (int)(i - (long)n * K);
+  unsigned h = 0, m = 0, l = 0;
+  if (n < N) split3(Bm[(long)k * N + n], h, m, l);
+  const long sl = (long)Npad * K;
+  Bx[i] = (unsigned short)(h >> 16);
+  Bx[sl + i] = (unsigned short)(m >> 16);
+  Bx[2 * sl + i] = (unsigned short)(l >> 16);
 }
 
 // scalar fall-back (first conv Fin=5 -> K=15; last conv Fout=3): one thread per (row, n)
@@ -614,18 +830,62 @@ using namespace p2m;
 
 extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
 
-static int gemm_kb() {          // K chunk per barrier of k_gemm_planes (tuning knob, P2M_GEMM_KB=16|32)
-  static int kb = [] {
-    const char* e = getenv("P2M_GEMM_KB");
-    return (e && atoi(e) == 16) ? 16 : 32;
-  }();
-  return kb;
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+// tuning knobs: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32) and of the split-bf16 kernel
+// (P2M_GEMM_BX_KB=16|32; 32 needs 123 KB of LDS -> one block per CU)
+static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 32; return kb; }
+static int gemm_bx_kb() { static int kb = env_int("P2M_GEMM_BX_KB", 16) == 32 ? 32 : 16; return kb; }
+
+extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
+  if (K <= 0 || N <= 0) return 0;
+  return 3ll * (cdiv(N, 128) * 128ll) * K;
+}
+
+extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream) {
+  P2M_CHECK_ARG(Bm && Bx && K > 0 && N > 0, "null pointer or empty shape");
+  const int Npad = cdiv(N, 128) * 128;
+  hipLaunchKernelGGL(k_weight_split, dim3(cdiv((long)Npad * K, 256)), dim3(256), 0, (hipStream_t)stream, Bm,
+                     static_cast<unsigned short*>(Bx), K, N, Npad);
+  return check_launch("weight_split");
+}
+
+// picks the instantiation: tile width from N, EXTRA epilogue, native f32 MFMA or split-bf16 (g.Bx != nullptr)
+template <bool ROWS>
+static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
+  const bool wide = (g.N % 128 == 0);
+  g.ntn = wide ? g.N / 128 : cdiv(g.N, 64);
+  const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn), block(256);
+#define P2M_LAUNCH(KERNEL, BNv, KBv, EX) hipLaunchKernelGGL((KERNEL<BNv, KBv, EX, ROWS>), grid, block, 0, s, g)
+  if (g.Bx != nullptr) {
+    const bool kb32 = gemm_bx_kb() == 32 && wide && g.Ka % 32 == 0;
+    if (wide) {
+      if (kb32) { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 32, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 32, false); }
+      else { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 16, false); }
+    } else {
+      if (extra) P2M_LAUNCH(k_gemm_planes_bx, 64, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 64, 16, false);
+    }
+  } else {
+    const bool kb16 = !ROWS && !extra && gemm_kb() == 16;
+    if (wide) {
+      if (extra) P2M_LAUNCH(k_gemm_planes, 128, 32, true);
+      else if (kb16) P2M_LAUNCH(k_gemm_planes, 128, 16, false);
+      else P2M_LAUNCH(k_gemm_planes, 128, 32, false);
+    } else {
+      if (extra) P2M_LAUNCH(k_gemm_planes, 64, 32, true);
+      else if (kb16) P2M_LAUNCH(k_gemm_planes, 64, 16, false);
+      else P2M_LAUNCH(k_gemm_planes, 64, 32, false);
+    }
+  }
+#undef P2M_LAUNCH
 }
 
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                               int32_t a0_shift, const float* Bm, const float* bias, const float* addend, float* C0,
-                               float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out, int64_t M,
-                               float* stats, void* stream) {
+                               int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias,
+                               const float* addend, float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc,
+                               int32_t pair_out, int64_t M, float* stats, void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesC >= 1 && nplanesC <= 3, "plane count must be 1..3");
   P2M_CHECK_ARG(A0 && Bm && C0 && Ka > 0 && Nc > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
@@ -641,6 +901,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
   g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0;
+  g.Bx = nullptr; g.Npad = 0; g.Ktot = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
   if (!mfma_ok) {
@@ -654,35 +915,20 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
     }
     return check_launch("gemm_planes(naive)");
   }
-  g.ntm = cdiv(M, BM);
-  if (g.N % 128 == 0) {
-    g.ntn = g.N / 128;
-    int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    const bool extra = addend != nullptr || pair_out;
-    if (extra)
-      hipLaunchKernelGGL((k_gemm_planes<128, 32, true>), dim3(grid), dim3(256), 0, s, g);
-    else if (gemm_kb() == 16)
-      hipLaunchKernelGGL((k_gemm_planes<128, 16, false>), dim3(grid), dim3(256), 0, s, g);
-    else
-      hipLaunchKernelGGL((k_gemm_planes<128, 32, false>), dim3(grid), dim3(256), 0, s, g);
-  } else {
-    g.ntn = cdiv(g.N, 64);
-    int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    const bool extra = addend != nullptr || pair_out;
-    if (extra)
-      hipLaunchKernelGGL((k_gemm_planes<64, 32, true>), dim3(grid), dim3(256), 0, s, g);
-    else if (gemm_kb() == 16)
-      hipLaunchKernelGGL((k_gemm_planes<64, 16, false>), dim3(grid), dim3(256), 0, s, g);
-    else
-      hipLaunchKernelGGL((k_gemm_planes<64, 32, false>), dim3(grid), dim3(256), 0, s, g);
+  if (Bsplit != nullptr) {
+    g.Bx = static_cast<const unsigned short*>(Bsplit);
+    g.Npad = cdiv(g.N, 128) * 128;
+    g.Ktot = nplanesA * Ka;
   }
+  g.ntm = cdiv(M, BM);
+  launch_gemm_planes<false>(g, addend != nullptr || pair_out, s);
   return check_launch("gemm_planes");
 }
 
 extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
                                     const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                    int32_t planes_compact, const float* Bm, const float* bias, const float* addend,
-                                    float* C, int32_t N, float* stats, void* stream) {
+                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
+                                    const float* addend, float* C, int32_t N, float* stats, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
   P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
@@ -698,21 +944,12 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = 0; g.stats = stats;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.N = N; g.Nc = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.tps = cdiv(rs.n, BM); g.compact = planes_compact;
+  g.Bx = static_cast<const unsigned short*>(Bsplit);
+  g.Npad = cdiv(N, 128) * 128;
+  g.Ktot = nplanesA * Ka;
   g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
   g.ntm = B * g.tps;
-  hipStream_t s = (hipStream_t)stream;
-  const bool extra = addend != nullptr;
-  if (N % 128 == 0) {
-    g.ntn = N / 128;
-    const int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    if (extra) hipLaunchKernelGGL((k_gemm_planes<128, 32, true, true>), dim3(grid), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm_planes<128, 32, false, true>), dim3(grid), dim3(256), 0, s, g);
-  } else {
-    g.ntn = cdiv(N, 64);
-    const int grid = cdiv(g.ntm, 8) * 8 * g.ntn;
-    if (extra) hipLaunchKernelGGL((k_gemm_planes<64, 32, true, true>), dim3(grid), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm_planes<64, 32, false, true>), dim3(grid), dim3(256), 0, s, g);
-  }
+  launch_gemm_planes<true>(g, addend != nullptr, (hipStream_t)stream);
   return check_launch("gemm_planes_rows");
 }
 

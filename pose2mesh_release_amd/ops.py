@@ -211,6 +211,22 @@ def cheb_basis_fwd_real(g, X, B, F, in_shift):
     return T1, T2
 
 
+# Arithmetic of the dense contractions: "f32" = native f32 MFMA; "bf16x3" = the same fp32 contraction on the BF16 matrix
+# pipe (operands cut exactly into 3 bf16 slices, 6 slice products, fp32 accumulate; see include/p2m.h).
+GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "f32")
+
+
+def weight_split(Bm):
+    """Pre-split, k-contiguous copy of a [K, N] weight operand for the bf16x3 contraction (None in f32 mode)."""
+    if GEMM_ARITH != "bf16x3":
+        return None
+    K, N = Bm.shape
+    lib = _lib.hip()
+    Bx = torch.empty((int(lib.p2m_weight_split_elems(K, N)),), device=Bm.device, dtype=torch.int16)
+    check(lib.p2m_weight_split(_p(_req(Bm, "B")), K, N, _p(Bx), _stream()), "p2m_weight_split")
+    return Bx
+
+
 def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False):
     """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None."""
     n = g.n_real if row_set == 1 else g.n_fake
@@ -221,7 +237,7 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     with _timed("gemm_planes_mfma", 2.0 * B * n * len(A) * Ka * N):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
-                                              int(compact), _p(_req(Bm, "B")),
+                                              int(compact), _p(_req(Bm, "B")), _p(weight_split(Bm)),
                                               _p(bias if bias is None else _req(bias, "bias")),
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
                                               _p(st), _stream()), "p2m_gemm_planes_rows")
@@ -353,8 +369,9 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     c = [_p(t) for t in C] + [None] * (3 - len(C))
     mfma = (Ka % 32 == 0) and (Nc % 32 == 0)
+    Bx = weight_split(Bm) if mfma else None
     with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", 2.0 * M * len(A) * Ka * N):   # algorithmic FLOPs
-        check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")),
+        check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")), _p(Bx),
                                          _p(bias if bias is None else _req(bias, "bias")),
                                          _p(addend if addend is None else _req(addend, "addend")), c[0], c[1], c[2],
                                          nplanesC, Nc, int(pair_out), M, _p(st), _stream()), "p2m_gemm_planes")

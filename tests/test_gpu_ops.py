@@ -33,6 +33,13 @@ def ops(hip_libs):
     return o
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def arith(request, ops, monkeypatch):
+    """Both arithmetics of the dense contraction: native f32 MFMA and the 3-slice bf16 split on the BF16 pipe."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("V,Fdim,shift", [(17, 5, 0), (96, 64, 0), (184, 256, 1), (1472, 128, 1), (736, 32, 0),
                                           (46, 3, 0)])
 def test_cheb_basis_fwd_bwd(ops, V, Fdim, shift):
@@ -64,7 +71,7 @@ def test_cheb_basis_fwd_bwd(ops, V, Fdim, shift):
 @pytest.mark.parametrize("M,Ka,N,planes,shift", [(300, 32, 64, 3, 0), (1000, 128, 256, 3, 1), (257, 64, 128, 1, 0),
                                                  (513, 5, 32, 3, 0), (640, 64, 3, 3, 0), (256, 1088, 5888, 1, 0),
                                                  (129, 256, 96, 1, 0)])
-def test_gemm_planes_and_stats(ops, M, Ka, N, planes, shift):
+def test_gemm_planes_and_stats(ops, arith, M, Ka, N, planes, shift):
     gen = torch.Generator().manual_seed(M + N)
     A = [torch.randn((M + 1) >> shift if (p == 0 and shift) else M, Ka, generator=gen) for p in range(planes)]
     Bm = torch.randn(planes * Ka, N, generator=gen) / np.sqrt(planes * Ka)
@@ -83,7 +90,7 @@ def test_gemm_planes_and_stats(ops, M, Ka, N, planes, shift):
         assert (st[t, 1].cpu() - ((blk - blk.mean(0)) ** 2).sum(0)).abs().max() < 2e-3
 
 
-def test_gemm_planes_output_planes(ops):
+def test_gemm_planes_output_planes(ops, arith):
     M, K, Nc = 500, 128, 64
     gen = torch.Generator().manual_seed(1)
     A = torch.randn(M, K, generator=gen)
@@ -239,7 +246,7 @@ def test_gemm_tn_with_planes_and_layout1(ops):
     assert (db.cpu() - G[0].double().sum(0)).abs().max() < 1e-3
 
 
-def test_gemm_planes_addend_and_pair_out(ops):
+def test_gemm_planes_addend_and_pair_out(ops, arith):
     """Epilogue extras used by the forward-form backward: + addend, and the un-pool pair-sum output."""
     M, K, N = 1000, 64, 128
     gen = torch.Generator().manual_seed(3)
@@ -255,7 +262,7 @@ def test_gemm_planes_addend_and_pair_out(ops):
     assert (Cp.cpu() - ref.view(M // 2, 2, N).sum(1)).abs().max() < 4e-5
 
 
-def test_fake_vertex_split_matches_unsplit(ops):
+def test_fake_vertex_split_matches_unsplit(ops, arith):
     """Row-set launches (real: 3-plane K, fake: K=Fin with W0 + a W1 + b W2) reproduce the plain conv, its
     BatchNorm statistics, and the weight gradient (fake vertices are isolated)."""
     V, Fin, Fout, B = 736, 64, 128, 3
@@ -293,3 +300,44 @@ def test_fake_vertex_split_matches_unsplit(ops):
     dW, db = ops.weight_grad_unpack2(P1, Pb1, n1, P2, Pb2, n2, g.fake_a, g.fake_b, Fout, Fin)
     assert (dW - dWref).abs().max() < 1e-4 * max(1.0, dWref.abs().max().item())
     assert (db - dbref).abs().max() < 1e-3
+
+
+def _bf16_bits_to_float(t):
+    return (t.to(torch.int32) << 16).view(torch.float32)
+
+
+def test_weight_split_is_exact(ops, monkeypatch):
+    """p2m_weight_split: Bm == slice0 + slice1 + slice2 bit for bit, layout [3][Npad][K], zero padding rows."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
+    K, N = 96, 160
+    gen = torch.Generator().manual_seed(5)
+    Bm = (torch.randn(K, N, generator=gen) * torch.exp(4 * torch.randn(K, N, generator=gen))).cuda()
+    Bx = ops.weight_split(Bm)
+    Npad = 256
+    assert Bx.numel() == 3 * Npad * K
+    sl = _bf16_bits_to_float(Bx.view(3, Npad, K))
+    assert (sl[:, N:, :] == 0).all()
+    rec = (sl[0, :N].double() + sl[1, :N].double() + sl[2, :N].double()).t()
+    assert torch.equal(rec, Bm.double())
+    # slices are ordered by magnitude: |slice1| <= 2^-7 |slice0|, |slice2| <= 2^-15 |slice0|
+    assert (sl[1].abs() <= sl[0].abs() * 2.0 ** -7).all() and (sl[2].abs() <= sl[0].abs() * 2.0 ** -15).all()
+
+
+@pytest.mark.parametrize("M,Ka,N", [(2048, 256, 256), (1000, 128, 64)])
+def test_bf16x3_error_is_fp32_class(ops, monkeypatch, M, Ka, N):
+    """The split-bf16 contraction is an fp32 contraction: against float64, its error stays within 4x of the native
+    f32 MFMA's on inputs with a wide dynamic range (a plain bf16 product would be ~1e4 times worse)."""
+    gen = torch.Generator().manual_seed(M)
+    A = [(torch.randn(M, Ka, generator=gen) * torch.exp(2 * torch.randn(M, Ka, generator=gen))).cuda()
+         for _ in range(3)]
+    Bm = (torch.randn(3 * Ka, N, generator=gen) * torch.exp(2 * torch.randn(3 * Ka, N, generator=gen))).cuda()
+    ref = torch.cat(A, 1).double() @ Bm.double()
+    scale = torch.cat(A, 1).abs().double() @ Bm.abs().double()          # sum |a||b|: the natural error scale
+    errs = {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setattr(ops, "GEMM_ARITH", mode)
+        (C,), _ = ops.gemm_planes(A, Ka, 0, Bm, None, M, N, 1, False)
+        errs[mode] = ((C.double() - ref).abs() / scale).max().item()
+    print("max |err| / sum|a||b|:", errs)
+    assert errs["f32"] < 5e-6 and errs["bf16x3"] < 5e-6, errs              # ~ sqrt(K) * 2^-24
+    assert errs["bf16x3"] <= 4.0 * errs["f32"] + 2.4e-7, errs              # 2.4e-7 = 2 fp32 ulps of the scale

@@ -1,13 +1,49 @@
-import os, sys
+"""Throughput and error of p2m_gemm_planes in both arithmetics (native f32 MFMA / bf16x3 split) on the layer shapes
+of the SMPL network at batch 256.   python tools/probes/gemm_probe.py [B]"""
+import os
+import sys
+
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R]
-import torch
-from pose2mesh_release_amd import ops
-B, V, F = 256, 11776, 128
-M = B * V
-A = [torch.randn(M, F, device="cuda") for _ in range(3)]
-W = torch.randn(3 * F, 128, device="cuda")
-bias = torch.randn(128, device="cuda")
-for _ in range(3):
-    ops.gemm_planes(A, F, 0, W, bias, M, 128, 1, True)
-torch.cuda.synchronize()
+import torch  # noqa: E402
+
+from pose2mesh_release_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SHAPES = [(96, 256, 256), (184, 256, 256), (368, 256, 128), (736, 128, 128), (1472, 128, 64), (2944, 64, 64),
+          (5888, 64, 64), (11776, 64, 32)]           # (V, Ka, N)
+
+
+def bench(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for V, Ka, N in SHAPES:
+    M = B * V
+    g = torch.Generator(device="cuda").manual_seed(V)
+    A = [torch.randn(M, Ka, device="cuda", generator=g) for _ in range(3)]
+    W = torch.randn(3 * Ka, N, device="cuda", generator=g) / (3 * Ka) ** 0.5
+    bias = torch.randn(N, device="cuda", generator=g)
+    rows = min(M, 4096)
+    ref = torch.cat([a[:rows] for a in A], 1).double() @ W.double() + bias.double()
+    line = f"V={V:6d} M={M:8d} K=3x{Ka:3d} N={N:3d}"
+    for mode in ("f32", "bf16x3"):
+        ops.GEMM_ARITH = mode
+        Bx = ops.weight_split(W)
+
+        def run():
+            ops.gemm_planes(A, Ka, 0, W, bias, M, N, 1, True)
+
+        (C,), _ = ops.gemm_planes(A, Ka, 0, W, bias, M, N, 1, True)
+        err = (C[:rows].double() - ref).abs().max().item()
+        ms = bench(run)
+        line += f" | {mode}: {ms:7.3f} ms {2.0 * M * 3 * Ka * N / ms / 1e9:6.1f} TF err {err:.2e}"
+    print(line, flush=True)
