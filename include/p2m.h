@@ -117,8 +117,9 @@ int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t n
                     int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias, const float* addend,
                     float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out,
                     int64_t M, float* stats, void* stream);
-/* Bx[s][n][k] (uint16 bf16 bit patterns; s < 3; n < ceil(N/128)*128, zero padded; k < K) = s-th slice of Bm[k][n],
- * Bm = Bx[0] + Bx[1] + Bx[2] exactly.  p2m_weight_split_elems(K, N) = number of uint16 elements of Bx.              */
+/* Bx[k / 16][s][n][k % 16] (uint16 bf16 bit patterns; s < 3 slices; n < ceil(N/128)*128, zero padded; K % 16 == 0):
+ * s-th slice of Bm[k][n], Bm = slice 0 + slice 1 + slice 2 exactly.  p2m_weight_split_elems(K, N) = number of uint16
+ * elements of Bx.                                                                                                  */
 int64_t p2m_weight_split_elems(int32_t K, int32_t N);
 int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream);
 /* rows per BatchNorm partial tile and the number of tiles for M rows */

@@ -22,6 +22,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -43,7 +44,7 @@ struct GemmArgs {
   // (tps tiles per sample); planes 1,2 of A are COMPACT ([B*nset, Ka]) when `compact`
   const int* ids;
   int nset, V, tps, compact;
-  // split-bf16 mode (k_gemm_planes_bx): Bx[s][n][k], s < 3, n < Npad, k < Ktot = nplanesA * Ka  (p2m_weight_split)
+  // split-bf16 mode (k_gemm_planes_bx): Bx[k / 16][s][n][k % 16], s < 3, n < Npad, k < Ktot = nplanesA * Ka
   const unsigned short* Bx;
   int Npad, Ktot;
 };
@@ -324,15 +325,13 @@ __device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) 
 template <int BN, int KB, bool EXTRA, bool ROWS = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
   constexpr int NS = 3;          // slices per operand
-  static_assert(BN * (KB / 8) % 256 == 0 || BN * (KB / 8) < 256, "B staging");
+  static_assert(KB == 16 && (BN == 128 || BN == 64), "one 16-byte B segment per thread and slice");
   constexpr int WTN = BN / 2;
   constexpr int TN = WTN / 32;
   constexpr int TM = 2;
   constexpr int LDX = KB + 8;                     // bf16 elements per LDS row
   constexpr int APASS = BM * KB / 4 / 256;        // float4 A loads per thread per chunk
   constexpr int AROWS = 256 / (KB / 4);
-  constexpr int BSEG = BN * (KB / 8);             // 16-byte segments of one B slice per chunk
-  constexpr int BPASS = (BSEG + 255) / 256;
   constexpr int A_BUF = NS * BM * LDX;            // bf16 elements of one A buffer
   constexpr int B_BUF = NS * BN * LDX;
   constexpr int SM_WORDS = (2 * A_BUF + 2 * B_BUF) / 2 + (ROWS ? BM : 0);
@@ -368,88 +367,78 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
   const int cpp = g.Ka / KB;
   const int nchunks = g.nplanesA * cpp;
 
-  float4 ra[APASS];
-  u32x4 rb[BPASS * NS];   // native vector type (HIP's struct vector type kept this array in scratch)
+  // two register stages: chunk kc+1 waits in one while chunk kc+2 is still in flight into the other.  This kernel
+  // is HBM/L2-latency bound once the MFMA work is 6/16 of the f32 kernel's, so the loads need > 1 chunk of lead and
+  // the block barrier must not drain them (lds_barrier below instead of __syncthreads).
+  // (native vector types: HIP's struct vector types kept these arrays in scratch)
+  f32x4 ra0[APASS], ra1[APASS];
+  u32x4 rb0[NS], rb1[NS];
   const int a_row = t / (KB / 4), a_k4 = (t % (KB / 4)) * 4;
-  long rs_full[ROWS ? APASS : 1], rs_comp[ROWS ? APASS : 1];
-  if (ROWS) {
+  // source rows of this thread's APASS tile rows (full layout; compact layout for planes 1,2 of a row set).  Rows past
+  // the end are CLAMPED to the last valid row, not predicated: a conditional load makes hipcc drain vmcnt, and what
+  // such a row accumulates is never stored (the epilogue masks it).
+  long off0[APASS], off12[APASS];     // element offsets of the thread's rows in plane 0 / planes 1,2
 #pragma unroll
-    for (int ps = 0; ps < APASS; ps++) {
-      const int i = rs_i0 + ps * AROWS + a_row;
-      if (i < g.nset) {
-        rs_full[ps] = (long)rs_b * g.V + g.ids[i];
-        rs_comp[ps] = (long)rs_b * g.nset + i;
-      } else {
-        rs_full[ps] = -1;
-        rs_comp[ps] = -1;
-      }
+  for (int ps = 0; ps < APASS; ps++) {
+    long rf, rc;
+    if (ROWS) {
+      int i = rs_i0 + ps * AROWS + a_row;
+      if (i >= g.nset) i = g.nset - 1;
+      rf = (long)rs_b * g.V + g.ids[i];
+      rc = g.compact ? (long)rs_b * g.nset + i : rf;
+    } else {
+      rf = m0 + ps * AROWS + a_row;
+      if (rf >= g.M) rf = g.M - 1;
+      rc = rf;
     }
+    off0[ps] = (rf >> g.a0_shift) * g.Ka + a_k4;
+    off12[ps] = rc * g.Ka + a_k4;
   }
-  const long bx_slice = (long)g.Npad * g.Ktot;    // elements between two slices of Bx
+  // Bx is chunk-major: [k / 16][slice][n < Npad][16]: the 128 x 16 slice of one chunk is one contiguous 4 KB run
+  const int b_n = (t % (BN * 2)) >> 1, b_half = (t & 1) * 8;     // BN = 64: the upper 128 threads duplicate the lower
+  const unsigned short* bx_base = g.Bx + ((long)(n0 + b_n) * 16 + b_half);
+  const long bx_slice = (long)g.Npad * 16;        // elements between two slices of one chunk
 
-  auto load_chunk = [&](int kc) {
+  auto load_chunk = [&](int kc, f32x4 (&ra)[APASS], u32x4 (&rb)[NS]) {
     const int p = kc / cpp;
     const int k0 = (kc - p * cpp) * KB;
-    const float* Ap = g.A[p];
-    const int sh = (p == 0) ? g.a0_shift : 0;
+    const float* Ap = g.A[p] + k0;
 #pragma unroll
-    for (int ps = 0; ps < APASS; ps++) {
-      long r;
-      if (ROWS) r = (p == 0 || !g.compact) ? rs_full[ps] : rs_comp[ps];
-      else { r = m0 + ps * AROWS + a_row; if (r >= g.M) r = -1; }
-      if (r >= 0)
-        ra[ps] = *reinterpret_cast<const float4*>(Ap + (r >> sh) * g.Ka + k0 + a_k4);
-      else
-        ra[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int ps = 0; ps < BPASS; ps++) {
-      const int seg = (ps * 256 + t) % BSEG;     // BSEG < 256 (BN = 64): the upper threads duplicate the lower ones
-      const int n = seg / (KB / 8), ks = (seg % (KB / 8)) * 8;
-      const unsigned short* src = g.Bx + (long)(n0 + n) * g.Ktot + p * g.Ka + k0 + ks;   // n0 + n < Npad always
-      rb[ps * NS + 0] = *reinterpret_cast<const u32x4*>(src);
-      rb[ps * NS + 1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
-      rb[ps * NS + 2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
-    }
+    for (int ps = 0; ps < APASS; ps++)
+      ra[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
+    const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
+    rb[0] = *reinterpret_cast<const u32x4*>(src);
+    rb[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
+    rb[2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, f32x4 (&ra)[APASS], const u32x4 (&rb)[NS]) {
     unsigned short* as = As + buf * A_BUF;
+    // opaque use: keeps the optimiser from starting the slice arithmetic (and so the wait for these loads) earlier
+#pragma unroll
+    for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(ra[ps]));
 #pragma unroll
     for (int ps = 0; ps < APASS; ps++) {
       unsigned h[4], m[4], l[4];
-      split3(ra[ps].x, h[0], m[0], l[0]);
-      split3(ra[ps].y, h[1], m[1], l[1]);
-      split3(ra[ps].z, h[2], m[2], l[2]);
-      split3(ra[ps].w, h[3], m[3], l[3]);
+      split3(ra[ps][0], h[0], m[0], l[0]);
+      split3(ra[ps][1], h[1], m[1], l[1]);
+      split3(ra[ps][2], h[2], m[2], l[2]);
+      split3(ra[ps][3], h[3], m[3], l[3]);
       unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
       *reinterpret_cast<u32x2*>(d) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
       *reinterpret_cast<u32x2*>(d + BM * LDX) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
       *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
     }
-    unsigned short* bs = Bs + buf * B_BUF;
-#pragma unroll
-    for (int ps = 0; ps < BPASS; ps++) {
-      const int seg = (ps * 256 + t) % BSEG;
-      const int n = seg / (KB / 8), ks = (seg % (KB / 8)) * 8;
-      unsigned short* d = bs + n * LDX + ks;
-      *reinterpret_cast<u32x4*>(d) = rb[ps * NS + 0];
-      *reinterpret_cast<u32x4*>(d + BN * LDX) = rb[ps * NS + 1];
-      *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = rb[ps * NS + 2];
-    }
+    unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
+    *reinterpret_cast<u32x4*>(d) = rb[0];
+    *reinterpret_cast<u32x4*>(d + BN * LDX) = rb[1];
+    *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = rb[2];
   };
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int kc = 0; kc < nchunks; kc++) {
-    const int cur = kc & 1;
-    if (kc + 1 < nchunks) load_chunk(kc + 1);
+  auto compute = [&](int cur) {
     const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
     const unsigned short* bs = Bs + cur * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
 #pragma unroll
     for (int ks = 0; ks < KB / 16; ks++) {
-      // explicit slice registers (an indexed [slice][tile] array gets demoted to LDS by the compiler)
       bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; i++) {
@@ -477,23 +466,65 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
       P2M_PAIR(ah, bh)
 #undef P2M_PAIR
     }
-    if (kc + 1 < nchunks) store_chunk(cur ^ 1);
-    __syncthreads();
+  };
+  // LDS-only barrier: waits for this wave's LDS traffic, leaves its global loads in flight
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // Software pipeline, two chunks of lead.  Invariant at the top of an even phase: LDS buffer 0 holds chunk kc,
+  // stage 1 holds (or is receiving) chunk kc+1.  The steady-state loop issues its loads UNCONDITIONALLY: the
+  // compiler's vmcnt bookkeeping needs a static number of loads per phase - one conditional load and every wait in
+  // the loop degrades to vmcnt(0).  sched_barrier(0) keeps the scheduler from hoisting the slice arithmetic of the
+  // waiting stage above the MFMA phase (that would wait for its loads a whole phase early).
+  load_chunk(0, ra0, rb0);
+  load_chunk(nchunks > 1 ? 1 : 0, ra1, rb1);
+  store_chunk(0, ra0, rb0);
+  lds_barrier();
+  int kc = 0;
+  for (; kc + 3 < nchunks; kc += 2) {
+    load_chunk(kc + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_chunk(1, ra1, rb1);
+    lds_barrier();
+    load_chunk(kc + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_chunk(0, ra0, rb0);
+    lds_barrier();
   }
+  // tail: 1..3 chunks left, same invariant
+  const int left = nchunks - kc;
+  if (left == 3) load_chunk(kc + 2, ra0, rb0);
+  compute(0);
+  if (left >= 2) {
+    store_chunk(1, ra1, rb1);
+    lds_barrier();
+    compute(1);
+    if (left == 3) {
+      store_chunk(0, ra0, rb0);
+      lds_barrier();
+      compute(0);
+    }
+  }
+  __syncthreads();   // every wave is done with the staging buffers: the epilogue reuses them
   gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
 }
 
-// Bx[s][n][k] = s-th bf16 slice of Bm[k][n] (zero for N <= n < Npad): the k-contiguous, pre-split weight operand
+// Bx[k / 16][s][n][k % 16] = s-th bf16 slice of Bm[k][n] (zero for N <= n < Npad): the pre-split weight operand,
+// chunk-major so that the [BN x 16] slice a block stages per chunk is one contiguous run
 __global__ void k_weight_split(const float* __restrict__ Bm, unsigned short* __restrict__ Bx, int K, int N, int Npad) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Npad * K) return;
-  const int n = (int)(i / K), k = (int)(i - (long)n * K);
+  const int k = (int)(i / Npad), n = (int)(i - (long)k * Npad);      // n fastest: coalesced reads of Bm
   unsigned h = 0, m = 0, l = 0;
   if (n < N) split3(Bm[(long)k * N + n], h, m, l);
-  const long sl = (long)Npad * K;
-  Bx[i] = (unsigned short)(h >> 16);
-  Bx[sl + i] = (unsigned short)(m >> 16);
-  Bx[2 * sl + i] = (unsigned short)(l >> 16);
+  const long sl = (long)Npad * 16;
+  unsigned short* d = Bx + (long)(k >> 4) * 3 * sl + (long)n * 16 + (k & 15);
+  d[0] = (unsigned short)(h >> 16);
+  d[sl] = (unsigned short)(m >> 16);
+  d[2 * sl] = (unsigned short)(l >> 16);
 }
 
 // scalar fall-back (first conv Fin=5 -> K=15; last conv Fout=3): one thread per (row, n)
@@ -834,18 +865,17 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// tuning knobs: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32) and of the split-bf16 kernel
-// (P2M_GEMM_BX_KB=16|32; 32 needs 123 KB of LDS -> one block per CU)
+// tuning knob: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32)
 static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 32; return kb; }
-static int gemm_bx_kb() { static int kb = env_int("P2M_GEMM_BX_KB", 16) == 32 ? 32 : 16; return kb; }
 
 extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
-  if (K <= 0 || N <= 0) return 0;
+  if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
   return 3ll * (cdiv(N, 128) * 128ll) * K;
 }
 
 extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream) {
   P2M_CHECK_ARG(Bm && Bx && K > 0 && N > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(K % 16 == 0, "K must be a multiple of 16");
   const int Npad = cdiv(N, 128) * 128;
   hipLaunchKernelGGL(k_weight_split, dim3(cdiv((long)Npad * K, 256)), dim3(256), 0, (hipStream_t)stream, Bm,
                      static_cast<unsigned short*>(Bx), K, N, Npad);
@@ -860,13 +890,8 @@ static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
   const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn), block(256);
 #define P2M_LAUNCH(KERNEL, BNv, KBv, EX) hipLaunchKernelGGL((KERNEL<BNv, KBv, EX, ROWS>), grid, block, 0, s, g)
   if (g.Bx != nullptr) {
-    const bool kb32 = gemm_bx_kb() == 32 && wide && g.Ka % 32 == 0;
-    if (wide) {
-      if (kb32) { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 32, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 32, false); }
-      else { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 16, false); }
-    } else {
-      if (extra) P2M_LAUNCH(k_gemm_planes_bx, 64, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 64, 16, false);
-    }
+    if (wide) { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 16, false); }
+    else { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 64, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 64, 16, false); }
   } else {
     const bool kb16 = !ROWS && !extra && gemm_kb() == 16;
     if (wide) {

@@ -307,7 +307,7 @@ def _bf16_bits_to_float(t):
 
 
 def test_weight_split_is_exact(ops, monkeypatch):
-    """p2m_weight_split: Bm == slice0 + slice1 + slice2 bit for bit, layout [3][Npad][K], zero padding rows."""
+    """p2m_weight_split: Bm == slice0 + slice1 + slice2 bit for bit, layout [K/16][3][Npad][16], zero padding rows."""
     monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
     K, N = 96, 160
     gen = torch.Generator().manual_seed(5)
@@ -315,7 +315,7 @@ def test_weight_split_is_exact(ops, monkeypatch):
     Bx = ops.weight_split(Bm)
     Npad = 256
     assert Bx.numel() == 3 * Npad * K
-    sl = _bf16_bits_to_float(Bx.view(3, Npad, K))
+    sl = _bf16_bits_to_float(Bx.view(K // 16, 3, Npad, 16)).permute(1, 2, 0, 3).reshape(3, Npad, K)
     assert (sl[:, N:, :] == 0).all()
     rec = (sl[0, :N].double() + sl[1, :N].double() + sl[2, :N].double()).t()
     assert torch.equal(rec, Bm.double())

@@ -12,6 +12,9 @@ from pose2mesh_release_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(96, 256, 256), (184, 256, 256), (368, 256, 128), (736, 128, 128), (1472, 128, 64), (2944, 64, 64),
           (5888, 64, 64), (11776, 64, 32)]           # (V, Ka, N)
+if os.environ.get("PROBE_SHAPE"):                     # e.g. PROBE_SHAPE=736,128,128 PROBE_MODES=bf16x3 for a PMC pass
+    SHAPES = [tuple(int(x) for x in os.environ["PROBE_SHAPE"].split(","))]
+MODES = os.environ.get("PROBE_MODES", "f32,bf16x3").split(",")
 
 
 def bench(fn, n=5):
@@ -35,7 +38,7 @@ for V, Ka, N in SHAPES:
     rows = min(M, 4096)
     ref = torch.cat([a[:rows] for a in A], 1).double() @ W.double() + bias.double()
     line = f"V={V:6d} M={M:8d} K=3x{Ka:3d} N={N:3d}"
-    for mode in ("f32", "bf16x3"):
+    for mode in MODES:
         ops.GEMM_ARITH = mode
         Bx = ops.weight_split(W)
 
