@@ -11,8 +11,9 @@ joint regression, the five reference losses, backward, [gradient all-reduce], Ad
 every rank owns `--batch` samples.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (FP32-MFMA contraction k_gemm_planes): algorithmic FLOPs of its
-                launches / their HIP-event time, against the 157.3 TFLOP/s dense FP32 MFMA peak
+  roofline      the dominant kernel (the dense contraction k_gemm_planes[_bx]): algorithmic fp32 FLOPs of its
+                launches / their HIP-event time, against the MFMA peak of the pipe it runs on expressed in
+                algorithmic FLOPs (bf16x3: 2500 / 6 = 416.7 TFLOP/s; P2M_GEMM_ARITH=f32: 157.3 TFLOP/s)
   roofline_sparse  the Chebyshev-basis gather kernels (HBM-bound): algorithmic bytes / event time vs 8 TB/s
   cpu_baseline  the oracle port of the reference CPU path (oracle/meshnet_oracle.py), same train step,
                 small batch, timed on this host's cores (rank 0, N=1 only)
@@ -34,6 +35,8 @@ from pose2mesh_release_amd import loss as p2m_loss  # noqa: E402
 from pose2mesh_release_amd import ops, optim, pose2mesh_net, synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense FP32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, dense BF16 matrix peak; the bf16x3 contraction spends 6 bf16 MFMA flops
+                                  # per algorithmic fp32 flop -> 416.7 TFLOP/s fp32-equivalent
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec peak (achievable copy ceiling ~6300 GB/s)
 
 
@@ -213,6 +216,9 @@ def main():
                                     f"{'MANO' if args.joint_set == 'mano' else 'SMPL'}-like hull mesh {step.nv} verts "
                                     f"(padded {step.V0}), FlatPose2Mesh fwd + 5 reference losses + bwd + Adam"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "gemm_arith": ("fp32 contraction as 3 exact bf16 slices x 6 products on the BF16 MFMA pipe, "
+                                      "fp32 accumulate (error vs float64 <= native f32 MFMA)"
+                                      if ops.GEMM_ARITH == "bf16x3" else "native f32 MFMA"),
                        "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if world > 1 else 0},
         }
         if timer is not None:
@@ -224,17 +230,27 @@ def main():
                                             "work": sum(k["work"] for k in ks)}
             g = merged("gemm_planes_mfma", "gemm_planes_mfma_bwd")
             if g:
+                if ops.GEMM_ARITH == "bf16x3":
+                    kname = "k_gemm_planes_bx (fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product)"
+                    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+                else:
+                    kname, peak = "k_gemm_planes (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
                 ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-                line["roofline"] = {"bound": "mfma", "kernel": "k_gemm_planes (v_mfma_f32_32x32x2_f32)",
-                                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                                    "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4)}
+                line["roofline"] = {"bound": "mfma", "kernel": kname,
+                                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                    "frac": round(ach / peak, 4), "traffic": None,
+                                    "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                                    "note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = pipe peak "
+                                            "in algorithmic fp32 FLOPs (BF16 dense 2500 / 6 slice products, or the "
+                                            "f32 MFMA 157.3)",
+                                    "frac_of_f32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
                 f = summ.get("gemm_planes_mfma")       # forward launches: no other kernel shares the GPU with them
                 if f:
                     achf = f["work"] / (f["ms"] * 1e-3) / 1e12
                     line["roofline"]["exclusive"] = {
                         "note": "forward launches only; backward launches overlap the side-stream k_gemm_tn",
-                        "achieved": round(achf, 2), "frac": round(achf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "achieved": round(achf, 2), "frac": round(achf / peak, 4),
+                        "frac_of_f32_mfma_peak": round(achf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "launches": f["launches"], "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
             sp = merged("cheb_basis_fwd", "cheb_basis_fwd_bwd", "cheb_basis_bwd", "cheb_basis_bwd_bwd")
             if sp and sp["ms"] > 0:

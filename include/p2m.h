@@ -34,6 +34,12 @@ typedef enum {
   P2M_ERR_NOMEM = -3
 } p2m_status;
 
+/* Arithmetic of the dense contractions.  Both compute the SAME fp32 contraction with fp32 accumulation:
+ * F32     native f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain;
+ * BF16X3  every fp32 operand cut EXACTLY into three bf16 slices (8+8+8 significand bits), the six slice products of
+ *         weight >= 2^-16 on v_mfma_f32_32x32x16_bf16; dropped terms <= 2^-23 |a b| (one fp32 rounding).          */
+enum { P2M_ARITH_F32 = 0, P2M_ARITH_BF16X3 = 1 };
+
 typedef struct p2m_graph* p2m_graph_t;
 
 /* Thread-local description of the last error returned on this thread. */
@@ -131,7 +137,7 @@ int32_t p2m_stats_tile_rows(void);
  * (autograd of cheby_graph_conv.py:37 / meshnet.py:105.)                                       */
 int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                 int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
-                int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, void* stream);
+                int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith, void* stream);
 
 /* ---- BatchNorm1d over B*V rows + ReLU + residual (cheby_graph_conv.py:39, meshnet.py:100,108-115)
  * finalize: reduces the GEMM's partials to batch mean / biased var, writes
@@ -195,7 +201,7 @@ int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
                      const float* G0, const float* G1, const float* G2, int32_t nplanesG, int32_t Gc,
-                     int32_t planes_compact, int32_t splits, float* P, float* Pdb, void* stream);
+                     int32_t planes_compact, int32_t splits, float* P, float* Pdb, int32_t arith, void* stream);
 /* We[k][n] = Wt[k][n] + a Wt[Ka+k][n] + b Wt[2Ka+k][n]  (Wt = [3Ka, N]) */
 int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream);
 /* dW (nn.Linear layout) from the real-vertex partials P[c][fin][k*Fout+fo] plus the fake-vertex partials

@@ -37,7 +37,7 @@ HIP_SYMBOLS = {
                                         _vp, _i32, _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
-                                    _vp]),
+                                    _i32, _vp]),
     "p2m_weight_eff": (_c.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "p2m_weight_grad_unpack2": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _i32, _i32, _i32,
                                            _vp]),
@@ -53,7 +53,7 @@ HIP_SYMBOLS = {
     "p2m_weight_split": (_c.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),
     "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp,
-                               _vp]),
+                               _i32, _vp]),
     "p2m_bn_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                    _i32, _i32, _vp]),
     "p2m_bn_eval_coeffs": (_c.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -113,6 +113,9 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   g->V = V;
   g->n_real = (int)real_ids.size();
   g->n_fake = (int)fake_ids.size();
+  // 64 zero entries of slack: the pipelined kernels prefetch ids a few 16-row stages ahead without bounds checks
+  real_ids.resize(real_ids.size() + 64, 0);
+  fake_ids.resize(fake_ids.size() + 64, 0);
   g->fake_a = fa;
   g->fake_b = fb;
   g->nnz = (int)mc.size();

@@ -211,9 +211,18 @@ def cheb_basis_fwd_real(g, X, B, F, in_shift):
     return T1, T2
 
 
-# Arithmetic of the dense contractions: "f32" = native f32 MFMA; "bf16x3" = the same fp32 contraction on the BF16 matrix
-# pipe (operands cut exactly into 3 bf16 slices, 6 slice products, fp32 accumulate; see include/p2m.h).
-GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "f32")
+# Arithmetic of the dense contractions: "bf16x3" (default) = the fp32 contraction on the BF16 matrix pipe (operands cut
+# exactly into 3 bf16 slices, 6 slice products, fp32 accumulate; error vs float64 <= the native kernel's, see
+# include/p2m.h and tests/test_gpu_ops.py::test_bf16x3_error_is_fp32_class); "f32" = native f32 MFMA.
+# Measured: 3860-3970 vs 3400-3440 meshes/s.
+GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "bf16x3")
+if GEMM_ARITH not in ("f32", "bf16x3"):
+    raise ValueError(f"P2M_GEMM_ARITH must be f32 or bf16x3, not {GEMM_ARITH!r}")
+
+
+def arith_code():
+    """P2M_ARITH_* value of include/p2m.h for the current GEMM_ARITH."""
+    return 1 if GEMM_ARITH == "bf16x3" else 0
 
 
 def weight_split(Bm):
@@ -280,7 +289,8 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
     gp = [_p(_req(t, "G plane")) for t in G] + [None] * (3 - len(G))
     with _timed("gemm_tn_mfma", 2.0 * B * n * Ka * N):
         check(_lib.hip().p2m_gemm_tn_rows(g.handle, row_set, B, _p(_req(A, "A")), Ka, a0_shift, gp[0], gp[1], gp[2],
-                                          len(G), Gc, int(compact), splits, _p(P), _p(Pdb), _stream()),
+                                          len(G), Gc, int(compact), splits, _p(P), _p(Pdb), arith_code(),
+                                          _stream()),
               "p2m_gemm_tn_rows")
     return P, Pdb, nch
 
@@ -403,7 +413,7 @@ def gemm_tn(A, Ka, a0_shift, G, M, N):
     gp = [_p(_req(t, "G plane")) for t in Gl] + [None] * (3 - len(Gl))
     with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", 2.0 * M * Ktot * N):
         check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, gp[0], gp[1], gp[2], len(Gl), Gc, M,
-                                     chunk_rows, _p(P), _p(Pdb), _stream()), "p2m_gemm_tn")
+                                     chunk_rows, _p(P), _p(Pdb), arith_code(), _stream()), "p2m_gemm_tn")
     return P, Pdb, nchunks
 
 

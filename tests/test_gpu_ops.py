@@ -103,7 +103,7 @@ def test_gemm_planes_output_planes(ops, arith):
 
 @pytest.mark.parametrize("M,Ka,N,planes,shift", [(3000, 128, 128, 3, 1), (700, 32, 64, 3, 0), (513, 5, 32, 3, 0),
                                                  (2000, 64, 3, 3, 0), (256, 1088, 320, 1, 0), (999, 256, 256, 3, 0)])
-def test_gemm_tn_and_unpack(ops, M, Ka, N, planes, shift):
+def test_gemm_tn_and_unpack(ops, arith, M, Ka, N, planes, shift):
     gen = torch.Generator().manual_seed(M + Ka)
     A = [torch.randn((M + 1) >> shift if (p == 0 and shift) else M, Ka, generator=gen) for p in range(planes)]
     G = torch.randn(M, N, generator=gen)
@@ -233,7 +233,7 @@ def test_cheb_gemm_fused(ops, V, Ka, N, shift, pair, B):
         assert (planes[1].cpu().view(B, V, Ka) - Z[..., 2 * Ka:]).abs().max() < 1e-5
 
 
-def test_gemm_tn_with_planes_and_layout1(ops):
+def test_gemm_tn_with_planes_and_layout1(ops, arith):
     """dW = X^T [g | E1 | E2] unpacked to nn.Linear layout (the fused backward's weight gradient)."""
     M, Fin, Fout = 1500, 64, 128
     gen = torch.Generator().manual_seed(5)
