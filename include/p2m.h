@@ -101,7 +101,7 @@ int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, fl
                            int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, int32_t layout,
                            int32_t pdb_stride, void* stream);
 
-/* ---- dense contraction (FP32 MFMA, v_mfma_f32_32x32x2_f32) ---------------------------------
+/* ---- dense contraction (fp32; on the BF16 or the f32 MFMA pipe, see P2M_ARITH_*) -------------
  * C[r, n] = sum_p sum_k A_p[r (>> a0_shift if p==0), k] * Bm[p*Ka + k, n]  + bias[n]
  * A_p: nplanesA row-major [M, Ka] matrices (the Chebyshev basis planes X|T1|T2, or one plane);
  * Bm: [nplanesA*Ka, N] row-major; C is split in nplanesC column planes of width Nc (N = nplanesC*Nc),
@@ -233,7 +233,9 @@ int32_t p2m_fused_stats_tile_rows(int32_t N);   /* rows per BatchNorm partial of
 
 /* ---- composite: one Chebyshev graph convolution (cheby_graph_conv.py:5-40, K=3) ------------
  * Y = [X|L X|L2 X] Wt + bias, BatchNorm partials in `stats` (may be NULL).  T1/T2 are caller
- * workspaces of B*V*Fin floats each and hold the basis planes afterwards (saved for backward). */
+ * workspaces of B*V*Fin floats each and hold the basis planes afterwards (saved for backward).
+ * Convenience entry: native f32 MFMA arithmetic, unsplit rows; the network path composes the pieces itself
+ * (p2m_cheb_basis_fwd_real + p2m_weight_split + p2m_gemm_planes_rows).                                  */
 int p2m_chebconv_fwd(p2m_graph_t g, const float* X, const float* Wt, const float* bias,
                      float* T1, float* T2, float* Y, float* stats,
                      int32_t B, int32_t Fin, int32_t Fout, int32_t in_shift, void* stream);
