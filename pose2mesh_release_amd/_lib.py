@@ -101,7 +101,7 @@ def hip():
         # torch ships its own libamdhip64: import it FIRST so that this library binds to the same HIP
         # runtime instance (two runtimes in one process do not see each other's device memory).
         import torch  # noqa: F401
-        _hip = _load(os.path.join(LIBDIR, "libp2m_hip.so"), HIP_SYMBOLS)
+        _hip = _load(os.environ.get("P2M_HIP_LIB") or os.path.join(LIBDIR, "libp2m_hip.so"), HIP_SYMBOLS)
     return _hip
 
 

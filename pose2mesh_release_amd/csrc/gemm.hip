@@ -512,6 +512,254 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
   gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised form of k_gemm_planes_bx: 512 threads = 4 consumer waves (fragment reads + MFMAs, the 2 x 2 wave
+// tiling of the other kernels) + 4 producer waves (global loads, slice arithmetic, LDS stores).  The hardware places
+// waves i and i+4 of a block on the same SIMD, so each SIMD runs one MFMA stream and one VALU/memory stream side by
+// side instead of one wave doing both in turn (k_gemm_planes_bx: 24 % of a wave's phase is MFMA).
+//   * producers: FOUR register stages of lead (they hold no accumulators), loads unconditional in the steady state,
+//     LDS ring of three chunks; during iteration kc they store chunk kc+2 and refill that stage with chunk kc+6;
+//   * consumers: fragments double-buffered in registers - the 12 ds_read_b128 of chunk kc+1 are issued under the 24
+//     MFMAs of chunk kc;
+//   * one LDS-only block barrier per chunk.  1 block (8 waves) per CU, 110 KB of LDS.
+// ---------------------------------------------------------------------------------------------
+// probe builds only (tools/probes/ablate_gemm.sh build|run): -DP2M_ABLATE=mask removes 1 A loads, 2 B loads, 4 slice arithmetic,
+// 8 LDS stores, 16 fragment reads, 32 MFMAs from k_gemm_planes_ws to see what the chunk time is made of
+#ifndef P2M_ABLATE
+#define P2M_ABLATE 0
+#endif
+template <int BN, bool EXTRA, bool ROWS, int NBUF, int NST>
+__global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmArgs g) {
+  constexpr int NS = 3, KB = 16;
+  constexpr int AHEAD = NBUF - 1;     // the producers store chunk kc + AHEAD during iteration kc
+  static_assert((NBUF == 2 || NBUF == 3) && NST >= AHEAD, "ring / stage configuration");
+  constexpr int WTN = BN / 2;
+  constexpr int TN = WTN / 32;
+  constexpr int TM = 2;
+  constexpr int LDX = KB + 8;
+  constexpr int APASS = BM * KB / 4 / 256;
+  constexpr int AROWS = 256 / (KB / 4);
+  constexpr int A_BUF = NS * BM * LDX;
+  constexpr int B_BUF = NS * BN * LDX;
+  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0);
+  __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bs = As + NBUF * A_BUF;
+  int* rowtab = reinterpret_cast<int*>(smem + NBUF * (A_BUF + B_BUF) / 2);
+
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
+  const long m0 = (long)mt * BM;
+  const int n0 = nt * BN;
+  const int t = threadIdx.x;
+  const bool producer = t >= 256;          // wave-uniform
+  const int pt = t & 255;
+  const int rs_b = ROWS ? mt / g.tps : 0;
+  const int rs_i0 = ROWS ? (mt - rs_b * g.tps) * BM : 0;
+  if (ROWS && t < BM) {
+    const int i = rs_i0 + t;
+    rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
+  }
+  const int lane = t & 63, wave = (t >> 6) & 3;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int cpp = g.Ka / KB;
+  const int n = g.nplanesA * cpp;           // chunks
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  if (producer) {
+    const int a_row = pt / (KB / 4), a_k4 = (pt % (KB / 4)) * 4;
+    long off0[APASS], off12[APASS];
+#pragma unroll
+    for (int ps = 0; ps < APASS; ps++) {
+      long rf, rc;
+      if (ROWS) {
+        int i = rs_i0 + ps * AROWS + a_row;
+        if (i >= g.nset) i = g.nset - 1;
+        rf = (long)rs_b * g.V + g.ids[i];
+        rc = g.compact ? (long)rs_b * g.nset + i : rf;
+      } else {
+        rf = m0 + ps * AROWS + a_row;
+        if (rf >= g.M) rf = g.M - 1;
+        rc = rf;
+      }
+      off0[ps] = (rf >> g.a0_shift) * g.Ka + a_k4;
+      off12[ps] = rc * g.Ka + a_k4;
+    }
+    const int b_n = (pt % (BN * 2)) >> 1, b_half = (pt & 1) * 8;
+    const unsigned short* bx_base = g.Bx + ((long)(n0 + b_n) * 16 + b_half);
+    const long bx_slice = (long)g.Npad * 16;
+
+    f32x4 ra[NST][APASS];
+    u32x4 rb[NST][NS];
+    if (P2M_ABLATE & 3) {
+#pragma unroll
+      for (int i = 0; i < NST; i++) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ps++) ra[i][ps] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) rb[i][sl] = u32x4{1u, 2u, 3u, 4u};
+      }
+    }
+    auto load_chunk = [&](int kc, f32x4 (&a)[APASS], u32x4 (&b)[NS]) {
+      const int p = kc / cpp;
+      const int k0 = (kc - p * cpp) * KB;
+      const float* Ap = g.A[p] + k0;
+      if (!(P2M_ABLATE & 1)) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ps++)
+          a[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
+      }
+      const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
+      if (!(P2M_ABLATE & 2)) {
+        b[0] = *reinterpret_cast<const u32x4*>(src);
+        b[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
+        b[2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
+      }
+    };
+    auto store_chunk = [&](int kc, f32x4 (&a)[APASS], const u32x4 (&b)[NS]) {
+      const int buf = kc % NBUF;
+      unsigned short* as = As + buf * A_BUF;
+#pragma unroll
+      for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(a[ps]));
+#pragma unroll
+      for (int ps = 0; ps < APASS; ps++) {
+        unsigned h[4], m[4], l[4];
+        if (P2M_ABLATE & 4) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { h[e] = __float_as_uint(a[ps][e]); m[e] = h[e]; l[e] = h[e]; }
+        } else {
+          split3(a[ps][0], h[0], m[0], l[0]);
+          split3(a[ps][1], h[1], m[1], l[1]);
+          split3(a[ps][2], h[2], m[2], l[2]);
+          split3(a[ps][3], h[3], m[3], l[3]);
+        }
+        if (P2M_ABLATE & 8) continue;
+        unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
+        *reinterpret_cast<u32x2*>(d) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
+        *reinterpret_cast<u32x2*>(d + BM * LDX) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
+        *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+      }
+      if (P2M_ABLATE & 8) return;
+      unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
+      *reinterpret_cast<u32x4*>(d) = b[0];
+      *reinterpret_cast<u32x4*>(d + BN * LDX) = b[1];
+      *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = b[2];
+    };
+    const int last = n - 1;
+    // chunk c lives in register stage c % NST and LDS buffer c % NBUF.  Prologue: chunks 0..AHEAD-1 stored, the next NST
+    // chunks in flight.
+#pragma unroll
+    for (int i = 0; i < NST; i++) load_chunk(i < last ? i : last, ra[i], rb[i]);
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) {
+      if (i < n) store_chunk(i, ra[i], rb[i]);
+      load_chunk(NST + i < last ? NST + i : last, ra[i], rb[i]);
+    }
+    lds_barrier();
+    // iteration kc (consumers: MFMAs of chunk kc): store chunk kc+AHEAD, refill its stage with chunk kc+AHEAD+NST
+    int kc = 0;
+    for (; kc + (NST - 1) + AHEAD + NST < n; kc += NST) {     // steady state: every load below is in range
+#pragma unroll
+      for (int i = 0; i < NST; i++) {
+        store_chunk(kc + i + AHEAD, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+        load_chunk(kc + i + AHEAD + NST, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+        lds_barrier();
+      }
+    }
+    for (; kc < n; kc += NST) {                                // tail: same rotation, range-checked
+#pragma unroll
+      for (int i = 0; i < NST; i++) {
+        if (kc + i < n) {
+          if (kc + i + AHEAD < n) store_chunk(kc + i + AHEAD, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+          if (kc + i + AHEAD + NST < n) load_chunk(kc + i + AHEAD + NST, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+          lds_barrier();
+        }
+      }
+    }
+  } else {
+    bf16x8 fa[NBUF - 1][NS][TM], fb[NBUF - 1][NS][TN];       // [register set][slice h,m,l][tile]
+    if (P2M_ABLATE & 16) {
+#pragma unroll
+      for (int q = 0; q < NBUF - 1; q++)
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) fa[q][sl][i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 2u, 3u, 4u});
+#pragma unroll
+          for (int j = 0; j < TN; j++) fb[q][sl][j] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 5u, 3u, 4u});
+        }
+    }
+    auto read_frags = [&](int kc, bf16x8 (&a)[NS][TM], bf16x8 (&b)[NS][TN]) {
+      if (P2M_ABLATE & 16) return;
+      const int buf = kc % NBUF;
+      const unsigned short* as = As + buf * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
+      const unsigned short* bs = Bs + buf * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
+#pragma unroll
+      for (int sl = 0; sl < NS; sl++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          a[sl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(as + (sl * BM + i * 32) * LDX));
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          b[sl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bs + (sl * BN + j * 32) * LDX));
+      }
+    };
+    auto mfmas = [&](const bf16x8 (&a)[NS][TM], const bf16x8 (&b)[NS][TN]) {
+      if (P2M_ABLATE & 32) return;
+#define P2M_PAIR(SA, SB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SA][i], b[SB][j], acc[i][j], 0, 0, 0);
+      P2M_PAIR(2, 0)
+      P2M_PAIR(0, 2)
+      P2M_PAIR(1, 1)
+      P2M_PAIR(1, 0)
+      P2M_PAIR(0, 1)
+      P2M_PAIR(0, 0)
+#undef P2M_PAIR
+    };
+    lds_barrier();                              // the first AHEAD chunks are in LDS
+    if (NBUF == 3) {                            // fragments of chunk kc+1 are read under the MFMAs of chunk kc
+      read_frags(0, fa[0], fb[0]);
+      int kc = 0;
+      for (; kc + 1 < n; kc += 2) {
+        read_frags(kc + 1, fa[1], fb[1]);
+        mfmas(fa[0], fb[0]);
+        lds_barrier();
+        if (kc + 2 < n) read_frags(kc + 2, fa[0], fb[0]);
+        mfmas(fa[1], fb[1]);
+        lds_barrier();
+      }
+      if (kc < n) {
+        mfmas(fa[0], fb[0]);
+        lds_barrier();
+      }
+    } else {
+      for (int kc = 0; kc < n; kc++) {
+        read_frags(kc, fa[0], fb[0]);
+        mfmas(fa[0], fb[0]);
+        lds_barrier();
+      }
+    }
+  }
+  __syncthreads();   // staging buffers are free: the epilogue reuses them
+  if (!producer) {
+    gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
+  } else if (g.stats != nullptr) {              // the three block barriers of the statistics reduction
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+  }
+}
+
 // Bx[k / 16][s][n][k % 16] = s-th bf16 slice of Bm[k][n] (zero for N <= n < Npad): the pre-split weight operand,
 // chunk-major so that the [BN x 16] slice a block stages per chunk is one contiguous run
 __global__ void k_weight_split(const float* __restrict__ Bm, unsigned short* __restrict__ Bx, int K, int N, int Npad) {
@@ -1094,6 +1342,9 @@ static int env_int(const char* name, int dflt) {
 }
 // tuning knob: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32)
 static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 32; return kb; }
+// bf16x3 plane contraction: the 4-wave kernel (0), or the wave-specialised kernel with a 3-chunk ring and 1 block/CU (1)
+// or a 2-chunk ring and 2 blocks/CU (2)
+static int gemm_ws() { static int v = env_int("P2M_GEMM_WS", 0); return v; }
 
 extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
@@ -1116,7 +1367,18 @@ static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
   g.ntn = wide ? g.N / 128 : cdiv(g.N, 64);
   const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn), block(256);
 #define P2M_LAUNCH(KERNEL, BNv, KBv, EX) hipLaunchKernelGGL((KERNEL<BNv, KBv, EX, ROWS>), grid, block, 0, s, g)
-  if (g.Bx != nullptr) {
+  if (g.Bx != nullptr && gemm_ws()) {
+#define P2M_LAUNCH_WS(BNv, EX)                                                                              \
+  do {                                                                                                      \
+    if (gemm_ws() == 2) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 2>), grid, dim3(512), 0, s, g); \
+    else if (gemm_ws() == 3) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 3>), grid, dim3(512), 0, s, g); \
+    else if (gemm_ws() == 4) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 4>), grid, dim3(512), 0, s, g); \
+    else hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 3, 4>), grid, dim3(512), 0, s, g);              \
+  } while (0)
+    if (wide) { if (extra) P2M_LAUNCH_WS(128, true); else P2M_LAUNCH_WS(128, false); }
+    else { if (extra) P2M_LAUNCH_WS(64, true); else P2M_LAUNCH_WS(64, false); }
+#undef P2M_LAUNCH_WS
+  } else if (g.Bx != nullptr) {
     if (wide) { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 16, false); }
     else { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 64, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 64, 16, false); }
   } else {

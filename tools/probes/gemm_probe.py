@@ -15,6 +15,7 @@ SHAPES = [(96, 256, 256), (184, 256, 256), (368, 256, 128), (736, 128, 128), (14
 if os.environ.get("PROBE_SHAPE"):                     # e.g. PROBE_SHAPE=736,128,128 PROBE_MODES=bf16x3 for a PMC pass
     SHAPES = [tuple(int(x) for x in os.environ["PROBE_SHAPE"].split(","))]
 MODES = os.environ.get("PROBE_MODES", "f32,bf16x3").split(",")
+PLANES = int(os.environ.get("PROBE_PLANES", "3"))      # 1..3 A planes: time vs K gives the per-tile overhead
 
 
 def bench(fn, n=5):
@@ -32,12 +33,12 @@ def bench(fn, n=5):
 for V, Ka, N in SHAPES:
     M = B * V
     g = torch.Generator(device="cuda").manual_seed(V)
-    A = [torch.randn(M, Ka, device="cuda", generator=g) for _ in range(3)]
-    W = torch.randn(3 * Ka, N, device="cuda", generator=g) / (3 * Ka) ** 0.5
+    A = [torch.randn(M, Ka, device="cuda", generator=g) for _ in range(PLANES)]
+    W = torch.randn(PLANES * Ka, N, device="cuda", generator=g) / (PLANES * Ka) ** 0.5
     bias = torch.randn(N, device="cuda", generator=g)
     rows = min(M, 4096)
     ref = torch.cat([a[:rows] for a in A], 1).double() @ W.double() + bias.double()
-    line = f"V={V:6d} M={M:8d} K=3x{Ka:3d} N={N:3d}"
+    line = f"V={V:6d} M={M:8d} K={PLANES}x{Ka:3d} N={N:3d}"
     for mode in MODES:
         ops.GEMM_ARITH = mode
         Bx = ops.weight_split(W)
@@ -48,5 +49,5 @@ for V, Ka, N in SHAPES:
         (C,), _ = ops.gemm_planes(A, Ka, 0, W, bias, M, N, 1, True)
         err = (C[:rows].double() - ref).abs().max().item()
         ms = bench(run)
-        line += f" | {mode}: {ms:7.3f} ms {2.0 * M * 3 * Ka * N / ms / 1e9:6.1f} TF err {err:.2e}"
+        line += f" | {mode}: {ms:7.3f} ms {2.0 * M * PLANES * Ka * N / ms / 1e9:6.1f} TF err {err:.2e}"
     print(line, flush=True)
