@@ -35,6 +35,8 @@ def _req(t, name):
 class KernelTimer:
     """Optional live per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
     Kernels are launched on torch's current stream, so torch.cuda.Event brackets exactly the launch.
+    `work` is a number (FLOPs or bytes the launch has to move) or a pair (that, SURVEY.md 8(d)'s algorithmic figure
+    for the same stage when the two differ - the basis stage after the fake-vertex split).
     Usage: ops.TIMER = KernelTimer(); ...; ops.TIMER.summary()."""
 
     def __init__(self):
@@ -48,7 +50,9 @@ class KernelTimer:
         out = {}
         for name, recs in self.records.items():
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            out[name] = {"launches": len(recs), "ms": ms, "work": float(sum(w for _, _, w in recs))}
+            out[name] = {"launches": len(recs), "ms": ms,
+                         "work": float(sum(w[0] if isinstance(w, tuple) else w for _, _, w in recs)),
+                         "work_alg": float(sum(w[1] if isinstance(w, tuple) else w for _, _, w in recs))}
         return out
 
 
@@ -163,7 +167,8 @@ def cheb_basis_fwd(g, X, B, F, in_shift):
     M = B * g.V
     T1 = torch.empty((M, F), device=X.device, dtype=torch.float32)
     T2 = torch.empty((M, F), device=X.device, dtype=torch.float32)
-    with _timed("cheb_basis_fwd", 4.0 * M * F * (2.0 + 1.0 / (1 << in_shift))):     # algorithmic HBM bytes
+    # bytes this launch moves (the un-pooled input is read at the coarse resolution), SURVEY 8(d): 4*K*V*Fin per sample
+    with _timed("cheb_basis_fwd", (4.0 * M * F * (2.0 + 1.0 / (1 << in_shift)), 12.0 * M * F)):
         check(_lib.hip().p2m_cheb_basis_fwd(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
               "p2m_cheb_basis_fwd")
     return T1, T2
@@ -205,7 +210,8 @@ def cheb_basis_fwd_real(g, X, B, F, in_shift):
     """Basis planes of the REAL vertices only, compact [B*n_real, F]."""
     T1 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
     T2 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
-    with _timed("cheb_basis_fwd", 4.0 * B * g.n_real * F * (2.0 + 1.0 / (1 << in_shift))):
+    # bytes moved: real rows only (the fake rows' planes are folded into the effective weight); SURVEY 8(d) counts all V
+    with _timed("cheb_basis_fwd", (4.0 * B * g.n_real * F * (2.0 + 1.0 / (1 << in_shift)), 12.0 * B * g.V * F)):
         check(_lib.hip().p2m_cheb_basis_fwd_real(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
               "p2m_cheb_basis_fwd_real")
     return T1, T2

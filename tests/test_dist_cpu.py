@@ -82,3 +82,43 @@ def test_single_process_is_a_noop():
     model(torch.ones(2, 4)).sum().backward()
     before = flat.clone()
     assert red.finish() == 1.0 and torch.equal(flat, before)
+
+
+def _worker_two_branches(rank, world, port, out):
+    """bench.py's data-parallel step: two branches without shared parameters, back-propagated one after the other
+    (PoseNet branch first so that its buckets reduce under the MeshNet backward)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from pose2mesh_release_amd import dist as pd
+    pd.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"a": torch.nn.Linear(20, 64), "b": torch.nn.Linear(20, 9)})
+    params, offsets, flat = _flat_setup(model)
+    red = pd.BucketedAllReduce(params, offsets, flat, bucket_bytes=2048)
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(16, 20, generator=g)
+    xs = X[rank * 8:(rank + 1) * 8]
+    for _ in range(2):
+        flat.zero_()
+        la, lb = model["a"](xs).pow(2).mean(), model["b"](xs.detach()).abs().mean()
+        la.backward()
+        lb.backward()
+        flat.mul_(red.finish())
+    if rank == 0:
+        torch.save({"flat": flat.clone(), "nb": len(red.buckets)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_backward_calls_share_one_reducer(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_two_branches, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"a": torch.nn.Linear(20, 64), "b": torch.nn.Linear(20, 9)})
+    params, offsets, flat = _flat_setup(model)
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(16, 20, generator=g)
+    (model["a"](X).pow(2).mean() + model["b"](X).abs().mean()).backward()
+    assert got["nb"] >= 2
+    assert (got["flat"] - flat).abs().max() < 1e-6
