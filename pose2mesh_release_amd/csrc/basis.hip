@@ -10,6 +10,8 @@
 // is re-used from L2 (one sample's level is <= 6 MB).  A block owns a contiguous tile of rows of
 // ONE sample, and block ids are swizzled so that consecutive tiles of a sample share an XCD (L2).
 // Algorithmic HBM bytes: read X once, write T1 and T2 once.
+#include <cstdlib>
+
 #include "p2m_common.h"
 
 namespace p2m {
@@ -19,6 +21,12 @@ namespace p2m {
                                    // (measured B=256,V=11776,F=128: bwd 1.5 -> 2.6 TB/s going from 16 to 4)
 #endif
 constexpr int ROWS_PER_BLOCK = P2M_BASIS_ROWS;
+
+// P2M_BASIS_TILED=0 falls back to the row-per-wave gather kernel for the real rows of split levels
+static bool basis_tiled() {
+  static int v = [] { const char* e = getenv("P2M_BASIS_TILED"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
   // observed dispatch: block b runs on XCD b % 8 -> give each XCD a contiguous range of logical ids
@@ -283,6 +291,103 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged basis kernel for the real rows of a split level (TilePlan, p2m_common.h).
+// One block (512 threads) = one tile (<= 32 consecutive real rows) x SPB samples x one 128-feature slice.  Per sample:
+// the tile's union of source rows (~4 per output row instead of ~21 gathered rows) is loaded ONCE with whole-row
+// coalesced float4 loads - into registers while the previous sample is being computed, then stored to LDS - and each
+// lane group (LPR lanes = one row of FB = 4 LPR features) accumulates its output
+// row from LDS: the per-entry {a, b, local index} is a broadcast ds_read_b128, the data a conflict-free ds_read_b128.
+// Entry order = merged-CSR order and the same fmaf chain as k_basis_fwd: results are bitwise identical to it.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int LPR>
+__global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
+                                                        float* __restrict__ T1, float* __restrict__ T2, int B, int F,
+                                                        long x_rows, int nset, int spb) {
+  constexpr int NT = 512;
+  constexpr int FB = LPR * 4;                 // features per slice
+  constexpr int RPI = NT / LPR;               // rows the block touches per instruction
+  constexpr int NPF = (TILE_UCAP + RPI - 1) / RPI;   // union rows per lane group
+  __shared__ __attribute__((aligned(16))) float xs[TILE_UCAP * FB];
+  __shared__ __attribute__((aligned(16))) f32x4v ents[TILE_ECAP];
+  __shared__ int rowoff[TILE_RMAX + 1];
+
+  const int tile = blockIdx.x;
+  const int t = threadIdx.x;
+  const int grp = t / LPR;                    // row group of this lane
+  const int lf = (t % LPR) * 4;
+  const int l4 = lf + blockIdx.z * FB;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  const int e0 = pl.erow[r0], nE = pl.erow[r0 + R] - e0;
+  for (int i = t; i < nE; i += NT) ents[i] = *reinterpret_cast<const f32x4v*>(&pl.ent[e0 + i]);
+  if (t <= R) rowoff[t] = pl.erow[r0 + t] - e0;
+  // this lane group's union rows (the same for every sample): element offsets inside one sample of X
+  long xoff[NPF];
+#pragma unroll
+  for (int q = 0; q < NPF; q++) {
+    const int u = grp + q * RPI;
+    xoff[q] = (long)pl.ucol[u0 + (u < U ? u : U - 1)] * F + l4;     // clamped: loads stay unconditional
+  }
+
+  const int b0 = blockIdx.y * spb;
+  int b1 = b0 + spb;
+  if (b1 > B) b1 = B;
+  // the union rows of sample b+1 are fetched into registers while sample b is computed from LDS
+  f32x4v pf[NPF];
+  auto issue = [&](int b) {
+    const float* Xb = X + (long)b * x_rows * F;
+#pragma unroll
+    for (int q = 0; q < NPF; q++) pf[q] = *reinterpret_cast<const f32x4v*>(Xb + xoff[q]);
+  };
+  issue(b0);
+  for (int b = b0; b < b1; b++) {
+    __syncthreads();                          // tables ready / the previous sample's LDS reads are done
+#pragma unroll
+    for (int q = 0; q < NPF; q++) {
+      const int u = grp + q * RPI;
+      if (u < U) *reinterpret_cast<f32x4v*>(&xs[u * FB + lf]) = pf[q];
+    }
+    __syncthreads();
+    issue(b + 1 < b1 ? b + 1 : b);            // unconditional (the last one re-reads sample b: harmless)
+    for (int i = grp; i < R; i += RPI) {
+      f32x4v t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+      const int s = rowoff[i], e = rowoff[i + 1];
+      int j = s;
+      for (; j + 4 <= e; j += 4) {
+        f32x4v en[4], x[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) en[q] = ents[j + q];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          x[q] = *reinterpret_cast<const f32x4v*>(&xs[__float_as_int(en[q][2]) * FB + lf]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            t1[c] = fmaf(en[q][0], x[q][c], t1[c]);
+            t2[c] = fmaf(en[q][1], x[q][c], t2[c]);
+          }
+        }
+      }
+      for (; j < e; j++) {
+        const f32x4v en = ents[j];
+        const f32x4v x = *reinterpret_cast<const f32x4v*>(&xs[__float_as_int(en[2]) * FB + lf]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          t1[c] = fmaf(en[0], x[c], t1[c]);
+          t2[c] = fmaf(en[1], x[c], t2[c]);
+        }
+      }
+      const long o = ((long)b * nset + r0 + i) * F + l4;
+      *reinterpret_cast<f32x4v*>(T1 + o) = t1;
+      *reinterpret_cast<f32x4v*>(T2 + o) = t2;
+    }
+  }
+}
+
 static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
                             int32_t in_shift, int real_only, void* stream) {
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
@@ -290,6 +395,16 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
   const int* ids = real_only ? g.real_ids : nullptr;
   const int nset = real_only ? g.n_real : g.V;
   if (nset == 0) return P2M_OK;
+  if (real_only && basis_tiled() && g.plan[in_shift].ntiles > 0 && (F == 32 || F == 64 || F % 128 == 0)) {
+    const TilePlan& pl = g.plan[in_shift];
+    const int spb = 8;                                        // samples per block (amortises the tile tables)
+    const long x_rows = g.V >> in_shift;
+    const dim3 grid(pl.ntiles, cdiv(B, spb), F >= 128 ? F / 128 : 1);
+    if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
+    else if (F == 64) hipLaunchKernelGGL(k_basis_tile<16>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
+    else hipLaunchKernelGGL(k_basis_tile<32>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
+    return check_launch("cheb_basis_fwd(tiled)");
+  }
   const int tps = cdiv(nset, ROWS_PER_BLOCK);
   auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
   switch (F) {

@@ -113,6 +113,71 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   g->V = V;
   g->n_real = (int)real_ids.size();
   g->n_fake = (int)fake_ids.size();
+  // tile plans of the LDS-staged basis kernel (levels with a real/fake split only; small levels keep the row kernel)
+  if (g->n_fake > 0 && g->n_real >= 256) {
+    for (int sh = 0; sh < 2; sh++) {
+      if (sh == 1 && (V & 1)) break;
+      std::vector<int> tile_row{0}, tile_u{0}, ucol, erow{0};
+      std::vector<float4> ent;
+      std::vector<int> local(V, -1), uni;
+      int i = 0;
+      const int n = g->n_real;
+      while (i < n) {
+        uni.clear();
+        int rows = 0, entries = 0;
+        while (i + rows < n && rows < TILE_RMAX) {
+          const int v = real_ids[i + rows];
+          const size_t before = uni.size();
+          for (int j = rp[v]; j < rp[v + 1]; j++) {
+            const int src = mc[j] >> sh;
+            if (local[src] < 0) { local[src] = 1; uni.push_back(src); }
+          }
+          const int len = rp[v + 1] - rp[v];
+          if (rows > 0 && ((int)uni.size() > TILE_UCAP || entries + len > TILE_ECAP)) {
+            for (size_t q = before; q < uni.size(); q++) local[uni[q]] = -1;   // undo this row
+            uni.resize(before);
+            break;
+          }
+          entries += len;
+          rows++;
+        }
+        if ((int)uni.size() > TILE_UCAP || entries > TILE_ECAP) {      // a single row too large for a tile
+          for (int c : uni) local[c] = -1;
+          tile_row.assign(1, 0);
+          break;
+        }
+        std::sort(uni.begin(), uni.end());
+        for (size_t q = 0; q < uni.size(); q++) local[uni[q]] = (int)q;
+        for (int r = 0; r < rows; r++) {
+          const int v = real_ids[i + r];
+          for (int j = rp[v]; j < rp[v + 1]; j++) {
+            float4 e4;
+            e4.x = ma[j]; e4.y = mb[j]; e4.w = 0.f;
+            const int lc = local[mc[j] >> sh];
+            memcpy(&e4.z, &lc, sizeof(int));
+            ent.push_back(e4);
+          }
+          erow.push_back((int)ent.size());
+        }
+        for (int c : uni) { ucol.push_back(c); local[c] = -1; }
+        i += rows;
+        tile_row.push_back(i);
+        tile_u.push_back((int)ucol.size());
+      }
+      if (tile_row.size() < 2) continue;                                 // no plan: the row kernel stays in charge
+      TilePlan& pl = g->plan[sh];
+      int rc2;
+      if ((rc2 = upload(tile_row.data(), sizeof(int) * tile_row.size(), (void**)&pl.tile_row)) != P2M_OK ||
+          (rc2 = upload(tile_u.data(), sizeof(int) * tile_u.size(), (void**)&pl.tile_u)) != P2M_OK ||
+          (rc2 = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
+          (rc2 = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
+          (rc2 = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK) {
+        p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
+        return rc2;
+      }
+      pl.ntiles = (int)tile_row.size() - 1;
+    }
+  }
   // 64 zero entries of slack: the pipelined kernels prefetch ids a few 16-row stages ahead without bounds checks
   real_ids.resize(real_ids.size() + 64, 0);
   fake_ids.resize(fake_ids.size() + 64, 0);
@@ -144,6 +209,13 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->b) (void)hipFree(g->b);
   if (g->real_ids) (void)hipFree(g->real_ids);
   if (g->fake_ids) (void)hipFree(g->fake_ids);
+  for (TilePlan& pl : g->plan) {
+    if (pl.tile_row) (void)hipFree(pl.tile_row);
+    if (pl.tile_u) (void)hipFree(pl.tile_u);
+    if (pl.ucol) (void)hipFree(pl.ucol);
+    if (pl.erow) (void)hipFree(pl.erow);
+    if (pl.ent) (void)hipFree(pl.ent);
+  }
   delete g;
   return P2M_OK;
 }

@@ -12,6 +12,27 @@ namespace p2m {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Tile plan of the LDS-staged basis kernel (k_basis_tile): the real rows, in compact order, are cut into tiles of
+// consecutive rows whose merged-CSR neighbourhoods have a small UNION (the coarsening-tree order keeps neighbours
+// close: 30 consecutive rows touch ~125 distinct rows, not 30 x 21).  A block stages the union rows of one sample in
+// LDS once (coalesced whole-row loads) and every output row then gathers from LDS.
+struct TilePlan {
+  int ntiles = 0;
+  int* tile_row = nullptr;    // [ntiles+1]  compact row range of each tile
+  int* tile_u = nullptr;      // [ntiles+1]  range of each tile in ucol
+  int* ucol = nullptr;        // union source rows (vertex id >> shift), ascending within a tile
+  int* erow = nullptr;        // [n_real+1]  entry range of each compact row
+  float4* ent = nullptr;      // per entry {a, b, bits(local index into the tile's union), 0}, merged-CSR order
+};
+#ifndef P2M_TILE_RMAX
+#define P2M_TILE_RMAX 32
+#define P2M_TILE_UCAP 120
+#define P2M_TILE_ECAP 896
+#endif
+constexpr int TILE_RMAX = P2M_TILE_RMAX;     // rows per tile
+constexpr int TILE_UCAP = P2M_TILE_UCAP;     // union rows per tile: 120 x 512 B = 60 KB of LDS at 128 features
+constexpr int TILE_ECAP = P2M_TILE_ECAP;     // entries per tile: 14 KB of LDS
+
 // Device-side CSR of one coarsening level.  `col/a/b` is the *merged* pattern of L and
 // L2 = 2*L*L - I: T1 = sum a*x[col], T2 = sum b*x[col] are produced by ONE gather pass.
 struct Graph {
@@ -30,6 +51,7 @@ struct Graph {
   int* real_ids = nullptr;   // [n_real]
   int* fake_ids = nullptr;   // [n_fake]
   float fake_a = 0.f, fake_b = 0.f;
+  TilePlan plan[2];          // [in_shift]; ntiles == 0: no plan (no real/fake split on this level)
 };
 
 // Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)

@@ -341,3 +341,29 @@ def test_bf16x3_error_is_fp32_class(ops, monkeypatch, M, Ka, N):
     print("max |err| / sum|a||b|:", errs)
     assert errs["f32"] < 5e-6 and errs["bf16x3"] < 5e-6, errs              # ~ sqrt(K) * 2^-24
     assert errs["bf16x3"] <= 4.0 * errs["f32"] + 2.4e-7, errs              # 2.4e-7 = 2 fp32 ulps of the scale
+
+
+@pytest.mark.parametrize("V,Fdim,shift,B", [(736, 128, 0, 5), (736, 128, 1, 3), (1472, 64, 1, 9), (2944, 32, 0, 4),
+                                            (736, 256, 0, 2), (1472, 256, 1, 6)])
+def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
+    """k_basis_tile (LDS-staged union of the neighbourhoods of a tile of real rows) keeps the merged-CSR order and
+    the fmaf chain of the row kernel: the compact planes equal the real rows of the full planes bit for bit."""
+    L = _rand_graph(V, 100 + V + shift, fake_frac=0.4)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert g.n_fake > 0 and g.n_real >= 256
+    gen = torch.Generator().manual_seed(V + Fdim)
+    X = torch.randn(B * (V >> shift), Fdim, generator=gen).cuda()
+    T1, T2 = ops.cheb_basis_fwd(g, X, B, Fdim, shift)
+    T1c, T2c = ops.cheb_basis_fwd_real(g, X, B, Fdim, shift)
+    real = torch.as_tensor(_real_ids(L), device="cuda")
+    assert real.numel() == g.n_real
+    ref1 = T1.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
+    ref2 = T2.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
+    assert torch.equal(T1c, ref1) and torch.equal(T2c, ref2)
+
+
+def _real_ids(L):
+    """Vertices whose row is not the lone diagonal (the complement of the isolated padding vertices)."""
+    L = L.tocsr()
+    deg = np.diff(L.indptr)
+    return np.where(~((deg == 1) & (L.indices[L.indptr[:-1].clip(max=L.nnz - 1)] == np.arange(L.shape[0]))))[0]
