@@ -314,11 +314,19 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
   __shared__ __attribute__((aligned(16))) f32x4v ents[TILE_ECAP];
   __shared__ int rowoff[TILE_RMAX + 1];
 
-  const int tile = blockIdx.x;
+  // block -> (feature slice, sample group, tile), tile fastest, through the XCD swizzle: the blocks resident on one
+  // XCD then work on ADJACENT tiles of the same samples, whose unions overlap ~4x - the overlap is served by that
+  // XCD's L2 instead of being fetched from HBM once per XCD
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int nsg = (B + spb - 1) / spb;
+  if (lid >= pl.ntiles * nsg * (F / FB)) return;
+  const int tile = lid % pl.ntiles;
+  const int sgrp = (lid / pl.ntiles) % nsg;
+  const int slice = lid / (pl.ntiles * nsg);
   const int t = threadIdx.x;
   const int grp = t / LPR;                    // row group of this lane
   const int lf = (t % LPR) * 4;
-  const int l4 = lf + blockIdx.z * FB;
+  const int l4 = lf + slice * FB;
   const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
   const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
   const int e0 = pl.erow[r0], nE = pl.erow[r0 + R] - e0;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
     xoff[q] = (long)pl.ucol[u0 + (u < U ? u : U - 1)] * F + l4;     // clamped: loads stay unconditional
   }
 
-  const int b0 = blockIdx.y * spb;
+  const int b0 = sgrp * spb;
   int b1 = b0 + spb;
   if (b1 > B) b1 = B;
   // the union rows of sample b+1 are fetched into registers while sample b is computed from LDS
@@ -399,7 +407,7 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
     const TilePlan& pl = g.plan[in_shift];
     const int spb = 8;                                        // samples per block (amortises the tile tables)
     const long x_rows = g.V >> in_shift;
-    const dim3 grid(pl.ntiles, cdiv(B, spb), F >= 128 ? F / 128 : 1);
+    const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (F >= 128 ? F / 128 : 1), 8) * 8);
     if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
     else if (F == 64) hipLaunchKernelGGL(k_basis_tile<16>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
     else hipLaunchKernelGGL(k_basis_tile<32>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
