@@ -1371,8 +1371,6 @@ static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
 #define P2M_LAUNCH_WS(BNv, EX)                                                                              \
   do {                                                                                                      \
     if (gemm_ws() == 2) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 2>), grid, dim3(512), 0, s, g); \
-    else if (gemm_ws() == 3) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 3>), grid, dim3(512), 0, s, g); \
-    else if (gemm_ws() == 4) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 4>), grid, dim3(512), 0, s, g); \
     else hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 3, 4>), grid, dim3(512), 0, s, g);              \
   } while (0)
     if (wide) { if (extra) P2M_LAUNCH_WS(128, true); else P2M_LAUNCH_WS(128, false); }
