@@ -389,9 +389,11 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
           t2[c] = fmaf(en[1], x[c], t2[c]);
         }
       }
+      // streaming stores: the planes are read next by the GEMM, long after they have left L2 anyway - keeping them
+      // out of L2 leaves it to the overlapping unions of neighbouring tiles
       const long o = ((long)b * nset + r0 + i) * F + l4;
-      *reinterpret_cast<f32x4v*>(T1 + o) = t1;
-      *reinterpret_cast<f32x4v*>(T2 + o) = t2;
+      __builtin_nontemporal_store(t1, reinterpret_cast<f32x4v*>(T1 + o));
+      __builtin_nontemporal_store(t2, reinterpret_cast<f32x4v*>(T2 + o));
     }
   }
 }

@@ -34,9 +34,9 @@ ms_full = bench(lambda: ops.cheb_basis_fwd(g, X, B, F, shift))
 ms_real = bench(lambda: ops.cheb_basis_fwd_real(g, X, B, F, shift))
 moved_full = 4.0 * B * V * F * (2 + 1.0 / (1 << shift))
 moved_real = 4.0 * B * g.n_real * F * (2 + 1.0 / (1 << shift))
-print(f"V={V} real={g.n_real} F={F} shift={shift}: all rows {ms_full:.3f} ms ({moved_full / ms_full / 1e9:.0f} GB/s) | "
-      f"real rows {ms_real:.3f} ms ({moved_real / ms_real / 1e9:.0f} GB/s moved, "
-      f"{12.0 * B * V * F / ms_real / 1e9:.0f} GB/s by the all-rows formula)")
+print(f"V={V} real={g.n_real} F={F} shift={shift}: all rows {ms_full:.3f} ms ({moved_full / ms_full / 1e6:.0f} GB/s) | "
+      f"real rows {ms_real:.3f} ms ({moved_real / ms_real / 1e6:.0f} GB/s moved, "
+      f"{12.0 * B * V * F / ms_real / 1e6:.0f} GB/s by the all-rows formula)")
 if os.environ.get("PROBE_BWD") == "1":
     d = [torch.randn(B * V, F, device="cuda") for _ in range(2)]
     Xf = torch.randn(B * V, F, device="cuda")
