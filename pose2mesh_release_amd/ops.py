@@ -283,12 +283,17 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     return T1c, T2c, st1, st2
 
 
+# blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,
+# 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce)
+TN_TARGET_BLOCKS = 768
+
+
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
     """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks)."""
     n = g.n_real if row_set == 1 else g.n_fake
     N = len(G) * Gc
     ntiles = ((Ka + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, -(-768 // (B * ntiles)))
+    splits = max(1, -(-TN_TARGET_BLOCKS // (B * ntiles)))
     nch = B * splits
     P = torch.empty((nch, Ka, N), device=A.device, dtype=torch.float32)
     Pdb = torch.empty((nch, N), device=A.device, dtype=torch.float32)
@@ -394,8 +399,10 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend
     return C, st
 
 
-def pick_chunk_rows(M, ntiles_out, target_blocks=768, quantum=32):
+def pick_chunk_rows(M, ntiles_out, target_blocks=None, quantum=32):
     """Rows per split for the weight-gradient contraction: enough blocks to fill 256 CUs."""
+    if target_blocks is None:
+        target_blocks = TN_TARGET_BLOCKS
     nchunks = max(1, min((target_blocks + ntiles_out - 1) // ntiles_out, (M + 255) // 256))
     rows = (M + nchunks - 1) // nchunks
     rows = ((rows + quantum - 1) // quantum) * quantum
