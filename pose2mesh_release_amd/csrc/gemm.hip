@@ -1266,9 +1266,15 @@ __global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ W
   We[idx] = Wt[idx] + a * Wt[plane + idx] + b * Wt[2 * plane + idx];
 }
 
-// 1024 threads = 32 consecutive output elements x 32 chunk groups: the partial buffers hold hundreds of chunks
-// (one per sample in row-set mode), so the chunk loop is split 32 ways (4 loads in flight each) and reduced through LDS.
-constexpr int UNP_CG = 32;
+// Block = 32 consecutive output elements x UNP_CG chunk groups: the partial buffers hold hundreds of chunks (one per
+// sample in row-set mode), so the chunk loop is split UNP_CG ways (4 loads in flight each) and reduced through LDS.
+// 8 groups (256 threads): alone on the GPU 32 groups are faster, but this kernel runs on the side stream next to the
+// GEMM blocks that own most of the CUs' registers and LDS, and small blocks find a slot sooner (whole step, meshes/s:
+// 2 groups 4213, 4: 4222-4230, 8: 4206-4253, 16: 4209, 32: 4174-4189).
+#ifndef P2M_UNP_CG
+#define P2M_UNP_CG 8
+#endif
+constexpr int UNP_CG = P2M_UNP_CG;
 __global__ __launch_bounds__(32 * UNP_CG) void k_weight_grad_unpack(
     const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks, float* __restrict__ dW,
     float* __restrict__ db, int Fout, int Fin, int K, int accumulate, int layout, int pdb_stride,
