@@ -98,10 +98,61 @@ __device__ __forceinline__ float lerp_feat(const float* __restrict__ row, int Fr
   return row[i0] * (1.f - w) + row[i1] * w;
 }
 
+// One float4 column group per thread, ACT_UNROLL rows per thread with all loads issued before the arithmetic (a
+// single 16-byte load per thread leaves the memory pipe half empty: 3.3 TB/s -> see DESIGN.md).  Needs 256 % (F/4) == 0.
+constexpr int ACT_UNROLL = 4;
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
                                                      const float* __restrict__ resid, int Fres, int res_shift,
                                                      float* __restrict__ x, long M, int F) {
+  const int F4 = F >> 2;
+  const int rpb = 256 / F4;                                  // rows per block pass
+  const int f = (threadIdx.x % F4) * 4;
+  const long rbase = (long)blockIdx.x * rpb * ACT_UNROLL + threadIdx.x / F4;
+  float4 v[ACT_UNROLL], q[ACT_UNROLL];
+  const bool same = resid != nullptr && Fres == F;
+#pragma unroll
+  for (int u = 0; u < ACT_UNROLL; u++) {
+    long r = rbase + (long)u * rpb;
+    if (r >= M) r = M - 1;                                   // clamped: keeps the loads unconditional
+    v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+    if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale != nullptr) {
+    sc = *reinterpret_cast<const float4*>(scale + f);
+    sh = *reinterpret_cast<const float4*>(shift + f);
+  }
+#pragma unroll
+  for (int u = 0; u < ACT_UNROLL; u++) {
+    const long r = rbase + (long)u * rpb;
+    if (r >= M) break;
+    float4 w = v[u];
+    if (scale != nullptr) {
+      w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
+      w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+    }
+    if (relu) {
+      w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+    }
+    if (same) {
+      w.x += q[u].x; w.y += q[u].y; w.z += q[u].z; w.w += q[u].w;
+    } else if (resid != nullptr) {
+      const float* rr = resid + (r >> res_shift) * Fres;
+      w.x += lerp_feat(rr, Fres, F, f);
+      w.y += lerp_feat(rr, Fres, F, f + 1);
+      w.z += lerp_feat(rr, Fres, F, f + 2);
+      w.w += lerp_feat(rr, Fres, F, f + 3);
+    }
+    *reinterpret_cast<float4*>(x + r * F + f) = w;
+  }
+}
+
+// one float4 per thread: any F % 4 == 0
+__global__ __launch_bounds__(256) void k_bn_act_fwd_v4(const float* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu,
+                                                        const float* __restrict__ resid, int Fres, int res_shift,
+                                                        float* __restrict__ x, long M, int F) {
   const int F4 = F >> 2;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = M * F4;
@@ -169,20 +220,32 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
   long r1 = r0 + BWD_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
-  for (long r = r0 + rloc; r < r1; r += RP) {
-    float4 g = *reinterpret_cast<const float4*>(gx + r * F + f);
-    float4 v = *reinterpret_cast<const float4*>(y + r * F + f);
-    if (relu) {
-      if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
-      if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
-      if (fmaf(v.z, sc.z, sh.z) <= 0.f) g.z = 0.f;
-      if (fmaf(v.w, sc.w, sh.w) <= 0.f) g.w = 0.f;
+  for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
+    float4 gq[4], vq[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      long r = rb + (long)u * RP;
+      if (r >= r1) r = r1 - 1;
+      gq[u] = *reinterpret_cast<const float4*>(gx + r * F + f);
+      vq[u] = *reinterpret_cast<const float4*>(y + r * F + f);
     }
-    s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
-    s1.x = fmaf(g.x, (v.x - mu.x) * is.x, s1.x);
-    s1.y = fmaf(g.y, (v.y - mu.y) * is.y, s1.y);
-    s1.z = fmaf(g.z, (v.z - mu.z) * is.z, s1.z);
-    s1.w = fmaf(g.w, (v.w - mu.w) * is.w, s1.w);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (rb + (long)u * RP >= r1) break;
+      float4 g = gq[u];
+      const float4 v = vq[u];
+      if (relu) {
+        if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
+        if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
+        if (fmaf(v.z, sc.z, sh.z) <= 0.f) g.z = 0.f;
+        if (fmaf(v.w, sc.w, sh.w) <= 0.f) g.w = 0.f;
+      }
+      s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+      s1.x = fmaf(g.x, (v.x - mu.x) * is.x, s1.x);
+      s1.y = fmaf(g.y, (v.y - mu.y) * is.y, s1.y);
+      s1.z = fmaf(g.z, (v.z - mu.z) * is.z, s1.z);
+      s1.w = fmaf(g.w, (v.w - mu.w) * is.w, s1.w);
+    }
   }
   *reinterpret_cast<float4*>(&red[0][rloc][f]) = s0;
   *reinterpret_cast<float4*>(&red[1][rloc][f]) = s1;
@@ -252,17 +315,28 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   const long r0 = (long)blockIdx.x * APPLY_ROWS_PER_BLOCK;
   long r1 = r0 + APPLY_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
-  for (long r = r0 + rloc; r < r1; r += RP) {
-    float g[4], v[4], o[4];
-    *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(gx + r * F + f);
-    *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(y + r * F + f);
+  for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
+    float g[4][4], v[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float go = g[i];
-      if (relu && fmaf(v[i], sc[i], sh[i]) <= 0.f) go = 0.f;
-      o[i] = fmaf(k[i], go, fmaf(a1[i], v[i] - mu[i], a0[i]));
+    for (int u = 0; u < 4; u++) {
+      long r = rb + (long)u * RP;
+      if (r >= r1) r = r1 - 1;
+      *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
+      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
     }
-    *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long r = rb + (long)u * RP;
+      if (r >= r1) break;
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float go = g[u][i];
+        if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
+        o[i] = fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+      }
+      *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+    }
   }
 }
 
@@ -356,9 +430,16 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
   if (M <= 0) return P2M_OK;
   hipStream_t s = (hipStream_t)stream;
   if (F % 4 == 0 && (resid == nullptr || Fres != F || Fres % 4 == 0)) {
-    long tot = M * (F / 4);
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
-                       res_shift, x, (long)M, F);
+    const int F4 = F / 4;
+    if (F4 <= 256 && 256 % F4 == 0) {
+      const long rows_per_block = (long)(256 / F4) * ACT_UNROLL;
+      hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
+                         Fres, res_shift, x, (long)M, F);
+    } else {
+      long tot = M * F4;
+      hipLaunchKernelGGL(k_bn_act_fwd_v4, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
+                         res_shift, x, (long)M, F);
+    }
   } else {
     long tot = M * F;
     hipLaunchKernelGGL(k_bn_act_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid,
