@@ -378,6 +378,23 @@ __global__ void k_lerp_bwd_add(const float* __restrict__ g, float* __restrict__ 
   dst[idx] += acc;
 }
 
+// Fres == 2 F (the 256 -> 128 block): the resize is the mean of channel pairs, src(j) = 2j + 0.5 exactly, so
+// dst[i] += 0.5 * g[i >> 1] - the same single fmaf per element as the generic gather, vectorised
+__global__ __launch_bounds__(256) void k_lerp_bwd_add_half(const float* __restrict__ g, float* __restrict__ dst,
+                                                            long M, int F) {
+  const int Q = F >> 1;                                     // float4 groups of dst per row = (2F)/4
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * Q) return;
+  const long r = idx / Q;
+  const int q = (int)(idx - r * Q);
+  const float2 gv = *reinterpret_cast<const float2*>(g + r * F + 2 * q);
+  float4* d = reinterpret_cast<float4*>(dst + r * 2 * F + 4 * q);
+  float4 v = *d;
+  v.x += fmaf(0.5f, gv.x, 0.f); v.y += fmaf(0.5f, gv.x, 0.f);
+  v.z += fmaf(0.5f, gv.y, 0.f); v.w += fmaf(0.5f, gv.y, 0.f);
+  *d = v;
+}
+
 }  // namespace p2m
 
 using namespace p2m;
@@ -508,6 +525,11 @@ extern "C" int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F
 extern "C" int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream) {
   P2M_CHECK_ARG(g && dst && F > 0 && Fres > 0, "null pointer or empty shape");
   if (M <= 0) return P2M_OK;
+  if (Fres == 2 * F && F % 2 == 0) {
+    hipLaunchKernelGGL(k_lerp_bwd_add_half, dim3(cdiv(M * (F / 2), 256)), dim3(256), 0, (hipStream_t)stream, g, dst,
+                       (long)M, F);
+    return check_launch("lerp_bwd_add");
+  }
   long tot = M * Fres;
   hipLaunchKernelGGL(k_lerp_bwd_add, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, g, dst, (long)M, F, Fres);
   return check_launch("lerp_bwd_add");
