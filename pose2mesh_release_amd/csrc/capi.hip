@@ -48,7 +48,7 @@ static int upload(const void* src, size_t bytes, void** dst) {
 using namespace p2m;
 
 extern "C" const char* p2m_last_error_string(void) { return g_err; }
-extern "C" const char* p2m_version(void) { return "p2m-hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+extern "C" const char* p2m_version(void) { return "p2m-hip 0.2 (gfx950; fp32 contractions on the BF16 MFMA pipe as 3 exact slices, or on the f32 MFMA)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).
 extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val, int32_t V, int32_t nnz,
