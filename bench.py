@@ -253,7 +253,8 @@ def main():
             g = merged("gemm_planes_mfma", "gemm_planes_mfma_bwd")
             if g:
                 if ops.GEMM_ARITH == "bf16x3":
-                    kname = "k_gemm_planes_bx (fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product)"
+                    kname = ("k_gemm_planes_ws" if os.environ.get("P2M_GEMM_WS", "2") != "0" else "k_gemm_planes_bx") + \
+                        " (fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product)"
                     peak = PEAK_BF16_MFMA_TFLOPS / 6.0
                 else:
                     kname, peak = "k_gemm_planes (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS

@@ -1348,9 +1348,9 @@ static int env_int(const char* name, int dflt) {
 }
 // tuning knob: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32)
 static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 32; return kb; }
-// bf16x3 plane contraction: the 4-wave kernel (0), or the wave-specialised kernel with a 3-chunk ring and 1 block/CU (1)
-// or a 2-chunk ring and 2 blocks/CU (2)
-static int gemm_ws() { static int v = env_int("P2M_GEMM_WS", 0); return v; }
+// bf16x3 plane contraction: the wave-specialised kernel with a 2-chunk ring and 2 blocks/CU (2, default: +1.4 % on the
+// whole step, 4296 vs 4237 meshes/s), with a 3-chunk ring and 1 block/CU (1), or the 4-wave kernel (0)
+static int gemm_ws() { static int v = env_int("P2M_GEMM_WS", 2); return v; }
 
 extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
