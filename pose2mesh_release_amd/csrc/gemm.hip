@@ -1212,6 +1212,225 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bx(TnArgs g) {
   }
 }
 
+// Wave-specialised form of k_gemm_tn_bx (4 MFMA waves + 4 staging waves, one LDS-only barrier per 16-row stage):
+// same staging, LDS image and epilogue; see k_gemm_planes_ws.
+template <int BN, bool ROWS = false>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
+  constexpr int NS = 3;
+  constexpr int RK = 16;                 // rows (reduction) per stage = one bf16 MFMA k-step
+  constexpr int LDX = RK + 8;            // bf16 per LDS row: 48-byte stride, conflict-free ds_read_b128
+  constexpr int WTN = BN / 2;
+  constexpr int TN = WTN / 32;
+  constexpr int TM = 2;
+  constexpr int A_BUF = NS * BM * LDX;
+  constexpr int G_BUF = NS * BN * LDX;
+  __shared__ __attribute__((aligned(16))) float smem[(2 * A_BUF + 2 * G_BUF) / 2];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Gs = As + 2 * A_BUF;
+
+  const int tile = blockIdx.x;
+  const int kt = tile / g.ntn, nt = tile % g.ntn;
+  const int chunk = blockIdx.y;
+  const int kk0 = kt * BM, n0 = nt * BN;
+  const int rs_b = ROWS ? chunk / g.splits : 0;
+  const long r_begin = ROWS ? (long)(chunk - rs_b * g.splits) * g.chunk_rows : (long)chunk * g.chunk_rows;
+  long r_end = r_begin + g.chunk_rows;
+  if (r_end > (ROWS ? (long)g.nset : g.M)) r_end = ROWS ? (long)g.nset : g.M;
+  const int nst = r_end > r_begin ? (int)((r_end - r_begin + RK - 1) / RK) : 0;
+
+  const int t = threadIdx.x;
+  const bool producer = t >= 256;          // waves 4..7 stage, waves 0..3 run the MFMAs (k_gemm_planes_ws)
+  const int pt = t & 255;
+  const int lane = t & 63, wave = (t >> 6) & 3;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // staging role of this thread: a 4-row x 4-column block of the A tile (t < 128) or of the G tile
+  const bool is_a = pt < 128;
+  const int st = pt & 127;
+  const int rq = st & 3;                                   // row quad of the 16-row stage
+  const int c4 = is_a ? (st >> 2) : (st >> 2) % (BN / 4);  // column quad (BN = 64: the upper threads duplicate)
+  const float* src;       // plane base + column offset
+  int pitch, shift;
+  bool compact_rows;      // ROWS: read at the compact row b*nset + r instead of b*V + ids[r]
+  unsigned short* dst;    // LDS image (buffer 0, slice 0) of this thread's first column, at its row quad
+  int slice_stride;
+  {
+    if (is_a) {
+      int kk = kk0 + c4 * 4;
+      if (kk >= g.Ktot) kk = 0;                            // clamped: those rows of P are never stored
+      const int ap = kk / g.Ka;
+      src = g.A[ap] + (kk - ap * g.Ka);
+      pitch = g.Ka;
+      shift = (ap == 0) ? g.a0_shift : 0;
+      compact_rows = false;
+      dst = As + (c4 * 4) * LDX + rq * 4;
+      slice_stride = BM * LDX;
+    } else {
+      int n = n0 + c4 * 4;
+      if (n >= g.N) n = 0;
+      const int gq = n / g.Gc;
+      src = g.G[gq] + (n - gq * g.Gc);
+      pitch = g.Gc;
+      shift = 0;
+      compact_rows = ROWS && gq != 0 && g.compact;
+      dst = Gs + (c4 * 4) * LDX + rq * 4;
+      slice_stride = BN * LDX;
+    }
+  }
+  const int buf_stride = is_a ? A_BUF : G_BUF;
+  const int* idp = ROWS ? g.ids + r_begin + rq * 4 : nullptr;
+  const long row_base = ROWS ? (long)rs_b * g.V : 0;
+  const long crow_base = ROWS ? (long)rs_b * g.nset : 0;
+
+  f32x4 x0[4], x1[4];       // two register stages (native vector types: no scratch)
+  i32x4 id0 = {0, 0, 0, 0}, id1 = {0, 0, 0, 0};
+  f32x4 dbs = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_ids = [&](int kc, i32x4& id) {
+    if (ROWS) id = *reinterpret_cast<const i32x4*>(idp + (long)kc * RK);
+  };
+  auto load_stage = [&](int kc, f32x4 (&x)[4], const i32x4& id) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      long r = r_begin + (long)kc * RK + rq * 4 + ps;
+      if (r >= r_end) r = r_end - 1;
+      long row;
+      if (ROWS) row = compact_rows ? crow_base + r : row_base + id[ps];
+      else row = r;
+      x[ps] = *reinterpret_cast<const f32x4*>(src + (row >> shift) * pitch);
+    }
+  };
+  auto store_stage = [&](int buf, int kc, f32x4 (&x)[4]) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) asm volatile("" : "+v"(x[ps]));     // see k_gemm_planes_bx
+    const long rlast = r_end - (r_begin + (long)kc * RK + rq * 4);        // rows of this quad that exist
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      if (ps >= rlast) x[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dbs += x[ps];
+    }
+    unsigned short* d = dst + buf * buf_stride;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ps++) split3(x[ps][e], h[ps], m[ps], l[ps]);
+      *reinterpret_cast<u32x2*>(d + e * LDX) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
+      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
+      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+    }
+  };
+  auto compute = [&](int cur) {
+    const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
+    const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + l31) * LDX + lhi * 8;
+    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const unsigned short* q = as + i * 32 * LDX;
+      ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
+      am[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BM * LDX));
+      al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BM * LDX));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const unsigned short* q = gs + j * 32 * LDX;
+      bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
+      bm[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BN * LDX));
+      bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BN * LDX));
+    }
+#define P2M_PAIR(XA, XB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA[i], XB[j], acc[i][j], 0, 0, 0);
+    P2M_PAIR(al, bh)
+    P2M_PAIR(ah, bl)
+    P2M_PAIR(am, bm)
+    P2M_PAIR(am, bh)
+    P2M_PAIR(ah, bm)
+    P2M_PAIR(ah, bh)
+#undef P2M_PAIR
+  };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  if (nst > 0) {
+    if (producer) {
+      // stage s lives in register set s & 1 and LDS buffer s & 1; ids of stage s in id set s & 1.  During iteration
+      // kc (consumers: MFMAs of stage kc) the producers store stage kc+1 and refill its set with stage kc+3.
+      load_ids(0, id0);
+      load_ids(1, id1);
+      load_stage(0, x0, id0);
+      load_ids(2, id0);
+      load_stage(nst > 1 ? 1 : 0, x1, id1);
+      load_ids(3, id1);
+      store_stage(0, 0, x0);
+      load_stage(nst > 2 ? 2 : nst - 1, x0, id0);
+      load_ids(4, id0);
+      lds_barrier();
+      int kc = 0;
+      for (; kc + 4 < nst; kc += 2) {            // steady state: stages kc+3, kc+4 exist, loads unconditional
+        store_stage(1, kc + 1, x1);
+        load_stage(kc + 3, x1, id1);
+        load_ids(kc + 5, id1);
+        lds_barrier();
+        store_stage(0, kc + 2, x0);
+        load_stage(kc + 4, x0, id0);
+        load_ids(kc + 6, id0);
+        lds_barrier();
+      }
+      for (; kc < nst; kc += 2) {                // tail: same rotation, range-checked
+        if (kc + 1 < nst) store_stage(1, kc + 1, x1);
+        if (kc + 3 < nst) load_stage(kc + 3, x1, id1);
+        lds_barrier();
+        if (kc + 1 < nst) {
+          if (kc + 2 < nst) store_stage(0, kc + 2, x0);
+          if (kc + 4 < nst) load_stage(kc + 4, x0, id0);
+          lds_barrier();
+        }
+      }
+    } else {
+      lds_barrier();                             // stage 0 is in LDS
+      for (int kc = 0; kc < nst; kc++) {
+        compute(kc & 1);
+        lds_barrier();
+      }
+    }
+  }
+  __syncthreads();
+
+  float* Pc = g.P + (long)chunk * g.Ktot * g.N;
+  if (!producer) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = acc[i][j][r];
+        }
+      }
+  }
+  if (kt == 0 && g.Pdb != nullptr) {
+    // bias gradient: column sums of G over this chunk; the four row quads of a column quad meet through LDS
+    float* red = smem;  // [4 (rq)][BN]
+    if (producer && !is_a && (st >> 2) < BN / 4) *reinterpret_cast<f32x4*>(red + rq * BN + c4 * 4) = dbs;
+    __syncthreads();
+    if (t < BN) {
+      const float sum = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
+      if (n0 + t < g.N) g.Pdb[(long)chunk * g.N + n0 + t] = sum;
+    }
+  }
+}
+
 __global__ void k_naive_gemm_tn(TnArgs g) {
   // one thread per output (kk, n), one block row per chunk
   int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1351,6 +1570,8 @@ static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 3
 // bf16x3 plane contraction: the wave-specialised kernel with a 2-chunk ring and 2 blocks/CU (2, default: +1.4 % on the
 // whole step, 4296 vs 4237 meshes/s), with a 3-chunk ring and 1 block/CU (1), or the 4-wave kernel (0)
 static int gemm_ws() { static int v = env_int("P2M_GEMM_WS", 2); return v; }
+// the weight-gradient contraction follows P2M_GEMM_WS unless P2M_TN_WS = 0 / 1 says otherwise
+static bool tn_ws() { static int v = env_int("P2M_TN_WS", -1); return v < 0 ? gemm_ws() != 0 : v != 0; }
 
 extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
@@ -1511,12 +1732,14 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   if (N % 128 == 0) {
     g.ntn = N / 128;
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, false>), grid, dim3(256), 0, s, g);
+    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, false>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, false>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, false>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, false>), grid, dim3(256), 0, s, g);
+    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<64, false>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, false>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, false>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn");
@@ -1552,12 +1775,14 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   if (N % 128 == 0) {
     g.ntn = N / 128;
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, true>), grid, dim3(256), 0, s, g);
+    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, true>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, true>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, true>), grid, dim3(256), 0, s, g);
+    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<64, true>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, true>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn_rows");
