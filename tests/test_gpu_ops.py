@@ -367,3 +367,21 @@ def _real_ids(L):
     L = L.tocsr()
     deg = np.diff(L.indptr)
     return np.where(~((deg == 1) & (L.indices[L.indptr[:-1].clip(max=L.nnz - 1)] == np.arange(L.shape[0]))))[0]
+
+
+@pytest.mark.parametrize("env", [{"P2M_GEMM_WS": "0", "P2M_BASIS_TILED": "0"}, {"P2M_GEMM_WS": "1"}])
+def test_non_default_kernel_variants_in_a_subprocess(env, hip_libs):
+    """The kernel variant knobs are read once per process (no mutable global state in the library), so the non-default
+    variants - 4-wave contractions k_gemm_planes_bx / k_gemm_tn_bx, row-per-wave basis kernel for the real rows, the
+    3-chunk-ring wave-specialised contraction - run the contraction / basis / split tests in a child process."""
+    import os
+    import subprocess
+    import sys
+    child_env = dict(os.environ, **env)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k",
+                        "gemm_planes or gemm_tn or bf16x3 or fake_vertex or tiled_basis or cheb_basis"],
+                       env=child_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
