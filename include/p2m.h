@@ -12,7 +12,8 @@
  *  - all matrices fp32 row-major; a "row" is one (sample, vertex) pair, r = b*V + v;
  *  - return 0 on success, negative p2m_status on error; p2m_last_error_string() has the detail;
  *    nothing throws across the boundary;
- *  - thread-safe: no mutable global state besides the thread-local error string;
+ *  - thread-safe: no mutable global state besides the thread-local error string; kernel-variant knobs
+ *    (P2M_GEMM_WS, P2M_TN_WS, P2M_GEMM_KB, P2M_BASIS_TILED) are read once from the environment and never change;
  *  - `shift` arguments implement the reference's nearest x2 vertex un-pooling
  *    (lib/models/meshnet.py:71-78) *virtually*: a tensor stored at V/2 vertices is read as if it
  *    had V vertices through row index r>>1 (valid because V is even and r = b*V+v).
@@ -44,7 +45,7 @@ typedef struct p2m_graph* p2m_graph_t;
 
 /* Thread-local description of the last error returned on this thread. */
 const char* p2m_last_error_string(void);
-/* Library version / build info (e.g. "p2m-hip 0.1 gfx950"). */
+/* Library version / build info (e.g. "p2m-hip 0.2 (gfx950; ...)"). */
 const char* p2m_version(void);
 
 /* ---- graph handle: one per coarsening level ------------------------------------------------
@@ -53,7 +54,9 @@ const char* p2m_version(void);
  * Laplacian L (fp32, V x V, symmetric).  The handle bakes, on the current device, the merged
  * CSR of L and L2 = 2*L*L - I (double accumulation on the host, rounded once to fp32) so the
  * K=3 Chebyshev recurrence T1 = L x, T2 = 2 L T1 - x (lib/models/backbones/cheby_graph_conv.py:25,28)
- * becomes ONE gather pass  T1 = L x, T2 = L2 x.                                               */
+ * becomes ONE gather pass  T1 = L x, T2 = L2 x.  It also bakes the lists of real / isolated (padding) vertices
+ * and, for levels that have both, the tile plans of the LDS-staged basis kernel (consecutive real rows grouped
+ * by the union of their neighbourhoods, one plan per un-pool shift).                                       */
 int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val,
                      int32_t V, int32_t nnz, p2m_graph_t* out);
 int p2m_graph_destroy(p2m_graph_t g);
