@@ -1729,8 +1729,9 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   }
   g.nkt = cdiv(g.Ktot, BM);
   const bool bx = arith == P2M_ARITH_BF16X3;
-  if (N % 128 == 0) {
-    g.ntn = N / 128;
+  // N = 192 (three planes of 64): two 128-wide tiles (the second half empty) stage A twice, three 64-wide tiles thrice
+  if (N % 128 == 0 || (bx && N > 128)) {
+    g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
     if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, false>), grid, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, false>), grid, dim3(256), 0, s, g);
@@ -1772,8 +1773,8 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   g.nkt = cdiv(g.Ktot, BM);
   const bool bx = arith == P2M_ARITH_BF16X3;
   if (bx) g.chunk_rows = cdiv(g.chunk_rows, 16) * 16;    // 16-byte aligned id loads; trailing splits may be empty
-  if (N % 128 == 0) {
-    g.ntn = N / 128;
+  if (N % 128 == 0 || (bx && N > 128)) {
+    g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
     if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, true>), grid, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, true>), grid, dim3(256), 0, s, g);
