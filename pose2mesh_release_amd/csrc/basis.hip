@@ -10,6 +10,9 @@
 // is re-used from L2 (one sample's level is <= 6 MB).  A block owns a contiguous tile of rows of
 // ONE sample, and block ids are swizzled so that consecutive tiles of a sample share an XCD (L2).
 // Algorithmic HBM bytes: read X once, write T1 and T2 once.
+// The row-per-wave kernels (k_basis_fwd / k_basis_bwd) are bound by the gathered volume through the texture path
+// (~21 rows gathered per real output row); k_basis_tile stages the UNION of the neighbourhoods of 32 consecutive real
+// rows in LDS (~4 rows loaded per output row) and is the default for the real rows of levels that have padding vertices.
 #include <cstdlib>
 
 #include "p2m_common.h"

@@ -1,17 +1,20 @@
-// Dense contractions of the Pose2Mesh Chebyshev GCN on gfx950 FP32 MFMA (v_mfma_f32_32x32x2_f32).
+// Dense contractions of the Pose2Mesh Chebyshev GCN on gfx950 matrix cores.
 //
-//   k_gemm_planes : C = [A0|A1|A2] * Bm + bias  (+ BatchNorm partial statistics in the epilogue)
-//   k_gemm_tn     : P[chunk] = [A0|A1|A2]^T * G  over a chunk of rows (weight gradient)
-//   k_naive_*     : scalar fall-backs for the odd shapes (Fin=5 first conv, Fout=3 last conv)
+//   k_gemm_planes[_bx|_ws] : C = [A0|A1|A2] * Bm + bias  (+ addend / un-pool pair-sum, BatchNorm partials in the epilogue)
+//   k_gemm_tn[_bx|_ws]     : P[chunk] = [A0|A1|A2]^T * G  over a chunk of rows (weight gradient)
+//   k_naive_*              : scalar fall-backs for the odd shapes (Fin=5 first conv, Fout=3 last conv)
 //
 // Replaces nn.Linear inside graph_conv_cheby (lib/models/backbones/cheby_graph_conv.py:37), the
-// fc lift (lib/models/meshnet.py:105) and their autograd backward.  1e-4 vertex parity needs exact
-// fp32 products: gfx950 has no TF32/xf32, the f32 MFMA is bitwise an fmaf chain.
+// fc lift (lib/models/meshnet.py:105) and their autograd backward.  1e-4 vertex parity needs fp32 products; gfx950
+// has no TF32/xf32.  Two arithmetics compute the same fp32 contraction (include/p2m.h, P2M_ARITH_*):
+//   plain    native f32 MFMA v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, 157 TFLOP/s peak);
+//   _bx/_ws  every operand cut exactly into three bf16 slices, six slice products per fp32 product on
+//            v_mfma_f32_32x32x16_bf16 (2500 / 6 = 417 TFLOP/s peak), fp32 accumulation - the default.  _ws is the
+//            wave-specialised form (4 MFMA waves + 4 staging waves per block), _bx the 4-wave form.
 //
-// Tiling (64-wide waves): block = 256 threads = 4 waves arranged 2(M) x 2(N); block tile 128 x BN
-// (BN = 128 or 64), K chunk 32; each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles.
-// A 32x32x2 f32 MFMA takes 64 cycles, so the 4 LDS reads that feed 4 MFMAs are noise; what matters
-// is keeping 4+ independent accumulators in flight and double-buffering the HBM->LDS staging.
+// Tiling (64-wide waves), all variants: the MFMA waves are arranged 2(M) x 2(N); block tile 128 x BN (BN = 128 or
+// 64); each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles; K chunk 32 (f32) or 16 (bf16 slices) per barrier,
+// global -> registers -> LDS staging with register prefetch, two blocks per CU.
 #include <cstdlib>
 
 #include "p2m_common.h"
