@@ -40,15 +40,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, dense BF16 matrix peak; the bf16
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec peak (achievable copy ceiling ~6300 GB/s)
 
 
-def synthetic_regressor(J, nv, seed=5):
-    """Sparse-ish row-stochastic joint regressor like J_regressor_h36m_correct.npy (107 nnz / 17 rows)."""
-    rng = np.random.default_rng(seed)
-    R = np.zeros((J, nv), dtype=np.float32)
-    for j in range(J):
-        idx = rng.choice(nv, size=6, replace=False)
-        w = rng.random(6).astype(np.float32)
-        R[j, idx] = w / w.sum()
-    return R
+synthetic_regressor = synth.synthetic_regressor
 
 
 class TrainStep:

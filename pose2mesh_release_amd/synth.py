@@ -50,3 +50,15 @@ def pose2d_batch(B, J, seed=123):
     x = torch.randn(B, J, 2, generator=g)
     x = (x - x.mean(dim=1, keepdim=True)) / x.std(dim=1, keepdim=True, unbiased=False)
     return x
+
+
+def synthetic_regressor(J, nv, seed=5):
+    """Sparse row-stochastic joint regressor like data/Human36M/J_regressor_h36m_correct.npy ((17, 6890), 107 nnz):
+    6 vertices per joint, weights summing to 1."""
+    rng = np.random.default_rng(seed)
+    R = np.zeros((J, nv), dtype=np.float32)
+    for j in range(J):
+        idx = rng.choice(nv, size=6, replace=False)
+        w = rng.random(6).astype(np.float32)
+        R[j, idx] = w / w.sum()
+    return R

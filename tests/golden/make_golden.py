@@ -10,6 +10,13 @@ Fixtures (all deterministic: numpy PCG64 weights/inputs, fixed hull meshes):
                      gradient norms (+ a few full gradients) for a seeded upstream gradient
   flat_<set>.npz     real lib/models/pose2mesh_net.FlatPose2Mesh in eval(): cam_mesh, pose3d
   chebconv.npz       real graph_conv_cheby (cheby_graph_conv.py:5-42) fwd/bwd at several shapes
+  loss_<set>.npz     real lib/core/loss.py classes driven exactly as lib/core/base.py:130-143 does: the five weighted
+                     loss values and d(loss)/d(cam_mesh) (inputs are re-created from seeds by helpers.loss_case)
+  state_<set>.npz    key / shape / checksum list of the real FlatPose2Mesh.state_dict() under torch.manual_seed(123)
+                     (+ the small tensors themselves), for the strict load_state_dict test
+  demo_h36m.npz      BASELINE configs[0]: demo/h36m_joint_input.npy through the real get_bbox / process_bbox /
+                     j2d_processing (demo/run.py:149-160), the real FlatPose2Mesh in eval(), and the
+                     perm-reverse + joint-regression epilogue (demo/run.py:169-171)
 """
 import os
 import sys
@@ -138,6 +145,85 @@ def save_chebconv(gL_mano):
     np.savez_compressed(os.path.join(HERE, "chebconv.npz"), **out)
 
 
+def save_loss(joint_set):
+    """The reference's loss classes, called in the order and with the weights of lib/core/base.py:130-143."""
+    L = ref_loader.load_loss()
+    c = helpers.loss_case(joint_set)
+    losses = L.get_loss(c["faces"])                                        # base.py:60 / loss.py:117-120
+    out = {}
+    for tag, with_edge in (("edge", True), ("noedge", False)):
+        cam = c["cam_mesh"].clone().requires_grad_(True)
+        lift = c["lift_pose"].clone().requires_grad_(True)
+        with ref_loader.cpu_cuda_shim():
+            pred_mesh = cam[:, c["perm_reverse"][:c["nv"]], :]                                     # base.py:130
+            pred_pose = torch.matmul(c["J_regressor"][None, :, :], pred_mesh * 1000)               # base.py:131
+            l1 = losses[0](pred_mesh, c["gt_mesh"], c["val_mesh"])                                 # base.py:134-137
+            l2 = 1e-1 * losses[1](pred_mesh, c["gt_mesh"])
+            l4 = 1e-3 * losses[3](pred_pose, c["gt_reg3dpose"], c["val_reg3dpose"])
+            l5 = 1e-3 * losses[4](lift, c["gt_lift3dpose"], c["val_lift3dpose"])
+            loss = l1 + l2 + 0 + l4 + l5                                                           # base.py:138-139
+            l3 = torch.zeros(())
+            if with_edge:                                                                          # base.py:141-143
+                l3 = 20 * losses[2](pred_mesh, c["gt_mesh"])
+                loss = loss + l3
+        loss.backward()
+        out[f"{tag}_losses"] = np.array([float(v) for v in (l1, l2, l3, l4, l5)], np.float64)
+        out[f"{tag}_total"] = np.float64(float(loss))
+        out[f"{tag}_grad_cam"] = cam.grad.numpy()
+        out[f"{tag}_grad_lift"] = lift.grad.numpy()
+    out["cam_sha"] = np.frombuffer(__import__("hashlib").sha256(c["cam_mesh"].numpy().tobytes()).digest(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, f"loss_{joint_set}.npz"), **out)
+
+
+def save_state_spec(joint_set, gL, J):
+    """Key / shape inventory of the REAL reference module's state dict (lib/models/pose2mesh_net.py:25-28 under the
+    reference's default seed, main/train.py:12), so that load_state_dict(strict=True) of the new module is tested
+    against the real key set; tensors with <= 4096 elements are stored, larger ones as (sum, abs-sum) checksums."""
+    ns = ref_loader.load("mano" if joint_set == "mano" else "human36")
+    torch.manual_seed(123)
+    net = ns.pose2mesh_net.get_model(J, [L.copy() for L in gL])
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    out = {"keys": np.array(keys), "shapes": np.array([",".join(str(d) for d in v.shape) for v in sd.values()]),
+           "dtypes": np.array([str(v.dtype) for v in sd.values()]),
+           "num_params": np.int64(sum(p.numel() for p in net.parameters()))}
+    for i, (k, v) in enumerate(sd.items()):
+        if v.numel() <= 4096:
+            out[f"t{i}"] = v.numpy()
+        else:
+            out[f"c{i}"] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+    np.savez_compressed(os.path.join(HERE, f"state_{joint_set}.npz"), **out)
+
+
+def save_demo(gL, rev):
+    """configs[0]: the demo's single-pose path with the real preprocessing functions and the real model."""
+    aug = ref_loader.load_aug()
+    ns = ref_loader.load("human36")
+    cfgm = ns.cfg.MODEL
+    joint_input = np.load(os.path.join(ref_loader.REF_ROOT, "demo", "h36m_joint_input.npy"))
+    bbox = aug.coord_utils.get_bbox(joint_input)                                                  # run.py:150
+    bbox2 = aug.coord_utils.process_bbox(bbox.copy())                                             # run.py:152
+    joint_img, trans = aug.aug_utils.j2d_processing(joint_input.copy(), (cfgm.input_shape[1], cfgm.input_shape[0]),
+                                                    bbox2, 0, 0, None)                            # run.py:154
+    joint_img = joint_img[:, :2]                                                                  # run.py:156-159
+    joint_img /= np.array([[cfgm.input_shape[1], cfgm.input_shape[0]]])
+    mean, std = np.mean(joint_img, axis=0), np.std(joint_img, axis=0)
+    joint_img = (joint_img.copy() - mean) / std
+    x = torch.Tensor(joint_img[None, :, :])                                                       # run.py:160
+    J, nv = 17, 6890
+    net = ns.pose2mesh_net.get_model(J, [L.copy() for L in gL])
+    net.load_state_dict(helpers.numpy_state(net.state_dict(), 2))
+    net.eval()                                                                                    # run.py:166
+    with torch.no_grad(), ref_loader.cpu_cuda_shim():
+        pred_mesh, pose3d = net(x)                                                                # run.py:167
+        mesh = pred_mesh[:, rev[:nv], :]                                                          # run.py:170
+        jreg = torch.from_numpy(synth.synthetic_regressor(J, nv))
+        joints = torch.matmul(jreg, mesh)                                                         # run.py:171
+    np.savez_compressed(os.path.join(HERE, "demo_h36m.npz"), joint_input=joint_input, bbox=bbox, bbox2=bbox2,
+                        trans=trans, model_input=x.numpy(), cam_mesh=pred_mesh.numpy(), pose3d=pose3d.numpy(),
+                        mesh=mesh.numpy(), joints=joints.numpy())
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference tree missing"
     torch.set_num_threads(os.cpu_count() or 1)
@@ -151,6 +237,14 @@ if __name__ == "__main__":
     save_flat("mano", *graphs["mano"])
     save_flat("coco", *graphs["coco"])
     save_chebconv(graphs["mano"][0])
+    for js in ("mano", "coco"):
+        save_loss(js)
+        print("loss", js)
+    for js in ("mano", "human36", "coco"):
+        save_state_spec(js, *graphs[js])
+        print("state", js)
+    _, gLh, _, revh, _, _ = ref_graphs("human36")
+    save_demo(gLh, revh)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

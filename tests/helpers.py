@@ -99,3 +99,34 @@ def rel_l2(a, b):
 def max_vertex_l2(a, b):
     """BASELINE.json's parity metric: max over (sample, vertex) of ||v_new - v_ref||_2."""
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).norm(dim=-1).max())
+
+
+def loss_case(joint_set, B=None, seed=17):
+    """Deterministic inputs of the train-step epilogue + losses (lib/core/base.py:122-143) for one joint set:
+    numpy PCG64 draws, mask shapes as the reference dataloaders emit them ([B, nv, 1] / [B, J, 1], constant per
+    sample: data/Human36M/dataset.py:392-394).  Used by make_golden.py (real reference) and by the tests."""
+    from pose2mesh_release_amd import synth
+    gL, _, rev = golden_graphs(joint_set)
+    J = int(gL[-1].shape[0])
+    nv = 778 if joint_set == "mano" else 6890
+    V0 = int(gL[0].shape[0])
+    if B is None:
+        B = 4 if joint_set == "mano" else 2
+    _, faces = synth.hull_mesh(nv, 0)
+    rng = np.random.default_rng(seed)
+
+    def t(shape, scale):
+        return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+    c = {"faces": faces, "perm_reverse": np.asarray(rev), "nv": nv, "V0": V0, "J": J, "B": B,
+         "J_regressor": torch.from_numpy(synth.synthetic_regressor(J, nv)),
+         "cam_mesh": t((B, V0, 3), 0.3), "lift_pose": t((B, J, 3), 300.0), "gt_mesh": t((B, nv, 3), 0.3),
+         "gt_reg3dpose": t((B, J, 3), 300.0), "gt_lift3dpose": t((B, J, 3), 300.0)}
+    vm = (rng.random(B) > 0.3).astype(np.float32)
+    vr = (rng.random(B) > 0.3).astype(np.float32)
+    vm[0], vr[0] = 1.0, 1.0
+    if B > 1:
+        vm[1] = 0.0
+    c["val_mesh"] = torch.from_numpy(np.repeat(vm[:, None, None], nv, axis=1).copy())
+    c["val_reg3dpose"] = torch.from_numpy(np.repeat(vr[:, None, None], J, axis=1).copy())
+    c["val_lift3dpose"] = torch.ones(B, J, 1)
+    return c

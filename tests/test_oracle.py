@@ -126,3 +126,86 @@ def test_oracle_vs_live_reference_mano():
     out, _, _ = helpers.oracle_run(sd, helpers.oracle_graphs(gL), x, True, False)
     assert helpers.max_vertex_l2(out, ref) < 2e-6
     ref_loader.load("human36")
+
+
+# ---------------------------------------------------------------------------------------------
+# loss / epilogue oracle and demo-preprocessing oracle vs goldens made by the REAL reference
+# ---------------------------------------------------------------------------------------------
+import demo_oracle as do
+import loss_oracle as lo
+
+
+@pytest.mark.parametrize("joint_set", ["mano", "coco"])
+@pytest.mark.parametrize("with_edge", [True, False])
+def test_loss_oracle_vs_reference_golden(joint_set, with_edge):
+    """oracle/loss_oracle.py against lib/core/loss.py driven as lib/core/base.py:130-143 does (values + gradients)."""
+    z = helpers.golden(f"loss_{joint_set}.npz")
+    c = helpers.loss_case(joint_set)
+    tag = "edge" if with_edge else "noedge"
+    cam = c["cam_mesh"].clone().requires_grad_(True)
+    lift = c["lift_pose"].clone().requires_grad_(True)
+    total, parts = lo.train_losses(cam, lift, c["perm_reverse"], c["nv"], c["faces"], c["J_regressor"], c["gt_mesh"],
+                                   c["gt_reg3dpose"], c["gt_lift3dpose"], c["val_mesh"], c["val_reg3dpose"],
+                                   c["val_lift3dpose"], with_edge=with_edge)
+    total.backward()
+    for a, b in zip(parts, z[f"{tag}_losses"]):
+        assert abs(float(a) - b) <= 1e-6 * max(1.0, abs(b))
+    assert abs(float(total) - float(z[f"{tag}_total"])) <= 1e-6 * max(1.0, abs(float(z[f"{tag}_total"])))
+    assert helpers.rel_l2(cam.grad, z[f"{tag}_grad_cam"]) < 1e-6
+    assert helpers.rel_l2(lift.grad, z[f"{tag}_grad_lift"]) < 1e-6
+    fake = np.setdiff1d(np.arange(c["V0"]), c["perm_reverse"][:c["nv"]])
+    assert float(cam.grad[:, fake].abs().max()) == 0.0
+
+
+def test_demo_preprocessing_oracle_vs_reference_golden():
+    """configs[0]: demo/h36m_joint_input.npy through the numpy restatement == the real get_bbox / process_bbox /
+    j2d_processing (SURVEY A7 lists the expected first rows)."""
+    z = helpers.golden("demo_h36m.npz")
+    x, bbox, bbox2 = do.demo_model_input(z["joint_input"].copy())
+    assert z["joint_input"].dtype == np.int64 and z["joint_input"].shape == (17, 2)
+    assert np.array_equal(bbox, z["bbox"]) and np.allclose(bbox2, z["bbox2"], rtol=0, atol=1e-12)
+    assert np.abs(x - z["model_input"][0]).max() < 1e-6
+    assert np.allclose(x[:4], [[0.1489, 0.2843], [-0.3839, 0.2843], [-1.9158, 0.8613], [-2.1156, 1.9963]], atol=1e-4)
+    # the model + epilogue part of the fixture: oracle forward on the golden input
+    gL, _, rev = helpers.golden_graphs("human36")
+    from pose2mesh_release_amd import pose2mesh_net
+    sd = helpers.numpy_state(pose2mesh_net.get_model(17, gL, mano=False).state_dict(), 2)
+    with torch.no_grad():
+        cam_mesh, pose3d = mo.flat_forward(sd, helpers.oracle_graphs(gL), torch.from_numpy(x[None]), False, False)
+    assert helpers.max_vertex_l2(cam_mesh, z["cam_mesh"]) < 5e-6
+    mesh, joints = do.demo_mesh_epilogue(cam_mesh.numpy(), rev, 6890, synth.synthetic_regressor(17, 6890))
+    assert mesh.shape == (1, 6890, 3) and np.abs(mesh - z["mesh"]).max() < 5e-6
+    assert np.abs(joints - z["joints"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("joint_set", ["mano", "human36", "coco"])
+def test_state_dict_inventory_matches_real_reference(joint_set):
+    """Keys, shapes and dtypes of FlatPose2Mesh.state_dict() == the REAL reference module's (SURVEY 8(a3), 8(b));
+    a state dict with exactly the reference's key set loads with strict=True."""
+    from pose2mesh_release_amd import pose2mesh_net
+    z = helpers.golden(f"state_{joint_set}.npz")
+    gL, _, _ = helpers.golden_graphs(joint_set)
+    net = pose2mesh_net.get_model(int(gL[-1].shape[0]), gL, mano=(joint_set == "mano"))
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    for (k, v), shp, dt in zip(sd.items(), z["shapes"], z["dtypes"]):
+        assert ",".join(str(d) for d in v.shape) == str(shp), k
+        assert str(v.dtype) == str(dt), k
+    assert sum(p.numel() for p in net.parameters()) == int(z["num_params"])
+    # a checkpoint-shaped dict with the reference's keys (module. prefix stripped as check_data_pararell does)
+    ref_sd = {}
+    for i, k in enumerate(z["keys"]):
+        k = str(k)
+        shp = tuple(int(d) for d in str(z["shapes"][i]).split(",") if d != "")
+        ref_sd[k] = torch.from_numpy(z[f"t{i}"]) if f"t{i}" in z else torch.zeros(shp, dtype=sd[k].dtype)
+    missing = net.load_state_dict(ref_sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    i = [str(k) for k in z["keys"]].index("pose2mesh.cl.0.weight")
+    assert np.array_equal(net.state_dict()["pose2mesh.cl.0.weight"].numpy(), z[f"t{i}"])
+    # same init distribution as the reference (meshnet.py:46-50): uniform with the same bound, zero bias
+    ours = pose2mesh_net.get_model(int(gL[-1].shape[0]), gL, mano=(joint_set == "mano")).state_dict()
+    for name in ("pose2mesh.cl.3.weight", "pose2mesh.fc.weight"):
+        j = [str(k) for k in z["keys"]].index(name)
+        n = ours[name].numel()
+        ref_absmean = float(z[f"c{j}"][1]) / n if f"c{j}" in z else float(np.abs(z[f"t{j}"]).mean())
+        assert abs(float(ours[name].abs().mean()) - ref_absmean) < 0.05 * ref_absmean, name
