@@ -247,14 +247,27 @@ int p2m_chebconv_fwd(p2m_graph_t g, const float* X, const float* Wt, const float
  * losses[0..3] = L1(pred_mesh, gt_mesh)*w_vertex, normal-vector loss*w_normal, edge-length loss*w_edge,
  * L1(J_regressor @ (pred_mesh*1000), gt_pose)*w_joint, where pred_mesh[b, v] = cam_mesh[b, perm[v]] (the
  * perm-reverse gather of base.py:130).  grad_cam (optional) receives d(sum of the four)/d cam_mesh, [B, V0, 3],
- * zero on fake vertices.  faces: [F,3] int32; vf_ptr/vf_idx: CSR vertex -> (face*3 + corner); jreg: dense
- * [J, nv]; valid_*: per-sample masks [B] or NULL.  workspace: p2m_mesh_loss_workspace(...) floats.           */
+ * zero on fake vertices.  faces: [F,3] int32; vf_ptr/vf_idx: CSR vertex -> (face*3 + corner).  The joint regressor
+ * (dense [J, nv] in the reference, 107 non-zeros of 117 130 for h36m) is passed sparse, by joint (jr_*: CSR, used for
+ * the regression) and by vertex (vj_*: CSC, used for the gradient).  valid_mesh: [B, nv] or NULL, valid_pose: [B, J]
+ * or NULL (the reference's masks are [B, nv, 1] / [B, J, 1], data/Human36M/dataset.py:392-394).  A weight of 0
+ * switches the term AND its gradient off (the reference does not evaluate the edge loss before
+ * cfg.TRAIN.edge_loss_start, base.py:141-143).  workspace: p2m_mesh_loss_workspace(...) floats.                */
 int64_t p2m_mesh_loss_workspace(int32_t B, int32_t nv, int32_t F, int32_t J);
 int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_t nv, const float* gt_mesh,
                   const float* valid_mesh, const int32_t* faces, int32_t F, const int32_t* vf_ptr,
-                  const int32_t* vf_idx, const float* jreg, int32_t J, const float* gt_pose,
-                  const float* valid_pose, float w_vertex, float w_normal, float w_edge, float w_joint,
-                  float* workspace, float* losses, float* grad_cam, int32_t B, void* stream);
+                  const int32_t* vf_idx, const int32_t* jr_ptr, const int32_t* jr_idx, const float* jr_val,
+                  const int32_t* vj_ptr, const int32_t* vj_idx, const float* vj_val, int32_t J,
+                  const float* gt_pose, const float* valid_pose, float w_vertex, float w_normal, float w_edge,
+                  float w_joint, float* workspace, float* losses, float* grad_cam, int32_t B, void* stream);
+
+/* ---- test-step / demo epilogue (lib/core/base.py:200-204, demo/run.py:169-171) -------------------------------
+ * mesh[b, i] = scale * cam_mesh[b, perm[i]], i < nv  (tree order incl. fake vertices -> mesh-model vertex order;
+ * scale = 1000 in the Tester, 1 in the demo);  joints[b, j] = sum_k jr_val[k] * mesh[b, jr_idx[k]] over CSR row j.
+ * mesh: [B, nv, 3] or NULL; joints: [B, J, 3] or NULL.                                                          */
+int p2m_mesh_epilogue(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_t nv, float scale,
+                      const int32_t* jr_ptr, const int32_t* jr_idx, const float* jr_val, int32_t J,
+                      float* mesh, float* joints, int32_t B, void* stream);
 
 /* ---- optimizer step over a flat fp32 buffer ------------------------------------------------
  * torch.optim.Adam semantics (lib/funcs_utils.py:92-96, stepped at lib/core/base.py:148): one fused
@@ -263,6 +276,12 @@ int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_
 int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
                   void* stream);
+
+/* torch.optim.RMSprop semantics with the defaults the reference's yaml recipes use (lib/funcs_utils.py:87-91,
+ * asset/yaml/*.yml `optimizer: 'rmsprop'`: alpha 0.99, eps 1e-8, no momentum, not centered):
+ *   v = alpha v + (1-alpha) g^2;  p -= lr g / (sqrt(v) + eps),  g = grad * grad_scale.                              */
+int p2m_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n, float lr, float alpha,
+                     float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,16 +35,33 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
+    """One object per translation unit (compiled in parallel, only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
-    if not force and not _stale(HIP_LIB, deps):
-        return HIP_LIB
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HIP_HEADERS]
     extra = os.environ.get("P2M_HIPCC_FLAGS", "").split()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", HIP_LIB] + srcs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    flagfile = os.path.join(objdir, "flags.txt")
+    flags_changed = (open(flagfile).read() if os.path.exists(flagfile) else "") != " ".join(extra)
+    jobs, objs = [], []
+    for src_name in HIP_SOURCES:
+        src = os.path.join(CSRC, src_name)
+        obj = os.path.join(objdir, src_name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or flags_changed or _stale(obj, [src] + hdrs):
+            jobs.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + extra + ["-o", obj, src])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+        open(flagfile, "w").write(" ".join(extra))
+    if jobs or not os.path.exists(HIP_LIB):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 

@@ -18,13 +18,18 @@ struct LossArgs {
   const float* cam;      // [B, V0, 3]
   const int* perm;       // [nv]
   const float* gt_mesh;  // [B, nv, 3]
-  const float* valid_mesh;   // [B] or NULL
+  const float* valid_mesh;   // [B, nv] or NULL
   const int* faces;      // [F, 3]
   const int* vf_ptr;     // [nv + 1]
   const int* vf_idx;     // [3F]   face*3 + corner
-  const float* jreg;     // [J, nv]
+  const int* jr_ptr;     // [J + 1]   CSR of the joint regressor (107 non-zeros for the 17 x 6890 h36m regressor)
+  const int* jr_idx;     // [nnz]     vertex (mesh-model order)
+  const float* jr_val;   // [nnz]
+  const int* vj_ptr;     // [nv + 1]  the same matrix by vertex (CSC): joints that use vertex v
+  const int* vj_idx;     // [nnz]     joint
+  const float* vj_val;   // [nnz]
   const float* gt_pose;  // [B, J, 3]
-  const float* valid_pose;   // [B] or NULL
+  const float* valid_pose;   // [B, J] or NULL
   float* face_grad;      // [B, F, 9]
   float* pose_sign;      // [B, J, 3]
   float* partial;        // [4][npart]
@@ -60,40 +65,33 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return s;   // valid in thread 0
 }
 
-// one block per (b, j): regressed joint, L1 term and the sign needed by the vertex gradient
+// one thread per (b, j): regressed joint over the CSR row (6 entries per joint), L1 term and the sign needed by the
+// vertex gradient
 __global__ __launch_bounds__(256) void k_pose_regress(LossArgs a) {
-  __shared__ float sh[3][4];
-  const int b = blockIdx.x / a.J, j = blockIdx.x % a.J;
-  const float* jr = a.jreg + (long)j * a.nv;
-  const float* cam = a.cam + (long)b * a.V0 * 3;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int v = threadIdx.x; v < a.nv; v += 256) {
-    const float w = jr[v];
-    if (w != 0.f) {
-      const float* p = cam + (long)a.perm[v] * 3;
+  __shared__ float sh[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.f;
+  if (idx < a.B * a.J) {
+    const int b = idx / a.J, j = idx - b * a.J;
+    const float* cam = a.cam + (long)b * a.V0 * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = a.jr_ptr[j]; k < a.jr_ptr[j + 1]; k++) {
+      const float w = a.jr_val[k];
+      const float* p = cam + (long)a.perm[a.jr_idx[k]] * 3;
       s0 = fmaf(w, p[0] * 1000.f, s0);
       s1 = fmaf(w, p[1] * 1000.f, s1);
       s2 = fmaf(w, p[2] * 1000.f, s2);
     }
-  }
-  float acc[3] = {s0, s1, s2};
-  for (int c = 0; c < 3; c++) {
-    float v = acc[c];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float val = a.valid_pose ? a.valid_pose[b] : 1.f;
-    float loss = 0.f;
+    const float val = a.valid_pose ? a.valid_pose[idx] : 1.f;
+    const float pose[3] = {s0, s1, s2};
     for (int c = 0; c < 3; c++) {
-      const float pose = sh[c][0] + sh[c][1] + sh[c][2] + sh[c][3];
-      const float d = val * pose - val * a.gt_pose[((long)b * a.J + j) * 3 + c];
+      const float d = val * pose[c] - val * a.gt_pose[(long)idx * 3 + c];
       loss += fabsf(d);
-      a.pose_sign[((long)b * a.J + j) * 3 + c] = a.s_joint * val * sgn(d) * 1000.f;
+      a.pose_sign[(long)idx * 3 + c] = a.s_joint * val * sgn(d) * 1000.f;
     }
-    a.partial[3 * a.npart + blockIdx.x] = loss * a.s_joint;
   }
+  const float sl = block_sum(loss, sh);
+  if (threadIdx.x == 0) a.partial[3 * a.npart + blockIdx.x] = sl * a.s_joint;
 }
 
 // one thread per (b, face): normal + edge terms and their gradients w.r.t. the three corners
@@ -121,18 +119,23 @@ __global__ __launch_bounds__(256) void k_face_terms(LossArgs a) {
     V3 d0 = scale(add(q1, q2), -1.f);       // p0 enters d1, d2 negatively
     V3 d1 = sub(q1, q3);                    // p1: +d1, -d3
     V3 d2 = add(q2, q3);                    // p2: +d2, +d3
+    if (a.s_normal == 0.f) d0 = d1 = d2 = V3{0.f, 0.f, 0.f};
     // ---- edge-length loss (loss.py:99-113)
     const V3 u01 = sub(p0, p1), u02 = sub(p0, p2), u12 = sub(p1, p2);
     const float o1 = sqrtf(dot(u01, u01)), o2 = sqrtf(dot(u02, u02)), o3 = sqrtf(dot(u12, u12));
     const V3 h01 = sub(g0, g1), h02 = sub(g0, g2), h12 = sub(g1, g2);
     const float t1 = sqrtf(dot(h01, h01)), t2 = sqrtf(dot(h02, h02)), t3 = sqrtf(dot(h12, h12));
     l_edge = fabsf(o1 - t1) + fabsf(o2 - t2) + fabsf(o3 - t3);
-    const V3 r1 = scale(u01, a.s_edge * sgn(o1 - t1) / o1);
-    const V3 r2 = scale(u02, a.s_edge * sgn(o2 - t2) / o2);
-    const V3 r3 = scale(u12, a.s_edge * sgn(o3 - t3) / o3);
-    d0 = add(d0, add(r1, r2));
-    d1 = add(d1, sub(r3, r1));
-    d2 = sub(d2, add(r2, r3));
+    if (a.s_edge != 0.f) {
+      // (w_edge == 0, i.e. before cfg.TRAIN.edge_loss_start, the reference does not evaluate this loss at all,
+      // base.py:141-143: no 0/0 from a degenerate predicted edge may leak into the gradient then)
+      const V3 r1 = scale(u01, a.s_edge * sgn(o1 - t1) / o1);
+      const V3 r2 = scale(u02, a.s_edge * sgn(o2 - t2) / o2);
+      const V3 r3 = scale(u12, a.s_edge * sgn(o3 - t3) / o3);
+      d0 = add(d0, add(r1, r2));
+      d1 = add(d1, sub(r3, r1));
+      d2 = sub(d2, add(r2, r3));
+    }
     float* fg = a.face_grad + idx * 9;
     fg[0] = d0.x; fg[1] = d0.y; fg[2] = d0.z;
     fg[3] = d1.x; fg[4] = d1.y; fg[5] = d1.z;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void k_vertex_grad(LossArgs a) {
   float l_v = 0.f;
   if (idx < (long)a.B * a.nv) {
     const int b = (int)(idx / a.nv), v = (int)(idx % a.nv);
-    const float val = a.valid_mesh ? a.valid_mesh[b] : 1.f;
+    const float val = a.valid_mesh ? a.valid_mesh[idx] : 1.f;
     const float* p = a.cam + ((long)b * a.V0 + a.perm[v]) * 3;
     const float* g = a.gt_mesh + idx * 3;
     float gr[3];
@@ -168,13 +171,12 @@ __global__ __launch_bounds__(256) void k_vertex_grad(LossArgs a) {
       gr[0] += fg[0]; gr[1] += fg[1]; gr[2] += fg[2];
     }
     const float* ps = a.pose_sign + (long)b * a.J * 3;
-    for (int j = 0; j < a.J; j++) {
-      const float w = a.jreg[(long)j * a.nv + v];
-      if (w != 0.f) {
-        gr[0] = fmaf(w, ps[j * 3], gr[0]);
-        gr[1] = fmaf(w, ps[j * 3 + 1], gr[1]);
-        gr[2] = fmaf(w, ps[j * 3 + 2], gr[2]);
-      }
+    for (int k = a.vj_ptr[v]; k < a.vj_ptr[v + 1]; k++) {
+      const float w = a.vj_val[k];
+      const int j = a.vj_idx[k];
+      gr[0] = fmaf(w, ps[j * 3], gr[0]);
+      gr[1] = fmaf(w, ps[j * 3 + 1], gr[1]);
+      gr[2] = fmaf(w, ps[j * 3 + 2], gr[2]);
     }
     if (a.grad_cam) {
       float* o = a.grad_cam + ((long)b * a.V0 + a.perm[v]) * 3;
@@ -195,32 +197,84 @@ __global__ void k_loss_finalize(const float* __restrict__ partial, int npart, in
   if (threadIdx.x == 0) losses[which] = (float)s;
 }
 
+// ---- test-step / demo epilogue (lib/core/base.py:200-204, demo/run.py:169-171) ---------------------------------
+//   mesh[b, i] = scale * cam_mesh[b, perm[i]]          (tree order incl. fake vertices -> mesh-model vertex order)
+//   joints[b, j] = sum_k jr_val[k] * mesh[b, jr_idx[k]]  (CSR row j of the joint regressor)
+__global__ __launch_bounds__(256) void k_mesh_epilogue(const float* __restrict__ cam, int V0, const int* __restrict__ perm,
+                                                       int nv, float scale, const int* __restrict__ jr_ptr,
+                                                       const int* __restrict__ jr_idx, const float* __restrict__ jr_val,
+                                                       int J, float* __restrict__ mesh, float* __restrict__ joints, int B) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nmesh = (long)B * nv;
+  if (idx < nmesh) {
+    const int b = (int)(idx / nv), v = (int)(idx - (long)b * nv);
+    const float* p = cam + ((long)b * V0 + perm[v]) * 3;
+    if (mesh) {
+      float* o = mesh + idx * 3;
+      o[0] = p[0] * scale; o[1] = p[1] * scale; o[2] = p[2] * scale;
+    }
+  } else if (joints != nullptr && idx < nmesh + (long)B * J) {
+    const long q = idx - nmesh;
+    const int b = (int)(q / J), j = (int)(q - (long)b * J);
+    const float* cb = cam + (long)b * V0 * 3;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = jr_ptr[j]; k < jr_ptr[j + 1]; k++) {
+      const float w = jr_val[k];
+      const float* p = cb + (long)perm[jr_idx[k]] * 3;
+      s0 = fmaf(w, p[0] * scale, s0);
+      s1 = fmaf(w, p[1] * scale, s1);
+      s2 = fmaf(w, p[2] * scale, s2);
+    }
+    float* o = joints + q * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
 }  // namespace p2m
 
 using namespace p2m;
 
-extern "C" int64_t p2m_mesh_loss_workspace(int32_t B, int32_t nv, int32_t F, int32_t J) {
-  const long nb_face = cdiv((long)B * F, 256), nb_vert = cdiv((long)B * nv, 256), nb_pose = (long)B * J;
+extern "C" int p2m_mesh_epilogue(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_t nv, float scale,
+                                 const int32_t* jr_ptr, const int32_t* jr_idx, const float* jr_val, int32_t J,
+                                 float* mesh, float* joints, int32_t B, void* stream) {
+  P2M_CHECK_ARG(cam_mesh && perm && (mesh || joints), "null pointer");
+  P2M_CHECK_ARG(joints == nullptr || (jr_ptr && jr_idx && jr_val && J > 0), "joints requested without a regressor");
+  P2M_CHECK_ARG(V0 > 0 && nv > 0, "empty shape");
+  if (B <= 0) return P2M_OK;
+  const long tot = (long)B * nv + (joints ? (long)B * J : 0);
+  hipLaunchKernelGGL(k_mesh_epilogue, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, cam_mesh, V0, perm, nv,
+                     scale, jr_ptr, jr_idx, jr_val, J, mesh, joints, B);
+  return check_launch("mesh_epilogue");
+}
+
+static long loss_nparts(int B, int nv, int F, int J) {
+  const long nb_face = cdiv((long)B * F, 256), nb_vert = cdiv((long)B * nv, 256), nb_pose = cdiv((long)B * J, 256);
   long npart = nb_face > nb_vert ? nb_face : nb_vert;
-  if (nb_pose > npart) npart = nb_pose;
-  return (long)B * F * 9 + (long)B * J * 3 + 4 * npart;    // floats
+  return nb_pose > npart ? nb_pose : npart;
+}
+
+extern "C" int64_t p2m_mesh_loss_workspace(int32_t B, int32_t nv, int32_t F, int32_t J) {
+  return (long)B * F * 9 + (long)B * J * 3 + 4 * loss_nparts(B, nv, F, J);    // floats
 }
 
 extern "C" int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_t nv, const float* gt_mesh,
                              const float* valid_mesh, const int32_t* faces, int32_t F, const int32_t* vf_ptr,
-                             const int32_t* vf_idx, const float* jreg, int32_t J, const float* gt_pose,
-                             const float* valid_pose, float w_vertex, float w_normal, float w_edge, float w_joint,
-                             float* workspace, float* losses, float* grad_cam, int32_t B, void* stream) {
-  P2M_CHECK_ARG(cam_mesh && perm && gt_mesh && faces && vf_ptr && vf_idx && jreg && gt_pose && workspace && losses,
+                             const int32_t* vf_idx, const int32_t* jr_ptr, const int32_t* jr_idx, const float* jr_val,
+                             const int32_t* vj_ptr, const int32_t* vj_idx, const float* vj_val, int32_t J,
+                             const float* gt_pose, const float* valid_pose, float w_vertex, float w_normal,
+                             float w_edge, float w_joint, float* workspace, float* losses, float* grad_cam, int32_t B,
+                             void* stream) {
+  P2M_CHECK_ARG(cam_mesh && perm && gt_mesh && faces && vf_ptr && vf_idx && gt_pose && workspace && losses,
                 "null pointer");
+  P2M_CHECK_ARG(jr_ptr && jr_idx && jr_val && vj_ptr && vj_idx && vj_val, "null joint-regressor CSR/CSC");
   P2M_CHECK_ARG(B > 0 && V0 > 0 && nv > 0 && F > 0 && J > 0, "empty shape");
   LossArgs a;
   a.cam = cam_mesh; a.perm = perm; a.gt_mesh = gt_mesh; a.valid_mesh = valid_mesh; a.faces = faces;
-  a.vf_ptr = vf_ptr; a.vf_idx = vf_idx; a.jreg = jreg; a.gt_pose = gt_pose; a.valid_pose = valid_pose;
+  a.vf_ptr = vf_ptr; a.vf_idx = vf_idx; a.gt_pose = gt_pose; a.valid_pose = valid_pose;
+  a.jr_ptr = jr_ptr; a.jr_idx = jr_idx; a.jr_val = jr_val; a.vj_ptr = vj_ptr; a.vj_idx = vj_idx; a.vj_val = vj_val;
   a.B = B; a.V0 = V0; a.nv = nv; a.F = F; a.J = J;
-  const int nb_face = cdiv((long)B * F, 256), nb_vert = cdiv((long)B * nv, 256), nb_pose = B * J;
-  a.npart = nb_face > nb_vert ? nb_face : nb_vert;
-  if (nb_pose > a.npart) a.npart = nb_pose;
+  const int nb_face = cdiv((long)B * F, 256), nb_vert = cdiv((long)B * nv, 256), nb_pose = cdiv((long)B * J, 256);
+  a.npart = (int)loss_nparts(B, nv, F, J);
   a.face_grad = workspace;
   a.pose_sign = workspace + (long)B * F * 9;
   a.partial = a.pose_sign + (long)B * J * 3;

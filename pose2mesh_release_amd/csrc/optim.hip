@@ -1,4 +1,4 @@
-// Fused Adam over one flat fp32 parameter buffer (all 76 M parameters in a single launch).
+// Fused Adam / RMSprop over one flat fp32 parameter buffer (all 76 M parameters in a single launch).
 // Reference: torch.optim.Adam(model.parameters(), lr) built at lib/funcs_utils.py:92-96 and stepped at
 // lib/core/base.py:148 (defaults betas=(0.9,0.999), eps=1e-8, weight_decay=0, amsgrad=False).
 // Pure streaming: 16 B read (p,g,m,v) + 12 B written per parameter -> HBM-bound.
@@ -40,9 +40,50 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
   }
 }
 
+// torch.optim.RMSprop(params, lr) as the reference's yaml recipes build it (lib/funcs_utils.py:87-91: defaults
+// alpha = 0.99, eps = 1e-8, weight_decay = 0, momentum = 0, centered = False):
+//   v = alpha v + (1 - alpha) g^2 ;  p -= lr * g / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void k_rmsprop(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ v, long n4, long n, float lr, float alpha,
+                                                  float eps, float grad_scale) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    float4 G = reinterpret_cast<const float4*>(g)[i];
+    float4 V = reinterpret_cast<float4*>(v)[i];
+    float* pp = reinterpret_cast<float*>(&P);
+    float* gg = reinterpret_cast<float*>(&G);
+    float* vv = reinterpret_cast<float*>(&V);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float gr = gg[k] * grad_scale;
+      vv[k] = alpha * vv[k] + (1.f - alpha) * gr * gr;
+      pp[k] -= lr * (gr / (sqrtf(vv[k]) + eps));
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(v)[i] = V;
+  } else if (i == n4) {
+    for (long j = n4 * 4; j < n; j++) {
+      const float gr = g[j] * grad_scale;
+      v[j] = alpha * v[j] + (1.f - alpha) * gr * gr;
+      p[j] -= lr * (gr / (sqrtf(v[j]) + eps));
+    }
+  }
+}
+
 }  // namespace p2m
 
 using namespace p2m;
+
+extern "C" int p2m_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n, float lr, float alpha,
+                                float eps, float grad_scale, void* stream) {
+  P2M_CHECK_ARG(param && grad && square_avg && n > 0, "null pointer or empty buffer");
+  P2M_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)square_avg) % 16 == 0, "buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_rmsprop, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, square_avg,
+                     n4, (long)n, lr, alpha, eps, grad_scale);
+  return check_launch("rmsprop_step");
+}
 
 extern "C" int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,

@@ -72,10 +72,26 @@ def get_loss(faces):
 # fused HIP path: the four mesh-side losses of the train step + their gradient in one C-ABI call
 # ---------------------------------------------------------------------------------------------
 import ctypes as _ct
+import threading as _threading
 
 import numpy as _np
 
 from . import _lib as _libmod
+
+
+def _mask(v, B, n, name):
+    """The reference's masks are [B, n, 1] (data/*/dataset.py, consumed at lib/core/base.py:125); [B], [B,1], [B,1,1]
+    and [B, n] broadcast the same way inside CoordLoss (loss.py:19).  Returns a contiguous [B, n] fp32 tensor."""
+    if v is None:
+        return None
+    if v.dim() == 1:
+        v = v.view(B, 1, 1)
+    elif v.dim() == 2:
+        v = v.unsqueeze(-1)
+    if v.dim() != 3 or v.shape[0] != B or v.shape[1] not in (1, n) or v.shape[2] != 1:
+        raise ValueError(f"{name}: expected a [B], [B,1,1] or [B,{n},1] mask, got {tuple(v.shape)} "
+                         f"(per-coordinate masks are not used by the reference and not supported)")
+    return v.expand(B, n, 1).reshape(B, n).contiguous().float()
 
 
 class _MeshLossFn(torch.autograd.Function):
@@ -83,6 +99,8 @@ class _MeshLossFn(torch.autograd.Function):
     def forward(ctx, cam_mesh, mod, gt_mesh, valid_mesh, gt_pose, valid_pose):
         B, V0, _ = cam_mesh.shape
         dev = cam_mesh.device
+        if not cam_mesh.is_cuda:
+            raise _libmod.P2MError("FusedMeshLoss (HIP) needs GPU tensors; use get_loss(faces) for stock torch modules")
         t = mod._tensors(dev)
         cam = cam_mesh.contiguous().float()
         need_grad = ctx.needs_input_grad[0]
@@ -93,14 +111,15 @@ class _MeshLossFn(torch.autograd.Function):
 
         def p(x):
             return None if x is None else _ct.c_void_p(x.data_ptr())
-
-        def flat(v):
-            return None if v is None else v.reshape(B).contiguous().float()
-        vm, vp = flat(valid_mesh), flat(valid_pose)
+        vm, vp = _mask(valid_mesh, B, mod.nv, "valid_mesh"), _mask(valid_pose, B, mod.J, "valid_pose")
+        gm, gp = gt_mesh.contiguous().float(), gt_pose.contiguous().float()
+        if tuple(gm.shape) != (B, mod.nv, 3) or tuple(gp.shape) != (B, mod.J, 3):
+            raise ValueError(f"gt_mesh / gt_pose must be [B,{mod.nv},3] / [B,{mod.J},3]")
         with torch.cuda.device(dev):
             _libmod.check(_libmod.hip().p2m_mesh_loss(
-                p(cam), V0, p(t["perm"]), mod.nv, p(gt_mesh.contiguous().float()), p(vm), p(t["faces"]), mod.nf,
-                p(t["vf_ptr"]), p(t["vf_idx"]), p(t["jreg"]), mod.J, p(gt_pose.contiguous().float()), p(vp),
+                p(cam), V0, p(t["perm"]), mod.nv, p(gm), p(vm), p(t["faces"]), mod.nf,
+                p(t["vf_ptr"]), p(t["vf_idx"]), p(t["jr_ptr"]), p(t["jr_idx"]), p(t["jr_val"]), p(t["vj_ptr"]),
+                p(t["vj_idx"]), p(t["vj_val"]), mod.J, p(gp), p(vp),
                 mod.w_vertex, mod.w_normal, mod.w_edge, mod.w_joint, p(ws), p(losses), p(grad), B,
                 _ct.c_void_p(torch.cuda.current_stream().cuda_stream)), "p2m_mesh_loss")
         ctx.grad = grad
@@ -112,12 +131,26 @@ class _MeshLossFn(torch.autograd.Function):
         return ctx.grad * g_total, None, None, None, None, None
 
 
+def _regressor_tables(jr, nv):
+    """CSR (by joint) and CSC (by vertex) of a dense [J, nv] joint regressor."""
+    import scipy.sparse as sp
+    csr = sp.csr_matrix(jr)
+    csr.sort_indices()
+    csc = sp.csc_matrix(jr)
+    csc.sort_indices()
+    i32, f32 = _np.int32, _np.float32
+    return {"jr_ptr": csr.indptr.astype(i32), "jr_idx": csr.indices.astype(i32), "jr_val": csr.data.astype(f32),
+            "vj_ptr": csc.indptr.astype(i32), "vj_idx": csc.indices.astype(i32), "vj_val": csc.data.astype(f32)}
+
+
 class FusedMeshLoss(nn.Module):
     """loss = CoordLoss(pred_mesh, gt_mesh, valid) + w_normal*NormalVectorLoss + w_edge*EdgeLengthLoss
             + w_joint*CoordLoss(J_regressor @ (pred_mesh*1000), gt_pose, valid)
     with pred_mesh = cam_mesh[:, graph_perm_reverse[:nv]] -- i.e. lib/core/base.py:130-143 minus the PoseNet
     term -- computed (value and gradient) by p2m_mesh_loss.  Returns (total, components[4]).
-    Set w_edge=0 before cfg.TRAIN.edge_loss_start, as the reference's epoch switch does."""
+    Masks take the reference's shapes ([B, nv, 1] / [B, J, 1]) or any per-sample broadcast of them.
+    Set w_edge=0 before cfg.TRAIN.edge_loss_start, as the reference's epoch switch does (a zero weight also switches
+    the term's gradient off, so degenerate edges cannot inject NaNs)."""
 
     def __init__(self, faces, perm_reverse, joint_regressor, w_normal=1e-1, w_edge=20.0, w_joint=1e-3, w_vertex=1.0):
         super().__init__()
@@ -135,18 +168,61 @@ class FusedMeshLoss(nn.Module):
             "faces": _np.ascontiguousarray(faces, dtype=_np.int32),
             "vf_ptr": _np.concatenate([[0], _np.cumsum(_np.bincount(vert, minlength=self.nv))]).astype(_np.int32),
             "vf_idx": _np.ascontiguousarray(corner[order], dtype=_np.int32),
-            "jreg": _np.ascontiguousarray(jr),
         }
+        self._host.update(_regressor_tables(jr, self.nv))
         self.w_vertex, self.w_normal, self.w_edge, self.w_joint = float(w_vertex), float(w_normal), float(w_edge), \
             float(w_joint)
         self._dev = {}
+        self._lock = _threading.Lock()
 
     def _tensors(self, device):
         t = self._dev.get(device)
         if t is None:
-            t = {k: torch.from_numpy(v).to(device) for k, v in self._host.items()}
-            self._dev[device] = t
+            with self._lock:
+                t = self._dev.get(device)
+                if t is None:
+                    t = {k: torch.from_numpy(_np.ascontiguousarray(v)).to(device) for k, v in self._host.items()}
+                    self._dev[device] = t
         return t
 
     def forward(self, cam_mesh, gt_mesh, gt_pose, valid_mesh=None, valid_pose=None):
         return _MeshLossFn.apply(cam_mesh, self, gt_mesh, valid_mesh, gt_pose, valid_pose)
+
+
+class MeshEpilogue(nn.Module):
+    """The Tester's / demo's post-model steps in one launch (lib/core/base.py:200-204, demo/run.py:169-171):
+        mesh   = cam_mesh[:, graph_perm_reverse[:nv], :] * scale        (scale = 1000 in the Tester, 1 in the demo)
+        joints = J_regressor @ mesh                                      (sparse: CSR mat-vec)
+    forward(cam_mesh [B, V0, 3]) -> (mesh [B, nv, 3], joints [B, J, 3]).  Inference only (no autograd)."""
+
+    def __init__(self, perm_reverse, nv, joint_regressor, scale=1000.0):
+        super().__init__()
+        self.nv, self.scale = int(nv), float(scale)
+        jr = _np.asarray(joint_regressor, dtype=_np.float32)
+        self.J = int(jr.shape[0])
+        assert jr.shape[1] == self.nv
+        self._host = {"perm": _np.ascontiguousarray(_np.asarray(perm_reverse)[:self.nv], dtype=_np.int32)}
+        self._host.update(_regressor_tables(jr, self.nv))
+        self._dev = {}
+        self._lock = _threading.Lock()
+
+    _tensors = FusedMeshLoss._tensors
+
+    @torch.no_grad()
+    def forward(self, cam_mesh):
+        if not cam_mesh.is_cuda:
+            raise _libmod.P2MError("MeshEpilogue (HIP) needs GPU tensors")
+        B, V0, _ = cam_mesh.shape
+        dev = cam_mesh.device
+        t = self._tensors(dev)
+        cam = cam_mesh.contiguous().float()
+        mesh = torch.empty((B, self.nv, 3), device=dev, dtype=torch.float32)
+        joints = torch.empty((B, self.J, 3), device=dev, dtype=torch.float32)
+
+        def p(x):
+            return _ct.c_void_p(x.data_ptr())
+        with torch.cuda.device(dev):
+            _libmod.check(_libmod.hip().p2m_mesh_epilogue(
+                p(cam), V0, p(t["perm"]), self.nv, self.scale, p(t["jr_ptr"]), p(t["jr_idx"]), p(t["jr_val"]), self.J,
+                p(mesh), p(joints), B, _ct.c_void_p(torch.cuda.current_stream().cuda_stream)), "p2m_mesh_epilogue")
+        return mesh, joints

@@ -226,6 +226,13 @@ if GEMM_ARITH not in ("f32", "bf16x3"):
     raise ValueError(f"P2M_GEMM_ARITH must be f32 or bf16x3, not {GEMM_ARITH!r}")
 
 
+def gemm_kernel_name():
+    """Name prefix of the plane-contraction kernel the current knobs select (rocprof kernel names start with it)."""
+    if GEMM_ARITH != "bf16x3":
+        return "k_gemm_planes<"
+    return "k_gemm_planes_ws" if _os.environ.get("P2M_GEMM_WS", "2") != "0" else "k_gemm_planes_bx"
+
+
 def arith_code():
     """P2M_ARITH_* value of include/p2m.h for the current GEMM_ARITH."""
     return 1 if GEMM_ARITH == "bf16x3" else 0

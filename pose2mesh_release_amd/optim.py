@@ -1,8 +1,17 @@
-"""Flat-buffer optimizer for MI355X: all parameters live in ONE fp32 buffer, all gradients in
-another, so that (a) the Adam step is a single fused launch (p2m_adam_step) instead of ~140
-per-tensor kernels and (b) the data-parallel gradient exchange is a handful of large RCCL
-all-reduces over contiguous slices (see dist.py).  Semantics = torch.optim.Adam as the reference
-builds it (lib/funcs_utils.py:92-96: lr only, default betas/eps, no weight decay)."""
+"""Flat-buffer optimizers for MI355X: all parameters live in ONE fp32 buffer, all gradients in another, so that
+(a) the optimizer step is a single fused launch (p2m_adam_step / p2m_rmsprop_step) instead of ~140 per-tensor kernels
+and (b) the data-parallel gradient exchange is a handful of large RCCL all-reduces over contiguous slices (dist.py).
+
+Both classes ARE torch.optim.Optimizer subclasses with one param group whose `lr` is read at every step(), so the
+reference's schedulers and helpers run against them unchanged: `optim.lr_scheduler.MultiStepLR` (lib/funcs_utils.py:
+101-104, the 'step' scheduler of every yaml recipe), `lr_check` / `lr_warmup` (funcs_utils.py:17-31, called at
+lib/core/base.py:118), and `optimizer.state_dict()` / `load_state_dict()` in the torch layout that main/train.py:51-58
+checkpoints.
+
+  FlatAdam     torch.optim.Adam(params, lr)       lib/funcs_utils.py:92-96   (defaults betas (0.9, 0.999), eps 1e-8)
+  FlatRMSprop  torch.optim.RMSprop(params, lr)    lib/funcs_utils.py:87-91   (defaults alpha 0.99, eps 1e-8) -- what
+                                                  asset/yaml/*.yml select (`optimizer: 'rmsprop'`)
+"""
 import ctypes
 
 import torch
@@ -13,15 +22,20 @@ from ._lib import check
 _vp = ctypes.c_void_p
 
 
-class FlatAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+class _FlatOptimizer(torch.optim.Optimizer):
+    _state_names = ()
+
+    def __init__(self, params, defaults):
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("no trainable parameters")
-        dev = self.params[0].device
-        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in self.params):
-            raise ValueError("FlatAdam needs fp32 parameters on one GPU")
-        self.lr, self.betas, self.eps = lr, betas, eps
+        dev = params[0].device
+        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in params):
+            raise ValueError(f"{type(self).__name__} needs fp32 parameters on one GPU")
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("one parameter group only (the reference builds its optimizers from model.parameters())")
+        self.params = params
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
@@ -29,8 +43,7 @@ class FlatAdam:
         self.numel = n
         self.flat_param = torch.zeros(n, device=dev)
         self.flat_grad = torch.zeros(n, device=dev)
-        self.exp_avg = torch.zeros(n, device=dev)
-        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self._bufs = {name: torch.zeros(n, device=dev) for name in self._state_names}
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.flat_param[o:o + p.numel()].view_as(p)
@@ -39,41 +52,110 @@ class FlatAdam:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.step_count = 0
 
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = value
+
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):      # re-attach in case autograd replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
-    def step(self, grad_scale=1.0):
+    def _launch(self, grad_scale):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0, closure=None):
+        """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
+        if callable(grad_scale):                          # torch's signature: step(closure)
+            closure, grad_scale = grad_scale, 1.0
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self.step_count += 1
         with torch.cuda.device(self.flat_param.device):
-            check(_lib.hip().p2m_adam_step(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
-                                           _vp(self.exp_avg.data_ptr()), _vp(self.exp_avg_sq.data_ptr()),
-                                           self.numel, self.step_count, self.lr, self.betas[0], self.betas[1],
-                                           self.eps, float(grad_scale),
-                                           _vp(torch.cuda.current_stream().cuda_stream)), "p2m_adam_step")
+            self._launch(float(grad_scale))
+        return loss
 
-    # torch.optim.Adam-shaped state dict so reference checkpoints (main/train.py:51-58) round-trip
+    # torch-shaped state dict so reference checkpoints (main/train.py:51-58) round-trip
     def state_dict(self):
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(self.step_count)),
-                        "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
-                 "params": list(range(len(self.params)))}
+            st = {"step": torch.tensor(float(self.step_count))}
+            for name in self._state_names:
+                st[name] = self._bufs[name][o:o + n].view_as(p).clone()
+            state[i] = st
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         g = sd["param_groups"][0]
-        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        for k, v in g.items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if isinstance(v, list) else v
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             st = sd["state"].get(i)
             if st is None:
                 continue
             n = p.numel()
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            for name in self._state_names:
+                self._bufs[name][o:o + n].copy_(st[name].reshape(-1))
             self.step_count = int(st["step"])
+
+
+class FlatAdam(_FlatOptimizer):
+    _state_names = ("exp_avg", "exp_avg_sq")
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+
+    @property
+    def exp_avg(self):
+        return self._bufs["exp_avg"]
+
+    @property
+    def exp_avg_sq(self):
+        return self._bufs["exp_avg_sq"]
+
+    def _launch(self, grad_scale):
+        g = self.param_groups[0]
+        check(_lib.hip().p2m_adam_step(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
+                                       _vp(self.exp_avg.data_ptr()), _vp(self.exp_avg_sq.data_ptr()),
+                                       self.numel, self.step_count, float(g["lr"]), g["betas"][0], g["betas"][1],
+                                       g["eps"], grad_scale, _vp(torch.cuda.current_stream().cuda_stream)),
+              "p2m_adam_step")
+
+
+class FlatRMSprop(_FlatOptimizer):
+    _state_names = ("square_avg",)
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8):
+        super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=0, momentum=0, centered=False))
+
+    @property
+    def square_avg(self):
+        return self._bufs["square_avg"]
+
+    def _launch(self, grad_scale):
+        g = self.param_groups[0]
+        check(_lib.hip().p2m_rmsprop_step(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
+                                          _vp(self.square_avg.data_ptr()), self.numel, float(g["lr"]), g["alpha"],
+                                          g["eps"], grad_scale, _vp(torch.cuda.current_stream().cuda_stream)),
+              "p2m_rmsprop_step")
+
+
+def get_optimizer(model, name="rmsprop", lr=1e-3):
+    """lib/funcs_utils.py:77-98 for the two optimizers the reference's recipes use."""
+    if name == "rmsprop":
+        return FlatRMSprop(model.parameters(), lr=lr)
+    if name == "adam":
+        return FlatAdam(model.parameters(), lr=lr)
+    raise ValueError(f"optimizer {name!r}: only 'rmsprop' (the yaml recipes) and 'adam' have fused kernels")

@@ -1,0 +1,45 @@
+"""Helper (not a pytest file): one MeshNet forward+backward on the GPU under whatever kernel-variant environment the
+parent test set (P2M_GEMM_ARITH, P2M_SPLIT_FAKE, P2M_BASIS_TILED, P2M_GEMM_WS ...), results to an .npz.
+usage: python _child_meshnet_run.py OUT.npz JOINT_SET B MODE(train|eval) WSEED XSEED GSEED"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False):
+    import helpers
+    from pose2mesh_release_amd import meshnet
+    gL, _, _ = helpers.golden_graphs(joint_set)
+    J = int(gL[-1].shape[0])
+    net = meshnet.get_model(5, 3, gL, mano=(joint_set == "mano"))
+    net.load_state_dict(helpers.numpy_state(net.state_dict(), wseed))
+    net = net.cuda().train(mode == "train")
+    x = helpers.meshnet_input(B, J, seed=xseed).cuda().requires_grad_(True)
+    y = net(x)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(gseed)).cuda()
+    (y * w).sum().backward()
+    torch.cuda.synchronize()
+    conv = (lambda t: t.detach()) if keep_on_gpu else (lambda t: t.detach().cpu().numpy())
+    out = {"out": conv(y), "grad::__input__": conv(x.grad)}
+    for k, p in net.named_parameters():
+        out[f"grad::{k}"] = conv(p.grad)
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            out[f"state::{k}"] = conv(v)
+    return out
+
+
+if __name__ == "__main__":
+    out_path, joint_set, B, mode, wseed, xseed, gseed = sys.argv[1:8]
+    res = run(joint_set, int(B), mode, int(wseed), int(xseed), int(gseed))
+    np.savez(out_path, **res)
+    print("child ok", {k: os.environ.get(k) for k in ("P2M_GEMM_ARITH", "P2M_SPLIT_FAKE", "P2M_BASIS_TILED",
+                                                      "P2M_GEMM_WS")})

@@ -1,0 +1,282 @@
+"""-m gpu: parity at the quantities and sizes that matter ("next round" 1):
+  (a) FULL-tensor gradients of every parameter and of the input against the CPU oracle on fresh inputs;
+  (b) the bench's own scale against the oracle where the oracle still finishes in seconds
+      (MANO B=256 train, SMPL-like B=32 train);
+  (c) BASELINE configs[2] itself (SMPL-like coco graph, B=256, train): the default kernel set against an INDEPENDENT
+      kernel set (native f32 MFMA, no fake-vertex split, row-per-wave basis kernel, 4-wave GEMM) in a child process,
+      plus eval slices of the same batch against the oracle;
+  (d) three optimizer steps of the bench's TrainStep against oracle + torch.optim.Adam;
+  (e) train-mode bitwise repeatability.
+All through the C ABI on the default (bf16x3) arithmetic.  Achieved maxima are written to
+gpurun_out/parity_maxima.json (DESIGN.md section 5 quotes them)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import meshnet_oracle as mo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+VERTEX_TOL = 1e-4
+ORACLE_THREADS = 16          # torch's CPU sparse path collapses when a 256-thread host is used fully
+
+
+def _record(key, value):
+    path = os.path.join(ROOT, "gpurun_out", "parity_maxima.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        d = {}
+    d[key] = value
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
+def _zero_grad_bias(k, names):
+    """conv bias in front of a train-mode BatchNorm: the true gradient is exactly 0 (round-off only)."""
+    return k.startswith("cl.") and k.endswith("bias") and f"bn.{k.split('.')[1]}.weight" in names
+
+
+def _compare_grads(hip, ref, tol, tag, train):
+    """hip/ref: dict name -> tensor/array.  Per-tensor rel-L2; returns the maxima."""
+    names = set(ref.keys())
+    worst, worst_k = 0.0, None
+    per = {}
+    for k, r in ref.items():
+        h = hip[k]
+        h = torch.as_tensor(h).detach().cpu()
+        r = torch.as_tensor(r).detach().cpu()
+        if train and _zero_grad_bias(k, names):
+            wk = k.replace("bias", "weight")
+            assert float(h.norm()) <= 1e-3 * max(1.0, float(torch.as_tensor(hip[wk]).norm())), k
+            continue
+        e = helpers.rel_l2(h, r)
+        per[k] = e
+        if e > worst:
+            worst, worst_k = e, k
+    _record(tag, {"max_rel_l2": worst, "at": worst_k})
+    bad = {k: v for k, v in per.items() if v > tol}
+    assert not bad, f"{tag}: gradient rel-L2 above {tol:g}: {bad}"
+    return worst
+
+
+def _hip_run(joint_set, B, mode, wseed, xseed, gseed):
+    sys.path.insert(0, HERE)
+    import _child_meshnet_run as child
+    return child.run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=True)
+
+
+def _oracle(joint_set, B, mode, wseed, xseed, gseed):
+    torch.set_num_threads(ORACLE_THREADS)
+    gL, _, _ = helpers.golden_graphs(joint_set)
+    J = int(gL[-1].shape[0])
+    mano = joint_set == "mano"
+    sd = helpers.numpy_state(mo.init_state(J, mo.trim_graph_list(gL), mano), wseed)
+    x = helpers.meshnet_input(B, J, seed=xseed)
+    return helpers.oracle_run(sd, helpers.oracle_graphs(gL), x, mano, mode == "train", grad_seed=gseed)
+
+
+# Bounds = 3x the maxima measured on MI355X (gpurun_out/parity_maxima.json of the run that set them, quoted in
+# DESIGN.md section 5).  A ReLU whose pre-activation is within rounding of 0 may flip between two fp32 evaluation
+# orders; that moves single elements, which is why the bound is on the per-tensor rel-L2 and not element-wise.
+GRAD_TOL = {"mano": 1e-3, "human36": 1e-3, "coco": 1e-3}
+
+
+@pytest.mark.parametrize("joint_set,B", [("mano", 5), ("human36", 3), ("coco", 2)])
+def test_full_gradients_vs_oracle_train(hip_libs, joint_set, B):
+    """(a) every parameter gradient and the input gradient, full tensors, train mode, fresh inputs."""
+    hip = _hip_run(joint_set, B, "train", 21, 99, 5)
+    ref_out, ref_g, ref_sd = _oracle(joint_set, B, "train", 21, 99, 5)
+    err = helpers.max_vertex_l2(hip["out"].cpu(), ref_out)
+    _record(f"a_{joint_set}_B{B}_vertex_l2", err)
+    assert err <= VERTEX_TOL
+    _compare_grads({k[6:]: v for k, v in hip.items() if k.startswith("grad::")}, ref_g, GRAD_TOL[joint_set],
+                   f"a_{joint_set}_B{B}_grads", True)
+    for k, v in ref_sd.items():
+        if "running" in k:
+            assert (hip[f"state::{k}"].cpu() - v).abs().max() < 1e-4, k
+
+
+def test_full_gradients_vs_oracle_eval(hip_libs):
+    """(a') eval mode (running statistics): gradients flow through BN as a fixed affine map."""
+    hip = _hip_run("mano", 5, "eval", 22, 98, 6)
+    ref_out, ref_g, _ = _oracle("mano", 5, "eval", 22, 98, 6)
+    assert helpers.max_vertex_l2(hip["out"].cpu(), ref_out) <= VERTEX_TOL
+    _compare_grads({k[6:]: v for k, v in hip.items() if k.startswith("grad::")}, ref_g, 1e-3, "a_mano_eval_grads", False)
+
+
+@pytest.mark.parametrize("joint_set,B,tol", [("mano", 256, 2e-3), ("human36", 32, 2e-3)])
+def test_bench_scale_vs_oracle_train(hip_libs, joint_set, B, tol):
+    """(b) MANO B=256 (the MANO config's row-set tiling, 256 x tiles-per-sample) and SMPL-like B=32 (BASELINE.md
+    section 2: 8.8 GB on the CPU) forward + backward against the oracle."""
+    hip = _hip_run(joint_set, B, "train", 31, 77, 8)
+    ref_out, ref_g, _ = _oracle(joint_set, B, "train", 31, 77, 8)
+    err = helpers.max_vertex_l2(hip["out"].cpu(), ref_out)
+    _record(f"b_{joint_set}_B{B}_vertex_l2", err)
+    assert err <= VERTEX_TOL
+    _compare_grads({k[6:]: v for k, v in hip.items() if k.startswith("grad::")}, ref_g, tol,
+                   f"b_{joint_set}_B{B}_grads", True)
+
+
+def test_configs2_default_vs_independent_kernel_set(hip_libs, tmp_path):
+    """(c) BASELINE configs[2]: SMPL-like coco graph, B=256, train.  The CPU oracle cannot run this size, so the
+    default kernel set (bf16x3 contraction on the BF16 pipe, fake-vertex split, LDS-tiled basis, wave-specialised GEMM)
+    is compared with an independent one (native f32 MFMA, unsplit rows, row-per-wave gather, 4-wave GEMM) that the
+    small-size tests pin to the oracle separately; plus 4 eval samples of the SAME batch against the oracle."""
+    out = str(tmp_path / "indep.npz")
+    env = dict(os.environ, P2M_GEMM_ARITH="f32", P2M_SPLIT_FAKE="0", P2M_BASIS_TILED="0", P2M_GEMM_WS="0",
+               P2M_TN_WS="0")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, "coco", "256", "train",
+                        "41", "55", "9"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ind = np.load(out)
+    hip = _hip_run("coco", 256, "train", 41, 55, 9)
+    err = helpers.max_vertex_l2(hip["out"].cpu(), ind["out"])
+    _record("c_coco_B256_vertex_l2_default_vs_independent", err)
+    assert err <= 2e-5
+    grads_h = {k[6:]: v for k, v in hip.items() if k.startswith("grad::")}
+    grads_i = {k[6:]: ind[k] for k in ind.files if k.startswith("grad::")}
+    _compare_grads(grads_h, grads_i, 1e-4, "c_coco_B256_grads_default_vs_independent", True)
+    for k in ind.files:
+        if k.startswith("state::"):
+            assert np.abs(hip[k].cpu().numpy() - ind[k]).max() < 1e-5, k
+    del hip, grads_h
+    torch.cuda.empty_cache()
+    # eval slices of the same batch vs the oracle (eval-mode samples are independent)
+    from pose2mesh_release_amd import meshnet
+    gL, _, _ = helpers.golden_graphs("coco")
+    net = meshnet.get_model(5, 3, gL, mano=False)
+    sd = helpers.numpy_state(net.state_dict(), 41)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = helpers.meshnet_input(256, 19, seed=55)
+    with torch.no_grad():
+        big = net(x.cuda())
+    idx = [0, 85, 170, 255]
+    torch.set_num_threads(ORACLE_THREADS)
+    ref, _, _ = helpers.oracle_run(sd, helpers.oracle_graphs(gL), x[idx], False, False)
+    err = helpers.max_vertex_l2(big[idx].cpu(), ref)
+    _record("c_coco_B256_eval_slices_vertex_l2", err)
+    assert err <= VERTEX_TOL
+
+
+def test_train_mode_is_bitwise_repeatable(hip_libs):
+    """(e) BN partial merge + side-stream dW + row-set split: two identical fwd+bwd give identical bits."""
+    a = _hip_run("human36", 4, "train", 7, 8, 9)
+    b = _hip_run("human36", 4, "train", 7, 8, 9)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_three_adam_steps_vs_oracle(hip_libs):
+    """(d) bench.TrainStep (FlatPose2Mesh fwd, fused epilogue + losses, bwd, FlatAdam) x 3 steps, MANO B=8, dropout
+    off, against oracle forward + oracle losses + torch.optim.Adam on the CPU: parameters <= 1e-5."""
+    import bench
+    import loss_oracle as lo
+    torch.set_num_threads(ORACLE_THREADS)
+    B = 8
+    step = bench.TrainStep(torch.device("cuda", 0), B, "mano", 1)
+    for m in step.model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in step.model.state_dict().items()}
+    names = [k for k, _ in step.model.named_parameters()]
+    params = [sd[k].requires_grad_(True) for k in names]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    glt = helpers.oracle_graphs(step.graph_L)
+    pose2d, gt_mesh = step.pose2d.cpu(), step.gt_mesh.cpu()
+    gt_reg, gt_lift, one = step.gt_reg.cpu(), step.gt_lift.cpu(), step.one.cpu()
+    Jreg = step.Jreg.cpu()
+    perm_rev = step.perm_rev
+    hip_losses, ref_losses = [], []
+    for _ in range(3):
+        hip_losses.append(float(step()))
+        opt.zero_grad()
+        mesh, lift = mo.flat_forward(sd, glt, pose2d, True, True)
+        loss, _ = lo.train_losses(mesh, lift, perm_rev, step.nv, step.faces, Jreg, gt_mesh, gt_reg, gt_lift, one, one,
+                                  one, with_edge=True)
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+    for a, b in zip(hip_losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (hip_losses, ref_losses)
+    worst = 0.0
+    got = dict(step.model.named_parameters())
+    for k in names:
+        d = float((got[k].detach().cpu() - sd[k].detach()).abs().max())
+        worst = max(worst, d)
+    _record("d_three_adam_steps_max_param_diff", worst)
+    assert worst <= 1e-5, worst
+    for k, v in step.model.state_dict().items():
+        if "running" in k:
+            assert (v.cpu() - sd[k]).abs().max() < 1e-4 * max(1.0, float(sd[k].abs().max())), k
+
+
+@pytest.mark.parametrize("joint_set", ["mano", "coco"])
+@pytest.mark.parametrize("with_edge", [True, False])
+def test_fused_mesh_loss_vs_reference_golden(hip_libs, joint_set, with_edge):
+    """p2m_mesh_loss (perm-reverse gather + J-regression + 4 losses + gradient) against fixtures
+    made by the REAL lib/core/loss.py driven as lib/core/base.py:130-143 does; masks in the reference's shapes."""
+    from pose2mesh_release_amd import loss as L
+    z = helpers.golden(f"loss_{joint_set}.npz")
+    c = helpers.loss_case(joint_set)
+    tag = "edge" if with_edge else "noedge"
+    fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy(), w_normal=1e-1,
+                            w_edge=20.0 if with_edge else 0.0, w_joint=1e-3)
+    cam = c["cam_mesh"].cuda().requires_grad_(True)
+    total, comp = fused(cam, c["gt_mesh"].cuda(), c["gt_reg3dpose"].cuda(), c["val_mesh"].cuda(),
+                        c["val_reg3dpose"].cuda())
+    total.backward()
+    want = z[f"{tag}_losses"]
+    for got, ref in zip(comp.tolist(), [want[0], want[1], want[2], want[3]]):
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (comp.tolist(), want)
+    e = helpers.rel_l2(cam.grad.cpu(), z[f"{tag}_grad_cam"])
+    _record(f"f_loss_{joint_set}_{tag}_grad_rel_l2", e)
+    assert e <= 1e-5
+    fake = np.setdiff1d(np.arange(c["V0"]), c["perm_reverse"][:c["nv"]])
+    assert float(cam.grad[:, torch.as_tensor(fake, device="cuda")].abs().max()) == 0.0
+    # mask shapes: [B], [B,1,1] give the same result as the reference's [B,nv,1] / [B,J,1]
+    vm, vr = c["val_mesh"][:, 0, 0].cuda(), c["val_reg3dpose"][:, 0, 0].cuda()
+    for shp in ((-1,), (-1, 1, 1)):
+        t2, c2 = fused(cam.detach(), c["gt_mesh"].cuda(), c["gt_reg3dpose"].cuda(), vm.view(*shp), vr.view(*shp))
+        assert torch.equal(c2, comp)
+    with pytest.raises(ValueError):
+        fused(cam.detach(), c["gt_mesh"].cuda(), c["gt_reg3dpose"].cuda(), torch.ones(c["B"], c["nv"], 3).cuda(), None)
+
+
+def test_disabled_edge_loss_cannot_inject_nan(hip_libs):
+    """w_edge = 0 with a zero-length predicted edge must give a finite gradient (the reference does not
+    evaluate the edge loss before cfg.TRAIN.edge_loss_start, lib/core/base.py:141-143)."""
+    from pose2mesh_release_amd import loss as L
+    c = helpers.loss_case("mano")
+    fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy(), w_edge=0.0)
+    cam = c["cam_mesh"].clone()
+    f0 = c["faces"][0]
+    pr = c["perm_reverse"]
+    cam[:, pr[f0[1]]] = cam[:, pr[f0[0]]]          # degenerate edge
+    cam = cam.cuda().requires_grad_(True)
+    total, _ = fused(cam, c["gt_mesh"].cuda(), c["gt_reg3dpose"].cuda(), None, None)
+    total.backward()
+    assert torch.isfinite(total) and torch.isfinite(cam.grad).all()
+
+
+@pytest.mark.parametrize("scale", [1000.0, 1.0])
+def test_mesh_epilogue_vs_oracle(hip_libs, scale):
+    """SURVEY 8(f1) for the Tester / demo: p2m_mesh_epilogue == lib/core/base.py:200-204 (x1000) / demo/run.py:169-171."""
+    import loss_oracle as lo
+    from pose2mesh_release_amd import loss as L
+    c = helpers.loss_case("coco", B=3)
+    epi = L.MeshEpilogue(c["perm_reverse"], c["nv"], c["J_regressor"].numpy(), scale=scale)
+    mesh, joints = epi(c["cam_mesh"].cuda())
+    rm, rj = lo.test_epilogue(c["cam_mesh"], c["perm_reverse"], c["nv"], c["J_regressor"])
+    if scale == 1.0:
+        rm, rj = rm / 1000, rj / 1000
+    assert (mesh.cpu() - rm).abs().max() <= 1e-6 * float(rm.abs().max())
+    assert (joints.cpu() - rj).abs().max() <= 1e-5 * float(rj.abs().max())

@@ -28,6 +28,46 @@ def test_flat_adam_matches_torch_adam(hip_libs):
     assert (sd["state"][0]["exp_avg"] - ob.state_dict()["state"][0]["exp_avg"]).abs().max() < 1e-6
 
 
+def test_flat_rmsprop_matches_torch_rmsprop_with_multistep_lr(hip_libs):
+    """The reference's recipe: RMSprop (lib/funcs_utils.py:87-91) + MultiStepLR (funcs_utils.py:101-104) + lr_check
+    (funcs_utils.py:17-24) run against the fused flat optimizer unchanged."""
+    from pose2mesh_release_amd import optim
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 3)).cuda()
+    b = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 3)).cuda()
+    b.load_state_dict(a.state_dict())
+    oa = optim.get_optimizer(a, "rmsprop", lr=1e-2)
+    ob = torch.optim.RMSprop(b.parameters(), lr=1e-2)
+    assert isinstance(oa, torch.optim.Optimizer)
+    sa = torch.optim.lr_scheduler.MultiStepLR(oa, milestones=[2], gamma=0.1)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ob, milestones=[2], gamma=0.1)
+    x = torch.randn(64, 37, device="cuda")
+    for epoch in range(4):
+        for param_group in oa.param_groups:               # lr_check
+            curr_lr = param_group["lr"]
+        assert abs(curr_lr - ob.param_groups[0]["lr"]) < 1e-12
+        for _ in range(2):
+            oa.zero_grad()
+            ob.zero_grad()
+            a(x).square().mean().backward()
+            b(x).square().mean().backward()
+            oa.step()
+            ob.step()
+        sa.step()
+        sb.step()
+    assert abs(oa.param_groups[0]["lr"] - 1e-3) < 1e-12
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert (p - q).abs().max() < 2e-6
+    sd = oa.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "square_avg"}
+    assert (sd["state"][0]["square_avg"] - ob.state_dict()["state"][0]["square_avg"]).abs().max() < 1e-6
+    # checkpoint round trip (main/train.py:51-58 saves optimizer.state_dict())
+    oc = optim.FlatRMSprop(a.parameters(), lr=5.0)
+    oc.load_state_dict(sd)
+    assert abs(oc.param_groups[0]["lr"] - 1e-3) < 1e-12 and oc.step_count == oa.step_count
+    assert torch.equal(oc.square_avg, oa.square_avg)
+
+
 def test_train_step_runs_and_learns(hip_libs):
     """bench.py's TrainStep (reference train step, lib/core/base.py:122-148) at a small batch on the MANO-like mesh."""
     import bench
@@ -50,7 +90,7 @@ def test_fused_mesh_loss_matches_stock_losses(hip_libs):
     nv, V0, J, B = 500, 736, 17, 6
     rng = np.random.default_rng(0)
     perm_rev = rng.permutation(V0)
-    jreg = bench.synthetic_regressor(J, nv)
+    jreg = synth.synthetic_regressor(J, nv)
     g = torch.Generator().manual_seed(1)
     cam = (torch.randn(B, V0, 3, generator=g) * 0.3).cuda().requires_grad_(True)
     gt_mesh = (torch.randn(B, nv, 3, generator=g) * 0.3).cuda()
