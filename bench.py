@@ -231,20 +231,21 @@ def cpu_baseline(joint_set, budget_s, edge_loss=True, batch=32, mode="train"):
 
 
 def _traffic_for(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC passes of this command (tools/rocprof_traffic.sh)."""
+    """HBM bytes per launch of a kernel family (all template instantiations whose name contains the prefix) from the
+    committed PMC passes of this command (tools/rocprof_traffic.sh -> profiles/traffic_latest.json)."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    best = None
+    tot, n = 0.0, 0
     for name, rec in t.get("kernels", {}).items():
         if kernel_prefix in name:
-            if best is None or rec.get("total_hbm_bytes", 0) > best[1].get("total_hbm_bytes", 0):
-                best = (name, rec)
-    if best is None:
+            tot += rec["total_hbm_bytes"]
+            n += rec["launches"]
+    if n == 0:
         return None, None
-    return best[1], t.get("source")
+    return {"hbm_bytes_per_launch": tot / n, "launches": n}, t.get("source")
 
 
 def main():

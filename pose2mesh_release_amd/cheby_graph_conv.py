@@ -11,26 +11,39 @@
 Differentiable w.r.t. x, cl.weight, cl.bias, bn.weight, bn.bias.  K = 3 is the native kernel path
 (every Pose2Mesh layer); K = 1, 2 reuse it with zero-padded weight planes; K > 3 is not implemented.
 """
+import threading
+
 import torch
 
 from . import ops
 from ._lib import P2MError
 
 _graph_cache = {}
+_graph_lock = threading.Lock()      # nn.DataParallel calls the op from one thread per GPU
 
 
 def _device_graph(L, device):
     if isinstance(L, ops.DeviceGraph):
         return L
-    key = (id(L), torch.device(device).index)
-    hit = _graph_cache.get(key)
-    if hit is not None and hit[0] is L:
-        return hit[1]
-    g = ops.DeviceGraph(L, device)
-    if len(_graph_cache) > 256:
-        _graph_cache.clear()
-    _graph_cache[key] = (L, g)      # holding L keeps id(L) unique
-    return g
+    dev = torch.device(device)
+    key = (id(L), dev.index if dev.index is not None else torch.cuda.current_device())
+    with _graph_lock:
+        hit = _graph_cache.get(key)
+        if hit is not None and hit[0] is L:
+            return hit[1]
+        g = ops.DeviceGraph(L, torch.device("cuda", key[1]))
+        if len(_graph_cache) > 256:
+            _graph_cache.clear()
+        _graph_cache[key] = (L, g)      # holding L keeps id(L) unique
+        return g
+
+
+def bn_momentum(bn):
+    """nn.BatchNorm1d's exponential_average_factor: `momentum`, or the cumulative average 1/num_batches_tracked when
+    momentum is None (torch/nn/modules/batchnorm.py; num_batches_tracked counts THIS batch already)."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    return 1.0 / float(int(bn.num_batches_tracked) + 1)
 
 
 class _ChebConvFn(torch.autograd.Function):
@@ -51,11 +64,11 @@ class _ChebConvFn(torch.autograd.Function):
             out = y
             if bn is not None:
                 if training:
+                    track = bn.track_running_stats and bn.running_mean is not None
                     co = ops.bn_finalize(st, M, gamma.contiguous(), beta.contiguous(),
-                                         bn.running_mean if bn.track_running_stats else None,
-                                         bn.running_var if bn.track_running_stats else None,
-                                         bn.momentum if bn.momentum is not None else 0.1, bn.eps)
-                    if bn.track_running_stats:
+                                         bn.running_mean if track else None, bn.running_var if track else None,
+                                         bn_momentum(bn) if track else 0.1, bn.eps)
+                    if track:
                         bn.num_batches_tracked.add_(1)
                 else:
                     co = ops.bn_eval_coeffs(gamma.contiguous(), beta.contiguous(), bn.running_mean, bn.running_var,
@@ -96,8 +109,13 @@ def graph_conv_cheby(x, cl, bn, L, Fout, K):
         pad = weight.new_zeros(Fout, Fin, 3)
         weight = torch.cat((weight.view(Fout, Fin, K), pad[:, :, K:]), dim=2).reshape(Fout, Fin * 3)
     bias = cl.bias if cl.bias is not None else x.new_zeros(Fout)
-    gamma = bn.weight if bn is not None else None
-    beta = bn.bias if bn is not None else None
+    gamma = beta = None
+    if bn is not None:
+        if bn.num_features != Fout:
+            raise P2MError(f"bn has {bn.num_features} features, expected {Fout}")
+        # affine=False: identity scale / zero shift (constants, no gradient)
+        gamma = bn.weight if bn.weight is not None else x.new_ones(Fout)
+        beta = bn.bias if bn.bias is not None else x.new_zeros(Fout)
     training = bn.training if bn is not None else False
     if bn is not None and not bn.training and not bn.track_running_stats:
         training = True            # nn.BatchNorm semantics: no running stats -> always batch statistics

@@ -259,6 +259,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   }
 }
 
+// any F: one block per BWD_ROWS_PER_BLOCK rows, threads stride over features (narrow / odd widths, e.g. Fout = 3 or 5)
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce_generic(const float* __restrict__ gx, const float* __restrict__ y,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu,
+                                                                float* __restrict__ part, long M, int F) {
+  const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
+  long r1 = r0 + BWD_ROWS_PER_BLOCK;
+  if (r1 > M) r1 = M;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const float sc = scale[f], sh = shift[f], mu = mean[f], is = invstd[f];
+    float s0 = 0.f, s1 = 0.f;
+    for (long r = r0; r < r1; r++) {
+      const float v = y[r * F + f];
+      float g = gx[r * F + f];
+      if (relu && fmaf(v, sc, sh) <= 0.f) g = 0.f;
+      s0 += g;
+      s1 = fmaf(g, (v - mu) * is, s1);
+    }
+    part[(long)blockIdx.x * 2 * F + f] = s0;
+    part[(long)blockIdx.x * 2 * F + F + f] = s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __restrict__ gx, const float* __restrict__ y,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ coef, int relu,
+                                                               float* __restrict__ gy, long M, int F) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * F) return;
+  const int f = (int)(idx % F);
+  const float v = y[idx];
+  float go = gx[idx];
+  if (relu && fmaf(v, scale[f], shift[f]) <= 0.f) go = 0.f;
+  const float k = gamma[f] * invstd[f];
+  const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
+  gy[idx] = fmaf(k, go, fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
+}
+
 __global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long M, float* dgamma, float* dbeta,
                                   float* coef, int accumulate, int F) {
   // one wave per column: lanes stride over blocks
@@ -473,7 +517,7 @@ extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
 extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, int32_t relu, float* part, int64_t M,
                                  int32_t F, void* stream) {
-  P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && M > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && M > 0 && F > 0, "null pointer or empty shape");
   hipStream_t s = (hipStream_t)stream;
   const int grid = p2m_bn_bwd_blocks(M, F);
   switch (F) {
@@ -482,8 +526,7 @@ extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* s
     case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
     case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
     default:
-      set_error("p2m_bn_bwd_reduce: unsupported feature width %d (need 32/64/128/256)", F);
-      return P2M_ERR_INVALID;
+      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, F);
   }
   return check_launch("bn_bwd_reduce");
 }
@@ -508,8 +551,7 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
     case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
     case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
     default:
-      set_error("p2m_bn_bwd_apply: unsupported feature width %d (need 32/64/128/256)", F);
-      return P2M_ERR_INVALID;
+      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv((long)M * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, F);
   }
   return check_launch("bn_bwd_apply");
 }

@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import P2MError
+from .cheby_graph_conv import bn_momentum
 
 K_CHEB = 3
 
@@ -73,20 +74,22 @@ class _MeshNetFn(torch.autograd.Function):
     """forward/backward of the whole coarse-to-fine stack (lib/models/meshnet.py:80-117)."""
 
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, keep, x, *params):
         dev = x.device
         if not x.is_cuda:
             raise P2MError("Pose2Mesh (HIP) needs CUDA/ROCm tensors: there is no CPU path in this package")
         ctx.x_shape = x.shape
         ctx.saved_params = params
         with torch.cuda.device(dev):
-            return _MeshNetFn._forward(ctx, net, x, params)
+            return _MeshNetFn._forward(ctx, net, keep, x, params)
 
     @staticmethod
-    def _forward(ctx, net, x, params):
+    def _forward(ctx, net, keep, x, params):
+        # `keep` (save activations for backward) is decided by the caller, where the grad mode is still visible:
+        # ctx.needs_input_grad only reflects requires_grad of the inputs and stays True under torch.no_grad(), which
+        # would make inference hold every layer's X / y until the forward returns (training-sized peak memory).
         graphs = net._graph_cache.on(x.device)
         training = net.training
-        keep = any(ctx.needs_input_grad)   # (autograd runs Function.forward with grad mode off)
         J, cin = net.num_joint, net.num_joint_input_chan
         x = x.reshape(-1, J * cin).contiguous().float()
         B = x.shape[0]
@@ -142,10 +145,10 @@ class _MeshNetFn(torch.autograd.Function):
                 gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
                 if training and tile_rows == "rows":
                     co = ops.bn_finalize_rows(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
-                                              bn.momentum, bn.eps)
+                                              bn_momentum(bn), bn.eps)
                     bn.num_batches_tracked.add_(1)
                 elif training:
-                    co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                    co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn_momentum(bn), bn.eps,
                                          tile_rows)
                     bn.num_batches_tracked.add_(1)
                 else:
@@ -181,11 +184,11 @@ class _MeshNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         with torch.cuda.device(grad_out.device):
-            ops.PHASE = "_bwd"
+            ops.set_phase("_bwd")
             try:
                 return _MeshNetFn._backward(ctx, grad_out)
             finally:
-                ops.PHASE = ""
+                ops.set_phase("")
 
     @staticmethod
     def _backward(ctx, grad_out):
@@ -318,9 +321,9 @@ class _MeshNetFn(torch.autograd.Function):
         keep.clear()
         ctx.saved = None
         gx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[2]:
             gx = g_cur.view(ctx.x_shape)
-        return (None, gx) + tuple(grads)
+        return (None, None, gx) + tuple(grads)
 
 
 class Pose2Mesh(nn.Module):
@@ -398,7 +401,8 @@ class Pose2Mesh(nn.Module):
 
     def forward(self, x):
         _, params = self._param_list()
-        return _MeshNetFn.apply(self, x, *params)
+        keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _MeshNetFn.apply(self, keep, x, *params)
 
 
 def get_model(num_joint_input_chan, num_mesh_output_chan, graph_L, mano=None):

@@ -80,11 +80,16 @@ class _NoBracket:
 
 _NOB = _NoBracket()
 TIMER = None
-PHASE = ""          # "" in forward, "_bwd" in backward: backward launches share the GPU with the side-stream dW GEMMs
+_tls = threading.local()      # .phase: "" in forward, "_bwd" in backward (backward launches share the GPU with the
+                              # side-stream dW GEMMs); thread-local because nn.DataParallel runs one thread per replica
+
+
+def set_phase(phase):
+    _tls.phase = phase
 
 
 def _timed(name, work):
-    return _NOB if TIMER is None else TIMER.bracket(name + PHASE, work)
+    return _NOB if TIMER is None else TIMER.bracket(name + getattr(_tls, "phase", ""), work)
 
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
@@ -267,15 +272,20 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
 
 
 _side_streams = {}
+_side_lock = threading.Lock()
 
 
 def side_stream(device, which=0):
-    """Helper streams per device (0 = weight-gradient GEMMs of the backward)."""
+    """Helper streams per device (0 = weight-gradient GEMMs of the backward).  Locked: nn.DataParallel runs one
+    thread per GPU through here."""
     key = (torch.device(device).index, which)
     st = _side_streams.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side_streams[key] = st
+        with _side_lock:
+            st = _side_streams.get(key)
+            if st is None:
+                st = torch.cuda.Stream(device=device)
+                _side_streams[key] = st
     return st
 
 

@@ -1,0 +1,142 @@
+"""-m gpu: the data-parallel path on the REAL model, provable on a 1-GPU box (VERDICT r1 "next round" 6):
+two ranks share cuda:0 over gloo (P2M_DIST_BACKEND=gloo; RCCL needs one GPU per rank and remains unmeasured).
+SURVEY 8(e)'s parity definition: the N-rank averaged gradient == the mean of the reference's (here: the oracle's)
+gradients computed on each shard separately; BatchNorm statistics stay per rank (nn.DataParallel semantics)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import meshnet_oracle as mo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+WORKER = r'''
+import os, sys
+sys.path[:0] = [{root!r}, {root!r} + "/oracle", {root!r} + "/tests"]
+import numpy as np, torch
+import helpers
+from pose2mesh_release_amd import dist as pd, loss as L, optim, pose2mesh_net, synth
+rank, world, local = pd.init_from_env()
+assert world == 2 and torch.distributed.get_backend() == "gloo"
+dev = torch.device("cuda", local)
+gL, _, rev = helpers.golden_graphs("mano")
+c = helpers.loss_case("mano", B=8, seed=23)
+net = pose2mesh_net.get_model(21, gL, mano=True)
+net.load_state_dict(helpers.numpy_state(net.state_dict(), 4))
+net = net.to(dev).train()
+for m in net.modules():
+    if isinstance(m, torch.nn.Dropout):
+        m.p = 0.0
+opt = optim.FlatAdam(net.parameters(), lr=1e-3)
+red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=32 << 20)
+fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy())
+stock = L.get_loss(c["faces"])
+sl = slice(rank * 4, rank * 4 + 4)
+pose2d = synth.pose2d_batch(8, 21, seed=31)[sl].to(dev)
+opt.zero_grad()
+mesh, lift = net(pose2d)
+total, _ = fused(mesh, c["gt_mesh"][sl].to(dev), c["gt_reg3dpose"][sl].to(dev), c["val_mesh"][sl].to(dev),
+                 c["val_reg3dpose"][sl].to(dev))
+lift_l = 1e-3 * stock[4](lift, c["gt_lift3dpose"][sl].to(dev), c["val_lift3dpose"][sl].to(dev))
+lift_l.backward()
+total.backward()
+scale = red.finish()
+assert abs(scale - 0.5) < 1e-12 and len(red.buckets) >= 2
+grads = {{k: (p.grad * scale).cpu().numpy() for k, p in net.named_parameters()}}
+stats = {{k: v.cpu().numpy() for k, v in net.state_dict().items() if "running" in k}}
+np.savez({out!r} + f"_r{{rank}}.npz", **{{"g::" + k: v for k, v in grads.items()}}, **{{"s::" + k: v for k, v in stats.items()}})
+opt.step(scale)          # identical update on both ranks
+np.save({out!r} + f"_p{{rank}}.npy", opt.flat_param.cpu().numpy())
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(nproc, argv, extra_env=None, timeout=900):
+    env = dict(os.environ, P2M_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + argv
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_two_ranks_real_model_gradient_is_mean_of_oracle_shard_gradients(hip_libs, tmp_path):
+    import loss_oracle as lo
+    out = str(tmp_path / "dp")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=out))
+    r = _launch(2, [str(script)])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = [np.load(out + f"_r{k}.npz") for k in range(2)]
+    # both ranks hold the same averaged gradient and, after the step, the same parameters
+    for k in z[0].files:
+        if k.startswith("g::"):
+            assert np.array_equal(z[0][k], z[1][k]), k
+    assert np.array_equal(np.load(out + "_p0.npy"), np.load(out + "_p1.npy"))
+    # oracle on each shard separately
+    torch.set_num_threads(16)
+    from pose2mesh_release_amd import pose2mesh_net, synth
+    gL, _, _ = helpers.golden_graphs("mano")
+    c = helpers.loss_case("mano", B=8, seed=23)
+    sd0 = helpers.numpy_state(pose2mesh_net.get_model(21, gL, mano=True).state_dict(), 4)
+    glt = helpers.oracle_graphs(gL)
+    pose2d = synth.pose2d_batch(8, 21, seed=31)
+    mean_g, stats = None, []
+    for rank in range(2):
+        sl = slice(rank * 4, rank * 4 + 4)
+        sd = {k: v.clone() for k, v in sd0.items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+        for k in names:
+            sd[k].requires_grad_(True)
+        mesh, lift = mo.flat_forward(sd, glt, pose2d[sl], True, True)
+        loss, _ = lo.train_losses(mesh, lift, c["perm_reverse"], c["nv"], c["faces"], c["J_regressor"], c["gt_mesh"][sl],
+                                  c["gt_reg3dpose"][sl], c["gt_lift3dpose"][sl], c["val_mesh"][sl],
+                                  c["val_reg3dpose"][sl], c["val_lift3dpose"][sl], with_edge=True)
+        loss.backward()
+        g = {k: sd[k].grad.clone() for k in names}
+        mean_g = g if mean_g is None else {k: 0.5 * (mean_g[k] + g[k]) for k in names}
+        stats.append({k: v.detach() for k, v in sd.items() if "running" in k})
+    worst = 0.0
+    for k, ref in mean_g.items():
+        got = z[0]["g::" + k]
+        if k.startswith("pose2mesh.cl.") and k.endswith("bias") and k.replace("cl.", "bn.").replace("bias", "weight") in mean_g:
+            continue                                       # zero gradient in front of train-mode BatchNorm
+        e = helpers.rel_l2(got, ref)
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    # BatchNorm running statistics are per rank (each rank saw only its shard), as under nn.DataParallel
+    for rank in range(2):
+        for k, v in stats[rank].items():
+            assert np.abs(z[rank]["s::" + k] - v.numpy()).max() < 1e-4 * max(1.0, float(v.abs().max())), (rank, k)
+    assert not np.array_equal(z[0]["s::pose2mesh.bn.0.running_mean"], z[1]["s::pose2mesh.bn.0.running_mean"])
+
+
+def test_bench_two_ranks_on_one_gpu(hip_libs):
+    """`torchrun --nproc-per-node 2 bench.py --gpus 2` exactly as the driver launches it (gloo instead of RCCL because
+    both ranks share the only GPU): one JSON line from rank 0 with the whole-job aggregate."""
+    r = _launch(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-kernel-timing"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 32 and j["config"]["parallelism"] == "dp2"
+    assert 300 < j["config"]["grad_allreduce_MB"] < 310          # 76.0 M parameters x 4 B
+    assert j["value"] > 0 and "cpu_baseline" not in j
