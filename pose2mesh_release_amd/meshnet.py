@@ -157,6 +157,8 @@ class _MeshNetFn(torch.autograd.Function):
                 if L.last_in_block and 1 <= L.block <= nblk - 2:       # meshnet.py:108-115
                     resid = block_in
                 out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout)
+                if net._tap is not None:          # test hook: raw conv output + BN scale/shift of every ReLU layer
+                    net._tap.append((L.ci, y, co[2], co[3]))
             else:
                 out = y                                               # final conv: no BN, no ReLU (:52-55,99)
             if keep:
@@ -380,6 +382,7 @@ class Pose2Mesh(nn.Module):
         self.bn = nn.ModuleList(bn)
         self._layers = layers
         self._graph_cache = ops.GraphCache(graph_L)
+        self._tap = None        # tests set this to a list to receive (conv index, y_raw, bn scale, bn shift) per layer
         names, _ = self._param_list()
         self._param_index = {n: i for i, n in enumerate(names)}
 

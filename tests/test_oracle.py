@@ -209,3 +209,44 @@ def test_state_dict_inventory_matches_real_reference(joint_set):
         n = ours[name].numel()
         ref_absmean = float(z[f"c{j}"][1]) / n if f"c{j}" in z else float(np.abs(z[f"t{j}"]).mean())
         assert abs(float(ours[name].abs().mean()) - ref_absmean) < 0.05 * ref_absmean, name
+
+
+def test_kink_accounting_counts_a_planted_flip():
+    """tests/kinks.py (the ReLU-kink accounting of the GPU gradient-parity tests): with the oracle's own masks nothing is
+    flipped and the gradient is the plain float64 gradient; with one mask bit flipped at the element closest to the
+    kink the flip is counted, located, and the gradient changes far above round-off."""
+    import kinks
+    gL, _, _ = helpers.golden_graphs("mano")
+    J = int(gL[-1].shape[0])
+    glt = helpers.oracle_graphs(gL)
+    sd = helpers.numpy_state(mo.init_state(J, mo.trim_graph_list(gL), True), 21)
+    x = helpers.meshnet_input(2, J, seed=99)
+    w = torch.randn(2, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(5))
+    out, g0, st0 = kinks.masked_oracle_gradients(sd, glt, x, True, w, None)
+    assert st0["n_flips"] == 0 and st0["n_relu_elements"] > 500000
+    ref, gref, _ = helpers.oracle_run(sd, glt, x, True, True, grad_seed=5)       # plain fp32 oracle
+    assert helpers.max_vertex_l2(out, ref) < 2e-5
+    # harvest the oracle's own masks, flip the element closest to zero in layer 6
+    masks, pre = [], []
+
+    class Rec(kinks._FProxy):
+        def relu(self, t, inplace=False):
+            pre.append(t.detach().clone())
+            masks.append(t.detach() > 0)
+            return super().relu(t)
+    old = mo.F
+    mo.F = Rec(None, {"n_relu_elements": 0, "n_flips": 0, "max_abs_preact_at_flip": 0.0, "flips_per_layer": {}})
+    try:
+        with torch.no_grad():
+            mo.meshnet_forward({k: v.double() if v.dtype.is_floating_point else v.clone() for k, v in sd.items()},
+                               [g.double() for g in glt], x.double(), True, True)
+    finally:
+        mo.F = old
+    i = int(pre[6].abs().reshape(-1).argmin())
+    masks[6].view(-1)[i] ^= True
+    _, g1, st1 = kinks.masked_oracle_gradients(sd, glt, x, True, w, masks)
+    assert st1["n_flips"] == 1 and st1["flips_per_layer"] == {6: 1}
+    assert st1["max_abs_preact_at_flip"] == float(pre[6].abs().reshape(-1)[i])
+    assert helpers.rel_l2(g1["bn.6.bias"], g0["bn.6.bias"]) > 1e-5
+    # downstream of the flip only the forward value moved, by |y| ~ 1e-7: gradients there are untouched
+    assert helpers.rel_l2(g1["cl.9.weight"], g0["cl.9.weight"]) < 1e-6
