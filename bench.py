@@ -125,21 +125,31 @@ class TrainStep:
 
 class InferStep:
     """BASELINE.json configs[1]: the Tester's step (lib/core/base.py:196-204) on resident synthetic data --
-    FlatPose2Mesh in eval() under no_grad, then mesh = pred[:, perm_reverse[:nv]] * 1000 and joints = J_reg @ mesh."""
+    FlatPose2Mesh in eval() under no_grad, then mesh = pred[:, perm_reverse[:nv]] * 1000 and joints = J_reg @ mesh.
+    Default: the captured hipGraph of the real-vertices-only inference path (pose2mesh_release_amd/infer.py);
+    --infer-path general runs the drop-in module + the separate epilogue kernel, launch by launch."""
 
-    def __init__(self, device, B, joint_set, seed=123):
-        self.device, self.B = device, B
+    def __init__(self, device, B, joint_set, seed=123, path="graph"):
+        from pose2mesh_release_amd import infer
+        self.device, self.B, self.path = device, B, path
         faces, graph_L, perm_rev, J = synth.make_graphs(joint_set)
         self.J, self.nv = J, int(faces.max()) + 1
         torch.manual_seed(seed)
         self.model = pose2mesh_net.get_model(J, graph_L).to(device).eval()
-        self.epilogue = p2m_loss.MeshEpilogue(perm_rev, self.nv, synthetic_regressor(J, self.nv), scale=1000.0)
         self.pose2d = synth.pose2d_batch(B, J, seed).to(device)
         self.V0 = graph_L[0].shape[0]
         self.dense_gflop_fwd = _dense_gflop_fwd(self.model.pose2mesh)
         self.dense_gflop_fwd_bwd = 3.0 * self.dense_gflop_fwd
+        if path == "general":
+            self.epilogue = p2m_loss.MeshEpilogue(perm_rev, self.nv, synthetic_regressor(J, self.nv), scale=1000.0)
+            self.step = None
+        else:
+            self.step = infer.GraphedInference(self.model, perm_rev, self.nv, synthetic_regressor(J, self.nv), B,
+                                               scale=1000.0, use_graph=(path == "graph"))
 
     def __call__(self):
+        if self.step is not None:
+            return self.step(self.pose2d)
         with torch.no_grad():
             pred_mesh, _ = self.model(self.pose2d)
             return self.epilogue(pred_mesh)
@@ -262,6 +272,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--stock-losses", action="store_true", help="use the stock-torch loss modules instead of p2m_mesh_loss")
+    ap.add_argument("--infer-path", default="graph", choices=["graph", "eager", "general"],
+                    help="--mode infer: captured hipGraph of the real-only path (default), the same launch by launch, "
+                         "or the general drop-in module + epilogue kernel")
     args = ap.parse_args()
     infer = args.mode == "infer"
     if args.batch is None:
@@ -280,7 +293,7 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if infer:
-        step = InferStep(device, args.batch, args.joint_set)
+        step = InferStep(device, args.batch, args.joint_set, path=args.infer_path)
     else:
         step = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss,
                          stock_losses=args.stock_losses, optimizer=args.optimizer)
@@ -290,9 +303,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = infer and args.infer_path == "graph"
     for _ in range(args.warmup):
         step()
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and not graphed:
         ops.TIMER = ops.KernelTimer()
     barrier()
     t0 = time.perf_counter()
@@ -300,6 +314,14 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if graphed and not args.no_kernel_timing:
+        # HIP events cannot bracket the nodes of a replayed graph: the per-kernel roofline of the graphed path is taken
+        # from the SAME launches issued one by one right after the timed region (stated in the JSON)
+        ops.TIMER = ops.KernelTimer()
+        with torch.no_grad():
+            for _ in range(args.steps):
+                step.step._eager()
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -311,9 +333,13 @@ def main():
         mano = args.joint_set == "mano"
         if infer:
             metric = f"{'MANO' if mano else 'SMPL'} meshes/sec fwd at batch {args.batch}"
+            how = {"graph": "captured hipGraph of the real-vertices-only inference path (kernel timings: same launches "
+                            "issued one by one after the timed region)",
+                   "eager": "real-vertices-only inference path, launch by launch",
+                   "general": "general drop-in module + epilogue kernel, launch by launch"}[args.infer_path]
             workload = (f"configs[1]: batch={args.batch}/GPU synthetic {args.joint_set} 2D poses (J={step.J}), "
                         f"{'MANO' if mano else 'SMPL'}-like hull mesh {step.nv} verts (padded {step.V0}), FlatPose2Mesh "
-                        f"eval forward + Tester epilogue (perm-reverse gather x1000, joint regression)")
+                        f"eval forward + Tester epilogue (perm-reverse gather x1000, joint regression); {how}")
         else:
             metric = "SMPL meshes/sec fwd+bwd at batch 256" if not mano else "MANO meshes/sec fwd+bwd"
             workload = (f"configs[{4 if mano else 2}]: batch={args.batch}/GPU synthetic "

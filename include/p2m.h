@@ -87,6 +87,13 @@ int p2m_cheb_combine_small(p2m_graph_t g, const float* P, int32_t ldp, int32_t n
                            float* Y, int32_t B, void* stream);
 int p2m_cheb_expand_small(p2m_graph_t g, const float* G, int32_t nc, float* E, int32_t lde, int32_t B,
                           void* stream);
+/* Inference form of the combine: only the REAL vertices of the level are computed (padding vertices never reach a
+ * caller: lib/core/base.py:201, demo/run.py:170 gather graph_perm_reverse[:nv]); P needs valid rows at real vertices
+ * only.  out_index == NULL: Y is [B*V, nc], rows of padding vertices are left untouched.  out_index != NULL
+ * ([V] int32, -1 = drop): vertex v goes to row out_index[v] of Y = [B, out_rows, nc], multiplied by scale -- the
+ * perm-reverse gather (and the Tester's x1000) folded into the last conv's store.                                  */
+int p2m_cheb_combine_small_real(p2m_graph_t g, const float* P, int32_t ldp, int32_t nc, const float* bias, float* Y,
+                                int32_t B, const int32_t* out_index, int32_t out_rows, float scale, void* stream);
 
 /* ---- weights ------------------------------------------------------------------------------
  * nn.Linear(Fin*K, Fout).weight is [Fout][fin*K + k] (cheby_graph_conv.py:32-37).  Packs it into
@@ -121,11 +128,17 @@ int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, fl
  * Arithmetic.  Bsplit == NULL: native f32 MFMA (bitwise an fmaf chain).  Bsplit != NULL (made from the same Bm by
  * p2m_weight_split): the same fp32 contraction on the BF16 matrix pipe - both operands are cut EXACTLY into three
  * bf16 slices (8+8+8 significand bits) and the six slice products of weight >= 2^-16 are accumulated in fp32 by
- * v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |a b|, i.e. fp32-level error at 6/16 of the MFMA cost.   */
+ * v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |a b|, i.e. fp32-level error at 6/16 of the MFMA cost.
+ *
+ * Fused activation (optional; inference): act_scale/act_shift != NULL applies v = fmaf(acc + bias, act_scale[n],
+ * act_shift[n]) and act_relu != 0 then v = max(v, 0) before the store -- eval-mode BatchNorm (p2m_bn_eval_coeffs) and
+ * F.relu (cheby_graph_conv.py:39, meshnet.py:100) folded into the contraction with the SAME two roundings as the
+ * separate p2m_bn_act_fwd pass (bitwise the unfused result).  Excludes stats and pair_out.                          */
 int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                     int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias, const float* addend,
                     float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out,
-                    int64_t M, float* stats, void* stream);
+                    int64_t M, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
+                    void* stream);
 /* Bx[k / 16][s][n][k % 16] (uint16 bf16 bit patterns; s < 3 slices; n < ceil(N/128)*128, zero padded; K % 16 == 0):
  * s-th slice of Bm[k][n], Bm = slice 0 + slice 1 + slice 2 exactly.  p2m_weight_split_elems(K, N) = number of uint16
  * elements of Bx.                                                                                                  */
@@ -198,7 +211,8 @@ int p2m_cheb_basis_fwd_real(p2m_graph_t g, const float* X, float* T1c, float* T2
 int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
                          const float* Bm, const void* Bsplit, const float* bias, const float* addend, float* C,
-                         int32_t N, float* stats, void* stream);
+                         int32_t N, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
+                         void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
@@ -278,7 +292,7 @@ int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   void* stream);
 
 /* torch.optim.RMSprop semantics with the defaults the reference's yaml recipes use (lib/funcs_utils.py:87-91,
- * asset/yaml/*.yml `optimizer: 'rmsprop'`: alpha 0.99, eps 1e-8, no momentum, not centered):
+ * the asset/yaml recipes, `optimizer: 'rmsprop'`: alpha 0.99, eps 1e-8, no momentum, not centered):
  *   v = alpha v + (1-alpha) g^2;  p -= lr g / (sqrt(v) + eps),  g = grad * grad_scale.                              */
 int p2m_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n, float lr, float alpha,
                      float eps, float grad_scale, void* stream);

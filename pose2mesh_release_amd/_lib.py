@@ -28,13 +28,14 @@ HIP_SYMBOLS = {
     "p2m_cheb_basis_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_cheb_basis_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_cheb_combine_small": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "p2m_cheb_combine_small_real": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _f32, _vp]),
     "p2m_cheb_expand_small": (_c.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "p2m_weight_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "p2m_graph_split_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2), _c.POINTER(_f32 * 2)]),
     "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                        _vp, _i32, _vp, _vp]),
+                                        _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                     _i32, _vp]),
@@ -48,7 +49,7 @@ HIP_SYMBOLS = {
     "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "p2m_fused_stats_tile_rows": (_i32, [_i32]),
     "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                                   _i32, _i64, _vp, _vp]),
+                                   _i32, _i64, _vp, _vp, _vp, _i32, _vp]),
     "p2m_weight_split_elems": (_i64, [_i32, _i32]),
     "p2m_weight_split": (_c.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),

@@ -207,22 +207,39 @@ __global__ void k_basis_bwd_generic(Graph g, const float* __restrict__ d0, const
 // P rows are `ldp` floats wide: columns [0,nc) = P0, [nc,2nc) = P1, [2nc,3nc) = P2.
 template <int NC>
 __global__ __launch_bounds__(256) void k_combine_small(Graph g, const float* __restrict__ P, int ldp,
-                                                        const float* __restrict__ bias, float* __restrict__ Y, int B) {
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int B,
+                                                        const int* __restrict__ ids, int nset,
+                                                        const int* __restrict__ out_index, int out_rows, float scale) {
+  // ids != nullptr: only the listed (real) vertices are computed; out_index != nullptr: vertex v is stored at row
+  // out_index[v] of a [B, out_rows, NC] tensor (mesh-model vertex order), scaled -- the Tester's / demo's
+  // pred_mesh[:, graph_perm_reverse[:nv], :] * scale (lib/core/base.py:201-202) folded into the last conv's store
+  const int n = ids ? nset : g.V;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * g.V) return;
-  const int row = (int)(idx % g.V);
-  const long base = (idx - row) * ldp;               // sample offset in P
+  if (idx >= (long)B * n) return;
+  const int b = (int)(idx / n);
+  const int i = (int)(idx - (long)b * n);
+  const int row = ids ? ids[i] : i;
+  const long base = (long)b * g.V * ldp;             // sample offset in P
+  const float* p0 = P + base + (long)row * ldp;
   float acc[NC];
 #pragma unroll
-  for (int c = 0; c < NC; c++) acc[c] = P[idx * ldp + c] + (bias ? bias[c] : 0.f);
+  for (int c = 0; c < NC; c++) acc[c] = p0[c] + (bias ? bias[c] : 0.f);
   for (int j = g.rowptr[row]; j < g.rowptr[row + 1]; j++) {
     const float* q = P + base + (long)g.col[j] * ldp;
-    const float a = g.a[j], b = g.b[j];
+    const float a = g.a[j], bb = g.b[j];
 #pragma unroll
-    for (int c = 0; c < NC; c++) acc[c] = fmaf(b, q[2 * NC + c], fmaf(a, q[NC + c], acc[c]));
+    for (int c = 0; c < NC; c++) acc[c] = fmaf(bb, q[2 * NC + c], fmaf(a, q[NC + c], acc[c]));
   }
+  long orow = row;
+  int rows_out = g.V;
+  if (out_index) {
+    orow = out_index[row];
+    rows_out = out_rows;
+    if (orow < 0) return;
+  }
+  float* y = Y + ((long)b * rows_out + orow) * NC;
 #pragma unroll
-  for (int c = 0; c < NC; c++) Y[idx * NC + c] = acc[c];
+  for (int c = 0; c < NC; c++) y[c] = out_index ? acc[c] * scale : acc[c];
 }
 
 // E[r] = [ G[r] | (L G)[r] | (L2 G)[r] | 0 ... ]   (row width lde >= 3*NC): the basis of a narrow gradient
@@ -259,21 +276,42 @@ __global__ __launch_bounds__(256) void k_expand_small(Graph g, const float* __re
 
 using namespace p2m;
 
+static int combine_small_launch(p2m_graph_t gh, const float* P, int32_t ldp, int32_t nc, const float* bias, float* Y,
+                                int32_t B, int real_only, const int32_t* out_index, int32_t out_rows, float scale,
+                                void* stream) {
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  const int* ids = real_only ? g.real_ids : nullptr;
+  const int nset = real_only ? g.n_real : g.V;
+  const long tot = (long)B * nset;
+  if (tot == 0) return P2M_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define P2M_COMBINE(NCv) hipLaunchKernelGGL(k_combine_small<NCv>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, \
+                                            Y, B, ids, nset, out_index, out_rows, scale)
+  switch (nc) {
+    case 1: P2M_COMBINE(1); break;
+    case 2: P2M_COMBINE(2); break;
+    case 3: P2M_COMBINE(3); break;
+    case 4: P2M_COMBINE(4); break;
+    default: set_error("p2m_cheb_combine_small: nc must be 1..4 (got %d)", nc); return P2M_ERR_INVALID;
+  }
+#undef P2M_COMBINE
+  return check_launch("cheb_combine_small");
+}
+
 extern "C" int p2m_cheb_combine_small(p2m_graph_t gh, const float* P, int32_t ldp, int32_t nc, const float* bias,
                                       float* Y, int32_t B, void* stream) {
   P2M_CHECK_ARG(gh && P && Y && ldp >= 3 * nc, "null pointer or ldp < 3*nc");
   if (B <= 0) return P2M_OK;
-  const Graph& g = *reinterpret_cast<const Graph*>(gh);
-  const long tot = (long)B * g.V;
-  hipStream_t s = (hipStream_t)stream;
-  switch (nc) {
-    case 1: hipLaunchKernelGGL(k_combine_small<1>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, Y, B); break;
-    case 2: hipLaunchKernelGGL(k_combine_small<2>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, Y, B); break;
-    case 3: hipLaunchKernelGGL(k_combine_small<3>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, Y, B); break;
-    case 4: hipLaunchKernelGGL(k_combine_small<4>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, Y, B); break;
-    default: set_error("p2m_cheb_combine_small: nc must be 1..4 (got %d)", nc); return P2M_ERR_INVALID;
-  }
-  return check_launch("cheb_combine_small");
+  return combine_small_launch(gh, P, ldp, nc, bias, Y, B, 0, nullptr, 0, 1.f, stream);
+}
+
+extern "C" int p2m_cheb_combine_small_real(p2m_graph_t gh, const float* P, int32_t ldp, int32_t nc, const float* bias,
+                                           float* Y, int32_t B, const int32_t* out_index, int32_t out_rows,
+                                           float scale, void* stream) {
+  P2M_CHECK_ARG(gh && P && Y && ldp >= 3 * nc, "null pointer or ldp < 3*nc");
+  P2M_CHECK_ARG(out_index == nullptr || out_rows > 0, "out_rows must be positive with out_index");
+  if (B <= 0) return P2M_OK;
+  return combine_small_launch(gh, P, ldp, nc, bias, Y, B, 1, out_index, out_rows, scale, stream);
 }
 
 extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc, float* E, int32_t lde, int32_t B,

@@ -248,5 +248,5 @@ extern "C" int p2m_chebconv_fwd(p2m_graph_t gh, const float* X, const float* Wt,
   int rc = p2m_cheb_basis_fwd(gh, X, T1, T2, B, Fin, in_shift, stream);
   if (rc != P2M_OK) return rc;
   return p2m_gemm_planes(X, T1, T2, 3, Fin, in_shift, Wt, nullptr, bias, nullptr, Y, nullptr, nullptr, 1, Fout, 0,
-                         (int64_t)B * g->V, stats, stream);
+                         (int64_t)B * g->V, stats, nullptr, nullptr, 0, stream);
 }

@@ -36,6 +36,12 @@ struct GemmArgs {
   const float* Bm;
   const float* bias;
   const float* addend;   // optional [M, N] added to the result (single output plane)
+  // optional fused activation (eval-mode BatchNorm + ReLU folded into the contraction that produces the tensor):
+  //   v = fmaf(acc + bias, act_scale[n], act_shift[n]);  v = max(v, 0) if act_relu   -- the same two roundings as the
+  //   separate p2m_bn_act_fwd pass, so the fused result is bitwise the unfused one
+  const float* act_scale;
+  const float* act_shift;
+  int act_relu;
   int pair_out;          // write C[(row>>1)] = v(row) + v(row^1): backward of the x2 un-pool (single output plane)
   float* C[3];
   float* stats;
@@ -73,12 +79,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
   constexpr int TN = WTN / 32;
   constexpr int TM = 2;
   // C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float bias_v[TN];
+  float bias_v[TN], sc_v[TN], sh_v[TN];
   int ncol[TN];
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     ncol[j] = n0 + wn * WTN + j * 32 + l31;
     bias_v[j] = (g.bias != nullptr && ncol[j] < g.N) ? g.bias[ncol[j]] : 0.f;
+    sc_v[j] = (g.act_scale != nullptr && ncol[j] < g.N) ? g.act_scale[ncol[j]] : 1.f;
+    sh_v[j] = (g.act_scale != nullptr && ncol[j] < g.N) ? g.act_shift[ncol[j]] : 0.f;
   }
   float csum[TN];
 #pragma unroll
@@ -97,6 +105,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         long row = ROWS ? (long)rowtab[ml] : m0 + ml;
         const bool rok = ROWS ? (row >= 0) : (row < g.M);
         float v = acc[i][j][r] + bias_v[j];
+        if (g.act_scale != nullptr) v = fmaf(v, sc_v[j], sh_v[j]);
+        if (g.act_relu) v = fmaxf(v, 0.f);
         if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
         acc[i][j][r] = rok ? v : 0.f;
         if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
@@ -791,6 +801,8 @@ __global__ void k_naive_gemm_planes(GemmArgs g) {
     for (int k = 0; k < g.Ka; k++) acc = fmaf(a[k], b[(long)k * g.N], acc);
   }
   if (g.bias) acc += g.bias[n];
+  if (g.act_scale) acc = fmaf(acc, g.act_scale[n], g.act_shift[n]);
+  if (g.act_relu) acc = fmaxf(acc, 0.f);
   if (g.addend) acc += g.addend[r * g.N + n];
   int q = n / g.Nc;
   g.C[q][r * g.Nc + (n - q * g.Nc)] = acc;
@@ -1627,8 +1639,11 @@ static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                                int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias,
                                const float* addend, float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc,
-                               int32_t pair_out, int64_t M, float* stats, void* stream) {
+                               int32_t pair_out, int64_t M, float* stats, const float* act_scale,
+                               const float* act_shift, int32_t act_relu, void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesC >= 1 && nplanesC <= 3, "plane count must be 1..3");
+  P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
+  P2M_CHECK_ARG(!((act_scale || act_relu) && (stats || pair_out)), "fused activation excludes stats and pair_out");
   P2M_CHECK_ARG(A0 && Bm && C0 && Ka > 0 && Nc > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
   if (M <= 0) return P2M_OK;
@@ -1640,6 +1655,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   P2M_CHECK_ARG((addend == nullptr && !pair_out) || nplanesC == 1, "addend / pair_out need a single output plane");
   P2M_CHECK_ARG(!(pair_out && stats), "pair_out and stats are mutually exclusive");
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = pair_out; g.stats = stats; g.M = M;
+  g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
   g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0;
@@ -1670,8 +1686,11 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
 extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
                                     const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
                                     int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
-                                    const float* addend, float* C, int32_t N, float* stats, void* stream) {
+                                    const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
+                                    const float* act_shift, int32_t act_relu, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
+  P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
+  P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
   P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
   P2M_CHECK_ARG(Ka > 0 && Ka % BK == 0 && N > 0 && N % 32 == 0, "Ka and N must be positive multiples of 32");
@@ -1684,6 +1703,7 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   for (int p = 0; p < nplanesA; p++) P2M_CHECK_ARG(g.A[p] != nullptr, "missing A plane");
   g.C[0] = C; g.C[1] = nullptr; g.C[2] = nullptr;
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = 0; g.stats = stats;
+  g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.N = N; g.Nc = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.tps = cdiv(rs.n, BM); g.compact = planes_compact;
   g.Bx = static_cast<const unsigned short*>(Bsplit);

@@ -1,0 +1,72 @@
+"""Graph-captured inference (BASELINE configs[1] / the Tester's loop, lib/core/base.py:196-204).
+
+A batch-64 forward is ~190 kernel launches of 5-50 us each: launch-bound when issued one by one from Python.  The whole
+step -- FlatPose2Mesh in eval(), the real-vertices-only fast path (Pose2Mesh.set_inference) with the mesh written straight
+in mesh-model vertex order, and the sparse joint regression -- is captured once into a hipGraph (torch.cuda.CUDAGraph on
+ROCm) and replayed per batch.  Shapes are static per instance; the input is copied into a resident buffer.
+"""
+import ctypes as _ct
+
+import numpy as _np
+import torch
+
+from . import _lib
+from . import loss as _loss
+
+
+class GraphedInference:
+    """step = GraphedInference(model, perm_reverse, nv, joint_regressor, batch, scale=1000.0)
+    mesh, joints, pose3d = step(pose2d)        # [B, nv, 3] (mesh order, x scale), [B, J, 3], [B, J, 3]
+    The returned tensors are the graph's static outputs: they are overwritten by the next call."""
+
+    def __init__(self, model, perm_reverse, nv, joint_regressor, batch, scale=1000.0, use_graph=True, warmup=3):
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise _lib.P2MError("GraphedInference needs the model on the GPU")
+        self.device = p.device
+        self.model = model.eval()
+        model.set_inference(real_only=True, perm_reverse=perm_reverse, nv=nv, scale=scale)
+        self.nv, self.J = int(nv), int(_np.asarray(joint_regressor).shape[0])
+        self._reg = {k: torch.from_numpy(_np.ascontiguousarray(v)).to(self.device)
+                     for k, v in _loss._regressor_tables(_np.asarray(joint_regressor, dtype=_np.float32), nv).items()}
+        self._ident = torch.arange(self.nv, dtype=torch.int32, device=self.device)
+        num_joint = model.num_joint
+        self.pose2d = torch.zeros((batch, num_joint, 2), device=self.device, dtype=torch.float32)
+        self.graph = None
+        with torch.cuda.device(self.device), torch.no_grad():
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):              # warm-up: graph handles, weight packs, allocator pools
+                for _ in range(max(1, warmup)):
+                    out = self._eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if use_graph:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    out = self._eager()
+            self.mesh, self.joints, self.pose3d = out
+
+    def _eager(self):
+        mesh, pose3d = self.model(self.pose2d)                       # mesh: [B, nv, 3] mesh order x scale
+        B = mesh.shape[0]
+        joints = torch.empty((B, self.J, 3), device=self.device, dtype=torch.float32)
+
+        def p(t):
+            return _ct.c_void_p(t.data_ptr())
+        # joints = J_regressor @ mesh (base.py:204): CSR mat-vec over the already-ordered mesh (perm = identity)
+        _lib.check(_lib.hip().p2m_mesh_epilogue(p(mesh), self.nv, p(self._ident), self.nv, 1.0, p(self._reg["jr_ptr"]),
+                                                p(self._reg["jr_idx"]), p(self._reg["jr_val"]), self.J, None, p(joints),
+                                                B, _ct.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "p2m_mesh_epilogue")
+        return mesh, joints, pose3d
+
+    @torch.no_grad()
+    def __call__(self, pose2d):
+        self.pose2d.copy_(pose2d.reshape(self.pose2d.shape), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.mesh, self.joints, self.pose3d
+        with torch.cuda.device(self.device):
+            self.mesh, self.joints, self.pose3d = self._eager()
+        return self.mesh, self.joints, self.pose3d

@@ -70,6 +70,96 @@ def _narrow(L):
     return (not L.has_bn) and K_CHEB * L.Fout <= 32 and L.Fin % 32 == 0 and not L.first_in_block and L.Fout <= 4
 
 
+def _narrow_operands(W, L):
+    """[Fin, 32] operand of the project-then-combine path: columns k*Fout + fo = W[fo][fin*3 + k], zero padded."""
+    Wp = torch.nn.functional.pad(W.detach().view(L.Fout, L.Fin, K_CHEB).permute(1, 2, 0).reshape(L.Fin, -1),
+                                 (0, 32 - K_CHEB * L.Fout)).contiguous()
+    return Wp, ops.weight_split(Wp)
+
+
+def _transposed_operands(Wp):
+    Wpt = Wp.t().contiguous()
+    return Wpt, ops.weight_split(Wpt)
+
+
+def _fc_operands(fw):
+    fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
+    return fwt, (ops.weight_split(fwt) if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
+
+
+def _forward_inference(net, graphs, x, params):
+    """eval() + no_grad fast path (Pose2Mesh.set_inference): SURVEY 8(f4) / A3 -- in eval() the real-vertex outputs are
+    bitwise independent of the padding vertices, so at every split level only the real rows are computed (no fake-row
+    contraction, no effective weight); eval-mode BatchNorm + ReLU ride in the contraction's epilogue (same two roundings
+    as the separate pass: the real-vertex outputs are bitwise those of the general path); the last conv stores straight
+    into mesh-model vertex order when an output order is set (lib/core/base.py:201-202 folded in).  Rows of padding
+    vertices hold unspecified values in the intermediate tensors and zeros in a tree-order output."""
+    wc = net._weight_cache
+    P = net._param_index
+    J, cin = net.num_joint, net.num_joint_input_chan
+    x = x.reshape(-1, J * cin).contiguous().float()
+    B = x.shape[0]
+    cur, cur_shift = x.view(B * J, cin), 0
+    nblk = len(net.CL_F)
+    block_in, block_in_shift, block_in_F = None, 0, 0
+    dev = x.device
+    for L in net._layers:
+        g = graphs[L.graph]
+        M = B * g.V
+        if L.first_in_block:
+            block_in, block_in_shift, block_in_F = cur, cur_shift, L.Fin
+        W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
+        if _narrow(L):
+            Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
+            oi = net._out_index_on(dev)
+            if g.split:
+                Pm = torch.empty((M, 32), device=dev, dtype=torch.float32)
+                ops.gemm_planes_rows(g, 1, B, [cur], L.Fin, cur_shift, False, Wp, None, None, Pm, 32, Bx=Wpx)
+            else:
+                (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False, Bx=Wpx)
+            if oi is not None:
+                return ops.cheb_combine_small_real(g, Pm, L.Fout, bvec, B, oi, net._out_nv, net._out_scale)
+            cur = ops.cheb_combine_small_real(g, Pm, L.Fout, bvec, B) if g.split \
+                else ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
+            cur_shift = 0
+            continue
+        act = None
+        if L.has_bn:
+            bn = net.bn[L.ci]
+            gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
+            co = wc.get((L.ci, "bn_eval"), (gamma, beta, bn.running_mean, bn.running_var),
+                        lambda: ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps))
+            act = (co[2], co[3], True)
+        want_w3 = ops.fused_supported(L.Fout, L.Fin) or _bwd_forward_form(L)
+        Wt, _, _ = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
+                                                                    need_w3=want_w3))
+        mfma = L.Fin % 32 == 0 and L.Fout % 32 == 0
+        if g.split and mfma:
+            y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
+            T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
+            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
+            ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout, Bx=Wtx,
+                                 act=act)
+        else:
+            T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
+            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) if mfma else None
+            (y,), _ = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, False, Bx=Wtx, act=act)
+        del T1, T2
+        if L.has_bn and L.last_in_block and 1 <= L.block <= nblk - 2:        # residual (meshnet.py:108-115)
+            y = ops.bn_act_fwd(y, None, False, block_in, block_in_F, block_in_shift, M, L.Fout)
+        cur, cur_shift = y, 0
+        if L.last_in_block:
+            if L.block == 0:                                                  # fc lift (:104-106)
+                h = cur.view(B, J * L.Fout)
+                fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
+                fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw))
+                (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx)
+                cur = u.view(B * net._Vc, net.CL_F[1][0])
+            elif L.block < nblk - 2:
+                cur_shift = 1
+    return cur.view(B, graphs[0].V, net.num_mesh_output_chan)
+
+
 class _MeshNetFn(torch.autograd.Function):
     """forward/backward of the whole coarse-to-fine stack (lib/models/meshnet.py:80-117)."""
 
@@ -90,7 +180,13 @@ class _MeshNetFn(torch.autograd.Function):
         # would make inference hold every layer's X / y until the forward returns (training-sized peak memory).
         graphs = net._graph_cache.on(x.device)
         training = net.training
+        wc = net._weight_cache
         J, cin = net.num_joint, net.num_joint_input_chan
+        if training:
+            ops.bump_weight_epoch()       # running statistics change behind torch's back: cached eval coefficients are stale
+        elif not keep and net._infer_real_only:
+            ctx.saved = None
+            return _forward_inference(net, graphs, x, params)
         x = x.reshape(-1, J * cin).contiguous().float()
         B = x.shape[0]
         P = net._param_index
@@ -108,9 +204,8 @@ class _MeshNetFn(torch.autograd.Function):
             W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
             if _narrow(L):
                 # final 64 -> 3 conv by linearity: project to 9 columns on the MFMA first, then combine sparsely
-                Wp = torch.nn.functional.pad(W.view(L.Fout, L.Fin, K_CHEB).permute(1, 2, 0).reshape(L.Fin, -1),
-                                             (0, 32 - K_CHEB * L.Fout)).contiguous()
-                (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False)
+                Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
+                (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False, Bx=Wpx)
                 out = ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
                 del Pm
                 if keep:
@@ -121,15 +216,19 @@ class _MeshNetFn(torch.autograd.Function):
             fwd_fused = ops.fused_supported(L.Fin, L.Fout)
             bwd_fused = ops.fused_supported(L.Fout, L.Fin)
             bwd_fwdform = _bwd_forward_form(L)
-            Wt, W2, W3 = ops.weight_pack(W, L.Fin, K_CHEB, need_w2=keep and not (bwd_fused or bwd_fwdform),
-                                         need_w3=keep and (bwd_fused or bwd_fwdform))
+            # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache)
+            want_w3 = bwd_fused or bwd_fwdform
+            Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
+                                                                           need_w3=want_w3))
             split = g.split and bwd_fwdform and not fwd_fused
             if split:
                 # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
+                opf = wc.get((L.ci, "split_fwd"), W,
+                             lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
                 T1, T2, st, st2 = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
-                                                 g.fake_b, need_stats)
+                                                 g.fake_b, need_stats, operands=opf)
                 tile_rows = "rows"
             elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
@@ -137,7 +236,9 @@ class _MeshNetFn(torch.autograd.Function):
                 tile_rows = ops.fused_stats_tile_rows(L.Fout)
             else:
                 T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
-                (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats)
+                Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) \
+                    if (L.Fin % 32 == 0 and L.Fout % 32 == 0) else None
+                (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats, Bx=Wtx)
                 tile_rows = None
             co = None
             if L.has_bn:
@@ -170,8 +271,8 @@ class _MeshNetFn(torch.autograd.Function):
                 if L.block == 0:                                      # fc lift (:104-106)
                     h = cur.view(B, J * L.Fout)
                     fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
-                    fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
-                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False)
+                    fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw))
+                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx)
                     if keep:
                         fc_saved = h
                     cur = u.view(B * net._Vc, net.CL_F[1][0])
@@ -198,6 +299,7 @@ class _MeshNetFn(torch.autograd.Function):
         if saved is None or len(saved) == 0:
             raise P2MError("backward called but the forward ran without gradient tracking (or twice)")
         graphs = net._graph_cache.on(grad_out.device)
+        wc = net._weight_cache
         P = net._param_index
         params = ctx.saved_params
         grads = [None] * ctx.n_params
@@ -238,7 +340,9 @@ class _MeshNetFn(torch.autograd.Function):
                     Pw, Pb, nch = ops.gemm_tn([h], fw.shape[1], 0, dU, B, fw.shape[0])
                     dW, db = ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
                     grads[P["fc.weight"]], grads[P["fc.bias"]] = dW, db
-                    (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False)
+                    fwx = wc.get("fc_bwd", fw, lambda: ops.weight_split(fw)
+                                 if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
+                    (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False, Bx=fwx)
                     G = dh.view(B * J, L.Fout)
                 g_cur = G
             if _narrow(L):
@@ -250,7 +354,9 @@ class _MeshNetFn(torch.autograd.Function):
                 grads[P[f"cl.{L.ci}.weight"]] = dW32[:nco].view(K_CHEB, L.Fout, L.Fin).permute(1, 2, 0) \
                     .reshape(L.Fout, L.Fin * K_CHEB).contiguous()
                 grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
-                (dX,), _ = ops.gemm_planes([E], 32, 0, Wp.t().contiguous(), None, M, L.Fin, 1, False)
+                Wl = params[P[f"cl.{L.ci}.weight"]]
+                Wpt, Wptx = wc.get((L.ci, "narrow_bwd"), Wl, lambda: _transposed_operands(Wp))
+                (dX,), _ = ops.gemm_planes([E], 32, 0, Wpt, None, M, L.Fin, 1, False, Bx=Wptx)
                 saved[L.ci] = None
                 g_cur = dX
                 continue
@@ -277,7 +383,11 @@ class _MeshNetFn(torch.autograd.Function):
                 # forward-form backward, split into real / fake vertex launches (see the forward)
                 dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)
                 add = G if fuse_res else None
-                E1, E2, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a, gph.fake_b)
+                Wl = params[P[f"cl.{L.ci}.weight"]]
+                opb = wc.get((L.ci, "split_bwd"), Wl,
+                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
+                E1, E2, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a, gph.fake_b,
+                                              operands=opb)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
@@ -294,8 +404,10 @@ class _MeshNetFn(torch.autograd.Function):
                 # gradient and the un-pool pair-sum in the GEMM epilogue, dW = X^T [gy|E1|E2].  One single-source
                 # gather (12.5 rows/row) replaces the two-source gather of p2m_cheb_basis_bwd (25 rows/row).
                 E1, E2 = ops.cheb_basis_fwd(gph, gy, B, L.Fout, 0)
+                Wl = params[P[f"cl.{L.ci}.weight"]]
+                W3x = wc.get((L.ci, "w3x"), Wl, lambda: ops.weight_split(W2))
                 (dX,), _ = ops.gemm_planes([gy, E1, E2], L.Fout, 0, W2, None, M, L.Fin, 1, False,
-                                           addend=G if fuse_res else None, pair_out=bool(x_shift))
+                                           addend=G if fuse_res else None, pair_out=bool(x_shift), Bx=W3x)
                 with side_ctx(keep, X, gy, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
                     dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
@@ -382,6 +494,9 @@ class Pose2Mesh(nn.Module):
         self.bn = nn.ModuleList(bn)
         self._layers = layers
         self._graph_cache = ops.GraphCache(graph_L)
+        self._weight_cache = ops.WeightCache()
+        self._infer_real_only = False
+        self._out_perm, self._out_nv, self._out_scale, self._out_index = None, 0, 1.0, {}
         self._tap = None        # tests set this to a list to receive (conv index, y_raw, bn scale, bn shift) per layer
         names, _ = self._param_list()
         self._param_index = {n: i for i, n in enumerate(names)}
@@ -401,6 +516,36 @@ class Pose2Mesh(nn.Module):
         scale = np.sqrt(2.0 / (Fin + Fout))
         W.uniform_(-scale, scale)
         return W
+
+    def set_inference(self, real_only=True, perm_reverse=None, nv=None, scale=1.0):
+        """Opt-in inference fast path, used in eval() under torch.no_grad() only (the Tester, lib/core/base.py:196;
+        the demo, demo/run.py:166).  real_only: compute only the real vertices at the split levels -- the real-vertex
+        outputs stay bitwise those of the general path, rows of padding vertices become 0 (no caller reads them: every
+        consumer gathers graph_perm_reverse[:nv] first).  perm_reverse / nv [/ scale]: additionally return the mesh in
+        mesh-model vertex order, [B, nv, 3] * scale -- `pred_mesh[:, graph_perm_reverse[:nv], :] * 1000`
+        (base.py:201-202) folded into the last conv's store."""
+        self._infer_real_only = bool(real_only)
+        self._out_index = {}
+        if perm_reverse is None:
+            self._out_perm, self._out_nv, self._out_scale = None, 0, 1.0
+        else:
+            if not real_only:
+                raise ValueError("an output order needs real_only=True")
+            self._out_perm = np.asarray(perm_reverse)[:int(nv)].astype(np.int64)
+            self._out_nv, self._out_scale = int(nv), float(scale)
+        return self
+
+    def _out_index_on(self, device):
+        if self._out_perm is None:
+            return None
+        t = self._out_index.get(device)
+        if t is None:
+            V0 = int(self.graph_L[0].shape[0])
+            inv = np.full((V0,), -1, dtype=np.int32)
+            inv[self._out_perm] = np.arange(self._out_nv, dtype=np.int32)
+            t = torch.from_numpy(inv).to(device)
+            self._out_index[device] = t
+        return t
 
     def forward(self, x):
         _, params = self._param_list()

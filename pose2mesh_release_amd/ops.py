@@ -200,6 +200,22 @@ def cheb_combine_small(g, P, nc, bias, B):
     return Y
 
 
+def cheb_combine_small_real(g, P, nc, bias, B, out_index=None, out_rows=0, scale=1.0):
+    """Inference: the combine over the real vertices only.  out_index ([V] int32 on the device, -1 = drop) stores vertex
+    v at row out_index[v] of a [B, out_rows, nc] tensor (mesh-model order) times `scale`; without it the result is
+    [B*V, nc] with zeros at the padding vertices."""
+    if out_index is None:
+        Y = torch.zeros((B * g.V, nc), device=P.device, dtype=torch.float32)
+    else:
+        Y = torch.empty((B, out_rows, nc), device=P.device, dtype=torch.float32)
+    with _timed("cheb_small", 4.0 * B * g.n_real * (P.shape[1] + nc)):
+        check(_lib.hip().p2m_cheb_combine_small_real(g.handle, _p(_req(P, "P")), P.shape[1], nc,
+                                                     _p(bias if bias is None else _req(bias, "bias")), _p(Y), B,
+                                                     _p(out_index), int(out_rows), float(scale), _stream()),
+              "p2m_cheb_combine_small_real")
+    return Y
+
+
 def cheb_expand_small(g, G, nc, lde, B):
     """E = [G | L G | L2 G | 0] with rows lde wide; G: [B*V, nc]."""
     M = B * g.V
@@ -231,6 +247,39 @@ if GEMM_ARITH not in ("f32", "bf16x3"):
     raise ValueError(f"P2M_GEMM_ARITH must be f32 or bf16x3, not {GEMM_ARITH!r}")
 
 
+# ---- per-step cache of derived weight operands ---------------------------------------------------------------
+# Packed / transposed / pre-split / fake-vertex-effective copies of a weight are constant between optimizer steps, but the
+# network needs them in the forward AND in the backward of every conv (~85 tiny launches per step).  They are cached
+# per (layer, kind, device) and rebuilt when the parameter changes: torch updates bump Tensor._version; the flat
+# optimizers (optim.py) update the buffer through a raw pointer and bump WEIGHT_EPOCH instead.
+WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+class WeightCache:
+    def __init__(self):
+        self._d = {}
+
+    def get(self, key, W, builder):
+        """W: the source tensor, or a tuple of source tensors."""
+        Ws = W if isinstance(W, tuple) else (W,)
+        tag = tuple((t.data_ptr(), t._version) for t in Ws) + (WEIGHT_EPOCH,)
+        key = (key, Ws[0].device.index)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        val = builder()
+        self._d[key] = (tag, val)
+        return val
+
+    def clear(self):
+        self._d.clear()
+
+
 def gemm_kernel_name():
     """Name prefix of the plane-contraction kernel the current knobs select (rocprof kernel names start with it)."""
     if GEMM_ARITH != "bf16x3":
@@ -254,8 +303,9 @@ def weight_split(Bm):
     return Bx
 
 
-def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False):
-    """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None."""
+def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None):
+    """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None.
+    Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
     n = g.n_real if row_set == 1 else g.n_fake
     st = None
     if stats:
@@ -264,10 +314,13 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     with _timed("gemm_planes_mfma", 2.0 * B * n * len(A) * Ka * N):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
-                                              int(compact), _p(_req(Bm, "B")), _p(weight_split(Bm)),
+                                              int(compact), _p(_req(Bm, "B")),
+                                              _p(Bx if Bx is not None else weight_split(Bm)),
                                               _p(bias if bias is None else _req(bias, "bias")),
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
-                                              _p(st), _stream()), "p2m_gemm_planes_rows")
+                                              _p(st), _p(None if act is None else act[0]),
+                                              _p(None if act is None else act[1]), int(bool(act and act[2])),
+                                              _stream()), "p2m_gemm_planes_rows")
     return st
 
 
@@ -289,14 +342,21 @@ def side_stream(device, which=0):
     return st
 
 
-def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False):
+def split_operands(Bm, Ka, N, fake_a, fake_b):
+    """Derived operands of one split contraction: (Bx, We, Wex) = pre-split Bm, the fake-vertex effective weight
+    W0 + a*W1 + b*W2 and its pre-split copy."""
+    We = weight_eff(Bm, Ka, N, fake_a, fake_b)
+    return weight_split(Bm), We, weight_split(We)
+
+
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None):
     """One split contraction: basis planes of the real vertices, the real-vertex GEMM (K = 3*Ka), then the fake-vertex
     GEMM (K = Ka, W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's
     basis on a side stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake)."""
     T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
-    st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats)
-    We = weight_eff(Bm, Ka, N, fake_a, fake_b)
-    st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats)
+    Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
+    st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx)
+    st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
     return T1c, T2c, st1, st2
 
 
@@ -394,9 +454,12 @@ def fused_supported(Ka, N):
     return USE_FUSED and Ka % 32 == 0 and N in (64, 128, 256)
 
 
-def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend=None, pair_out=False):
+def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend=None, pair_out=False, Bx=None,
+                act=None):
     """A: list of 1..3 plane tensors.  Returns (list of C planes, stats or None).
-    addend: [M, N] added in the epilogue; pair_out: the (single) output has M/2 rows = sums of row pairs."""
+    addend: [M, N] added in the epilogue; pair_out: the (single) output has M/2 rows = sums of row pairs.
+    Bx: cached weight_split(Bm), if the caller has one.  act = (scale[N], shift[N], relu): fused eval-mode
+    BatchNorm + ReLU in the epilogue (bitwise the separate bn_act_fwd pass)."""
     dev = A[0].device
     Nc = N // nplanesC
     C = [torch.empty((M >> 1 if pair_out else M, Nc), device=dev, dtype=torch.float32) for _ in range(nplanesC)]
@@ -407,12 +470,17 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     c = [_p(t) for t in C] + [None] * (3 - len(C))
     mfma = (Ka % 32 == 0) and (Nc % 32 == 0)
-    Bx = weight_split(Bm) if mfma else None
+    if not mfma:
+        Bx = None
+    elif Bx is None:
+        Bx = weight_split(Bm)
     with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", 2.0 * M * len(A) * Ka * N):   # algorithmic FLOPs
         check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")), _p(Bx),
                                          _p(bias if bias is None else _req(bias, "bias")),
                                          _p(addend if addend is None else _req(addend, "addend")), c[0], c[1], c[2],
-                                         nplanesC, Nc, int(pair_out), M, _p(st), _stream()), "p2m_gemm_planes")
+                                         nplanesC, Nc, int(pair_out), M, _p(st),
+                                         _p(None if act is None else act[0]), _p(None if act is None else act[1]),
+                                         int(bool(act and act[2])), _stream()), "p2m_gemm_planes")
     return C, st
 
 

@@ -16,7 +16,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check
 
 _vp = ctypes.c_void_p
@@ -81,6 +81,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.step_count += 1
         with torch.cuda.device(self.flat_param.device):
             self._launch(float(grad_scale))
+        ops.bump_weight_epoch()       # the parameters changed behind torch's back: derived weight operands are stale
         return loss
 
     # torch-shaped state dict so reference checkpoints (main/train.py:51-58) round-trip

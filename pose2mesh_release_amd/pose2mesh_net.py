@@ -20,6 +20,11 @@ class FlatPose2Mesh(nn.Module):
         self.pose2mesh = meshnet.get_model(num_joint_input_chan=2 + 3, num_mesh_output_chan=3, graph_L=graph_L,
                                            mano=mano)
 
+    def set_inference(self, real_only=True, perm_reverse=None, nv=None, scale=1.0):
+        """See Pose2Mesh.set_inference (eval() + no_grad fast path: real vertices only, optional mesh-order output)."""
+        self.pose2mesh.set_inference(real_only, perm_reverse, nv, scale)
+        return self
+
     def forward(self, pose2d):
         pose3d = self.pose_lifter(pose2d.view(len(pose2d), -1)).reshape(-1, self.num_joint, 3)
         # MeshNet gets no gradient path into PoseNet (pose2mesh_net.py:19)

@@ -1,0 +1,100 @@
+"""-m gpu: the inference fast path (VERDICT r1 "next round" 8): real vertices only in eval(),
+BatchNorm + ReLU fused into the contraction epilogue, mesh-order store in the last conv, hipGraph replay -- all pinned to
+the general drop-in path BITWISE on the real vertices, and to the oracle's Tester epilogue."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import loss_oracle as lo
+import meshnet_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(joint_set, seed=2):
+    from pose2mesh_release_amd import pose2mesh_net
+    gL, _, rev = helpers.golden_graphs(joint_set)
+    J = int(gL[-1].shape[0])
+    net = pose2mesh_net.get_model(J, gL, mano=(joint_set == "mano"))
+    sd = helpers.numpy_state(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), sd, gL, np.asarray(rev), J
+
+
+def test_fused_activation_epilogue_is_bitwise_the_separate_pass(hip_libs):
+    """p2m_gemm_planes(_rows) with act_scale/act_shift/act_relu == contraction, then p2m_bn_act_fwd (MFMA and scalar paths)."""
+    from pose2mesh_release_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M, Ka, N, planes in ((1000, 64, 128, 3), (517, 128, 64, 1), (300, 5, 32, 3)):
+        A = [torch.randn(M, Ka, device="cuda", generator=g) for _ in range(planes)]
+        W = torch.randn(planes * Ka, N, device="cuda", generator=g) * 0.1
+        bias = torch.randn(N, device="cuda", generator=g)
+        sc = torch.rand(N, device="cuda", generator=g) + 0.5
+        sh = torch.randn(N, device="cuda", generator=g)
+        (y,), _ = ops.gemm_planes(A, Ka, 0, W, bias, M, N)
+        co = torch.stack([sc, sc, sc, sh])
+        ref = ops.bn_act_fwd(y, co, True, None, 0, 0, M, N)
+        (fused,), _ = ops.gemm_planes(A, Ka, 0, W, bias, M, N, act=(sc, sh, True))
+        assert torch.equal(fused, ref)
+        (noact,), _ = ops.gemm_planes(A, Ka, 0, W, bias, M, N, act=(sc, sh, False))
+        assert torch.equal(noact, ops.bn_act_fwd(y, co, False, None, 0, 0, M, N))
+
+
+@pytest.mark.parametrize("joint_set,B", [("mano", 4), ("human36", 3)])
+def test_real_only_eval_is_bitwise_the_general_path_on_real_vertices(hip_libs, joint_set, B):
+    from pose2mesh_release_amd import synth
+    net, sd, gL, rev, J = _flat(joint_set)
+    nv = 778 if joint_set == "mano" else 6890
+    x = synth.pose2d_batch(B, J, seed=5).cuda()
+    with torch.no_grad():
+        ref_mesh, ref_pose = net(x)
+        net.set_inference(real_only=True)
+        fast_mesh, fast_pose = net(x)
+        net.set_inference(real_only=True, perm_reverse=rev, nv=nv, scale=1000.0)
+        ordered, _ = net(x)
+        net.set_inference(real_only=False)
+        again, _ = net(x)
+    real = torch.as_tensor(rev[:nv], device="cuda")
+    assert torch.equal(again, ref_mesh) and torch.equal(fast_pose, ref_pose)
+    assert torch.equal(fast_mesh[:, real], ref_mesh[:, real])                # bitwise on the real vertices
+    fake = np.setdiff1d(np.arange(gL[0].shape[0]), rev[:nv])
+    assert float(fast_mesh[:, torch.as_tensor(fake, device="cuda")].abs().max()) == 0.0
+    assert ordered.shape == (B, nv, 3) and torch.equal(ordered, ref_mesh[:, real] * 1000.0)
+    # gradients still work through the general path while the flag is set (training / fine-tuning is unaffected)
+    net.set_inference(real_only=True)
+    xg = x.clone().requires_grad_(True)
+    m, _ = net(xg)
+    assert torch.equal(m, ref_mesh)
+    m.sum().backward()
+    assert xg.grad is None or torch.isfinite(xg.grad).all()
+
+
+def test_graphed_inference_vs_general_path_and_oracle(hip_libs):
+    """pose2mesh_release_amd.infer.GraphedInference (hipGraph replay) == general module + MeshEpilogue, bit for bit,
+    across replays with different inputs; and == the oracle's Tester epilogue (lib/core/base.py:200-204) to 1e-4."""
+    from pose2mesh_release_amd import infer, loss as L, synth
+    net, sd, gL, rev, J = _flat("human36")
+    nv, B = 6890, 4
+    jreg = synth.synthetic_regressor(J, nv)
+    epi = L.MeshEpilogue(rev, nv, jreg, scale=1000.0)
+    xs = [synth.pose2d_batch(B, J, seed=s).cuda() for s in (7, 8, 7)]
+    with torch.no_grad():
+        refs = []
+        for x in xs:
+            cam, pose3d = net(x)
+            refs.append((*epi(cam), pose3d))
+    step = infer.GraphedInference(net, rev, nv, jreg, B, scale=1000.0)
+    assert step.graph is not None
+    for x, (rm, rj, rp) in zip(xs, refs):
+        mesh, joints, pose3d = step(x)
+        torch.cuda.synchronize()
+        assert torch.equal(mesh, rm) and torch.equal(joints, rj) and torch.equal(pose3d, rp)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        cam_o, _ = mo.flat_forward(sd, helpers.oracle_graphs(gL), xs[2].cpu(), False, False)
+    om, oj = lo.test_epilogue(cam_o, rev, nv, torch.from_numpy(jreg))
+    mesh, joints, _ = step(xs[2])
+    assert helpers.max_vertex_l2(mesh.cpu() / 1000.0, om / 1000.0) <= 1e-4
+    assert (joints.cpu() - oj).abs().max() <= 1e-1                      # millimetres (1e-4 m)
+    net.set_inference(real_only=False)

@@ -1,6 +1,6 @@
-"""Basis stage of the finest SMPL-like level (B=256, V=11776, 6890 real rows) for timing / PMC passes:
-the full-row kernel, the real-row kernel (P2M_BASIS_TILED=0: k_basis_fwd with ids, 1: k_basis_tile) and, with
-PROBE_BWD=1, the retired two-source k_basis_bwd.   python tools/probes/basis_probe.py [F] [shift]"""
+"""Basis stage of the split SMPL-like levels at B=256 for timing / PMC passes: real-row kernel (k_basis_tile_w /
+k_basis_tile / k_basis_fwd with ids, selected by P2M_BASIS_TILE_W / P2M_BASIS_TILED / P2M_BASIS_SPB) per
+(level, F, shift).   python tools/probes/basis_probe.py [all|finest] [B]"""
 import os
 import sys
 
@@ -10,15 +10,16 @@ import torch  # noqa: E402
 
 from pose2mesh_release_amd import ops, synth  # noqa: E402
 
-F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-shift = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 _, gL, _, J = synth.make_graphs("human36")
-g = ops.DeviceGraph(gL[0], "cuda:0")
-B, V = 256, g.V
-X = torch.randn(B * (V >> shift), F, device="cuda")
+CASES = [(0, 128, 1), (0, 128, 0), (0, 64, 0), (1, 128, 1), (1, 128, 0), (2, 256, 1), (2, 128, 0), (3, 256, 1), (3, 256, 0),
+         (4, 256, 1)]
+if which == "finest":
+    CASES = CASES[:2]
 
 
-def bench(fn, n=5):
+def bench(fn, n=6):
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,14 +31,18 @@ def bench(fn, n=5):
     return e0.elapsed_time(e1) / n
 
 
-ms_full = bench(lambda: ops.cheb_basis_fwd(g, X, B, F, shift))
-ms_real = bench(lambda: ops.cheb_basis_fwd_real(g, X, B, F, shift))
-moved_full = 4.0 * B * V * F * (2 + 1.0 / (1 << shift))
-moved_real = 4.0 * B * g.n_real * F * (2 + 1.0 / (1 << shift))
-print(f"V={V} real={g.n_real} F={F} shift={shift}: all rows {ms_full:.3f} ms ({moved_full / ms_full / 1e6:.0f} GB/s) | "
-      f"real rows {ms_real:.3f} ms ({moved_real / ms_real / 1e6:.0f} GB/s moved, "
-      f"{12.0 * B * V * F / ms_real / 1e6:.0f} GB/s by the all-rows formula)")
-if os.environ.get("PROBE_BWD") == "1":
-    d = [torch.randn(B * V, F, device="cuda") for _ in range(2)]
-    Xf = torch.randn(B * V, F, device="cuda")
-    print(f"k_basis_bwd: {bench(lambda: ops.cheb_basis_bwd(g, Xf, d[0], d[1], None, B, F, 0)):.3f} ms")
+graphs = {}
+tot_ms, tot_bytes = 0.0, 0.0
+for lvl, F, shift in CASES:
+    g = graphs.setdefault(lvl, ops.DeviceGraph(gL[lvl], "cuda:0"))
+    if not g.split:
+        continue
+    X = torch.randn(B * (g.V >> shift), F, device="cuda")
+    ms = bench(lambda: ops.cheb_basis_fwd_real(g, X, B, F, shift))
+    moved = 4.0 * B * g.n_real * F * (2 + 1.0 / (1 << shift))
+    tot_ms += ms
+    tot_bytes += moved
+    print(f"V={g.V:6d} real={g.n_real:5d} F={F:3d} shift={shift}: {ms:7.3f} ms  {moved / ms / 1e6:7.0f} GB/s moved", flush=True)
+    del X
+print(f"TOTAL {tot_ms:.3f} ms  {tot_bytes / tot_ms / 1e6:.0f} GB/s moved   [TILE_W={os.environ.get('P2M_BASIS_TILE_W', '1')} "
+      f"SPB={os.environ.get('P2M_BASIS_SPB', '8')} TILED={os.environ.get('P2M_BASIS_TILED', '1')}]")
