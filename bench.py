@@ -374,7 +374,8 @@ def main():
                 ks = [summ[n] for n in names if n in summ]
                 return None if not ks else {"launches": sum(k["launches"] for k in ks), "ms": sum(k["ms"] for k in ks),
                                             "work": sum(k["work"] for k in ks),
-                                            "work_alg": sum(k["work_alg"] for k in ks)}
+                                            "work_alg": sum(k["work_alg"] for k in ks),
+                                            "bytes": sum(k.get("bytes", 0.0) for k in ks)}
             g = merged("gemm_planes_mfma", "gemm_planes_mfma_bwd")
             if g:
                 if ops.GEMM_ARITH == "bf16x3":
@@ -390,6 +391,7 @@ def main():
                                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                     "frac": round(ach / peak, 4),
                                     "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                                    "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"]),
                                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                     "note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = pipe peak "
                                             "in algorithmic fp32 FLOPs (BF16 dense 2500 / 6 slice products, or the "
@@ -420,6 +422,7 @@ def main():
                                            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(mov / PEAK_HBM_GBPS, 4),
                                            "frac_of_copy_ceiling_6300": round(mov / 6300.0, 4),
                                            "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                                           "algorithmic_bytes_per_launch": round(sp["work"] / sp["launches"]),
                                            "launches": sp["launches"],
                                            "avg_launch_ms": round(sp["ms"] / sp["launches"], 4),
                                            "speedup_equivalent": {

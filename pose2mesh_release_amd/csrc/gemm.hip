@@ -412,17 +412,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
   const unsigned short* bx_base = g.Bx + ((long)(n0 + b_n) * 16 + b_half);
   const long bx_slice = (long)g.Npad * 16;        // elements between two slices of one chunk
 
-  const float* const Ap0 = g.A[0];      // plane bases in SGPRs (see k_gemm_planes_ws)
-  const float* const Ap1 = g.A[1];
-  const float* const Ap2 = g.A[2];
   auto load_chunk = [&](int kc, f32x4 (&ra)[APASS], u32x4 (&rb)[NS]) {
     const int p = kc / cpp;
     const int k0 = (kc - p * cpp) * KB;
-    const float* Ap = (p == 0 ? Ap0 : (p == 1 ? Ap1 : Ap2)) + k0;
+    const float* Ap = g.A[p] + k0;
 #pragma unroll
     for (int ps = 0; ps < APASS; ps++)
       ra[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
-    const unsigned short* src = bx_base + (long)kc * (NS * bx_slice);     // (p * Ka + k0) / 16 == kc
+    const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
     rb[0] = *reinterpret_cast<const u32x4*>(src);
     rb[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
     rb[2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
@@ -625,22 +622,16 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
         for (int sl = 0; sl < NS; sl++) rb[i][sl] = u32x4{1u, 2u, 3u, 4u};
       }
     }
-    // plane base pointers live in SGPRs for the whole kernel: indexing the kernel-argument array with the runtime plane
-    // number costs an s_load + s_waitcnt lgkmcnt(0) per chunk, and that wait also drains the chunk's own LDS stores
-    // before the next global loads can be issued
-    const float* const Ap0 = g.A[0];
-    const float* const Ap1 = g.A[1];
-    const float* const Ap2 = g.A[2];
     auto load_chunk = [&](int kc, f32x4 (&a)[APASS], u32x4 (&b)[NS]) {
       const int p = kc / cpp;
       const int k0 = (kc - p * cpp) * KB;
-      const float* Ap = (p == 0 ? Ap0 : (p == 1 ? Ap1 : Ap2)) + k0;
+      const float* Ap = g.A[p] + k0;
       if (!(P2M_ABLATE & 1)) {
 #pragma unroll
         for (int ps = 0; ps < APASS; ps++)
           a[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
       }
-      const unsigned short* src = bx_base + (long)kc * (NS * bx_slice);     // (p * Ka + k0) / 16 == kc
+      const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
       if (!(P2M_ABLATE & 2)) {
         b[0] = *reinterpret_cast<const u32x4*>(src);
         b[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);

@@ -52,7 +52,9 @@ class KernelTimer:
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
             out[name] = {"launches": len(recs), "ms": ms,
                          "work": float(sum(w[0] if isinstance(w, tuple) else w for _, _, w in recs)),
-                         "work_alg": float(sum(w[1] if isinstance(w, tuple) else w for _, _, w in recs))}
+                         "work_alg": float(sum(w[1] if isinstance(w, tuple) else w for _, _, w in recs)),
+                         # algorithmic HBM bytes of the launches (third element of the work tuple), for `traffic`
+                         "bytes": float(sum(w[2] if isinstance(w, tuple) and len(w) > 2 else 0.0 for _, _, w in recs))}
         return out
 
 
@@ -312,7 +314,9 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
         tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, row_set))
         st = torch.empty((B * tps, 2, N), device=C.device, dtype=torch.float32)
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
-    with _timed("gemm_planes_mfma", 2.0 * B * n * len(A) * Ka * N):
+    fl = 2.0 * B * n * len(A) * Ka * N
+    # algorithmic HBM bytes: every A plane row once, the output once (weights come from L2)
+    with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + N))):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
                                               int(compact), _p(_req(Bm, "B")),
                                               _p(Bx if Bx is not None else weight_split(Bm)),
@@ -474,7 +478,10 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend
         Bx = None
     elif Bx is None:
         Bx = weight_split(Bm)
-    with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", 2.0 * M * len(A) * Ka * N):   # algorithmic FLOPs
+    fl = 2.0 * M * len(A) * Ka * N                                                                  # algorithmic FLOPs
+    nbytes = 4.0 * M * ((len(A) - 1 + 1.0 / (1 << a0_shift)) * Ka + (0.5 if pair_out else 1.0) * N
+                        + (N if addend is not None else 0))
+    with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", (fl, fl, nbytes)):
         check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")), _p(Bx),
                                          _p(bias if bias is None else _req(bias, "bias")),
                                          _p(addend if addend is None else _req(addend, "addend")), c[0], c[1], c[2],
