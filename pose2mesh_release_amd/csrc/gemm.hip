@@ -541,6 +541,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
 #ifndef P2M_ABLATE
 #define P2M_ABLATE 0
 #endif
+// probe builds only (tools/probes/gemm_trace.py): -DP2M_GEMM_TRACE=1 stamps s_memtime at the phase boundaries of one
+// producer wave and one consumer wave of 8 blocks in the middle of the launch (LDS scratch, dumped to p2m_gemm_trace at
+// the end) to see where an iteration's cycles go
+#ifndef P2M_GEMM_TRACE
+#define P2M_GEMM_TRACE 0
+#endif
+#if P2M_GEMM_TRACE
+constexpr int TRACE_IT = 40, TRACE_ST = 6, TRACE_BLK0 = 4096;
+__device__ unsigned long long p2m_gemm_trace[8 * 2 * TRACE_IT * TRACE_ST];
+#define P2M_STAMP(role, it, k)                                                                                  \
+  do {                                                                                                          \
+    if (tracing && (it) < TRACE_IT && wave == 0 && lane == 0)                                                   \
+      trace_lds[((role) * TRACE_IT + (it)) * TRACE_ST + (k)] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
+#else
+#define P2M_STAMP(role, it, k) do { } while (0)
+#endif
 template <int BN, bool EXTRA, bool ROWS, int NBUF, int NST>
 __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmArgs g) {
   constexpr int NS = 3, KB = 16;
@@ -554,11 +571,21 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
   constexpr int AROWS = 256 / (KB / 4);
   constexpr int A_BUF = NS * BM * LDX;
   constexpr int B_BUF = NS * BN * LDX;
-  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0);
+#if P2M_GEMM_TRACE
+  constexpr int TRACE_WORDS = 2 * 2 * TRACE_IT * TRACE_ST;
+#else
+  constexpr int TRACE_WORDS = 0;
+#endif
+  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0) + TRACE_WORDS;
   __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);
   unsigned short* Bs = As + NBUF * A_BUF;
   int* rowtab = reinterpret_cast<int*>(smem + NBUF * (A_BUF + B_BUF) / 2);
+#if P2M_GEMM_TRACE
+  unsigned long long* trace_lds = reinterpret_cast<unsigned long long*>(smem + NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0));
+  const bool tracing = blockIdx.x >= TRACE_BLK0 && blockIdx.x < TRACE_BLK0 + 8;
+  if (tracing && threadIdx.x < TRACE_WORDS / 2) trace_lds[threadIdx.x] = 0;
+#endif
 
   int mt, nt;
   if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
@@ -589,6 +616,9 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   if (producer) {
+#ifdef P2M_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(P2M_PRODUCER_PRIO);
+#endif
     const int a_row = pt / (KB / 4), a_k4 = (pt % (KB / 4)) * 4;
     long off0[APASS], off12[APASS];
 #pragma unroll
@@ -643,6 +673,7 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       unsigned short* as = As + buf * A_BUF;
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(a[ps]));
+      P2M_STAMP(0, kc - AHEAD, 1);            // the A loads of this chunk have arrived
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
         unsigned h[4], m[4], l[4];
@@ -662,6 +693,7 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
         *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
       }
       if (P2M_ABLATE & 8) return;
+      P2M_STAMP(0, kc - AHEAD, 5);            // A slices computed and their LDS stores issued
       unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
       *reinterpret_cast<u32x4*>(d) = b[0];
       *reinterpret_cast<u32x4*>(d + BN * LDX) = b[1];
@@ -683,9 +715,13 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
     for (; kc + (NST - 1) + AHEAD + NST < n; kc += NST) {     // steady state: every load below is in range
 #pragma unroll
       for (int i = 0; i < NST; i++) {
+        P2M_STAMP(0, kc + i, 0);
         store_chunk(kc + i + AHEAD, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+        P2M_STAMP(0, kc + i, 2);              // slices written (s_memtime waits for the LDS stores)
         load_chunk(kc + i + AHEAD + NST, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
+        P2M_STAMP(0, kc + i, 3);              // next loads issued
         lds_barrier();
+        P2M_STAMP(0, kc + i, 4);              // barrier passed
       }
     }
     for (; kc < n; kc += NST) {                                // tail: same rotation, range-checked
@@ -757,13 +793,21 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       }
     } else {
       for (int kc = 0; kc < n; kc++) {
+        P2M_STAMP(1, kc, 0);
         read_frags(kc, fa[0], fb[0]);
+        P2M_STAMP(1, kc, 1);                  // fragments in registers (s_memtime waits for the LDS reads)
         mfmas(fa[0], fb[0]);
+        P2M_STAMP(1, kc, 2);                  // MFMAs issued
         lds_barrier();
+        P2M_STAMP(1, kc, 3);                  // barrier passed
       }
     }
   }
   __syncthreads();   // staging buffers are free: the epilogue reuses them
+#if P2M_GEMM_TRACE
+  if (tracing && t < TRACE_WORDS / 2) p2m_gemm_trace[(blockIdx.x - TRACE_BLK0) * (TRACE_WORDS / 2) + t] = trace_lds[t];
+  __syncthreads();
+#endif
   if (!producer) {
     gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
   } else if (g.stats != nullptr) {              // the three block barriers of the statistics reduction
@@ -1575,6 +1619,12 @@ __global__ __launch_bounds__(32 * UNP_CG) void k_weight_grad_unpack(
 using namespace p2m;
 
 extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
+
+#if P2M_GEMM_TRACE
+extern "C" int p2m_debug_gemm_trace(unsigned long long* host, int n) {      // probe builds only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(p2m_gemm_trace), sizeof(unsigned long long) * n);
+}
+#endif
 
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);

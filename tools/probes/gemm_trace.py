@@ -1,7 +1,7 @@
 """Where do the cycles of one k_gemm_planes_ws iteration go?  Needs the probe build of the library:
   P2M_HIPCC_FLAGS=-DP2M_GEMM_TRACE=1 python -m pose2mesh_release_amd.build   (into a scratch copy, see gemm_trace.sh)
 s_memtime stamps of producer wave 4 / consumer wave 0 of 8 mid-launch blocks:
-  producer: 0 top | 1 A loads arrived | 2 slices stored | 3 next loads issued | 4 barrier passed
+  producer: 0 top | 1 A loads arrived | 5 A slices stored | 2 B slices stored | 3 next loads issued | 4 barrier passed
   consumer: 0 top | 1 fragments read | 2 MFMAs issued | 3 barrier passed"""
 import ctypes
 import os
@@ -40,8 +40,9 @@ for blk in range(8):
     it = np.diff(p[4:36, 0])
     print(f"block {blk}: iteration {it.mean():7.0f} cycles (min {it.min()}, max {it.max()})")
     d = p[4:35]
-    print(f"   producer: wait A {np.mean(d[:, 1] - d[:, 0]):6.0f} | split+LDS stores {np.mean(d[:, 2] - d[:, 1]):6.0f} | "
-          f"issue loads {np.mean(d[:, 3] - d[:, 2]):6.0f} | barrier wait {np.mean(d[:, 4] - d[:, 3]):6.0f}")
+    print(f"   producer: wait A {np.mean(d[:, 1] - d[:, 0]):6.0f} | split A + issue A stores {np.mean(d[:, 5] - d[:, 1]):6.0f} | "
+          f"wait B + issue B stores {np.mean(d[:, 2] - d[:, 5]):6.0f} | "
+          f"(drain LDS +) issue loads {np.mean(d[:, 3] - d[:, 2]):6.0f} | barrier wait {np.mean(d[:, 4] - d[:, 3]):6.0f}")
     d = c[4:35]
     print(f"   consumer: frag reads {np.mean(d[:, 1] - d[:, 0]):6.0f} | 24 MFMAs issue {np.mean(d[:, 2] - d[:, 1]):6.0f} | "
           f"barrier wait {np.mean(d[:, 3] - d[:, 2]):6.0f} | next top {np.mean(c[5:36, 0] - d[:, 3]):6.0f}")
