@@ -67,6 +67,7 @@ class TrainStep:
             self.opt = optim.FlatAdam(self.model.parameters(), lr=1e-3)          # funcs_utils.py:92-96
         else:
             self.opt = optim.FlatRMSprop(self.model.parameters(), lr=1e-3)       # funcs_utils.py:87-91 (the yaml recipe)
+        self.model.pose2mesh.accumulate_grads_in_place(True)        # gradients land in opt.flat_grad directly
         self.reducer = p2m_dist.BucketedAllReduce(self.opt.params, self.opt.offsets, self.opt.flat_grad) \
             if world > 1 else None
         self.losses = p2m_loss.get_loss(faces)

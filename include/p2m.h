@@ -222,10 +222,11 @@ int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, 
 /* We[k][n] = Wt[k][n] + a Wt[Ka+k][n] + b Wt[2Ka+k][n]  (Wt = [3Ka, N]) */
 int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream);
 /* dW (nn.Linear layout) from the real-vertex partials P[c][fin][k*Fout+fo] plus the fake-vertex partials
- * P2[c][fin][fo] entering plane k with factor (1, s1, s2)[k]; db from both.                                       */
+ * P2[c][fin][fo] entering plane k with factor (1, s1, s2)[k]; db from both.  accumulate != 0 adds into dW/db (the
+ * caller's gradient buffer, e.g. a slice of optim.FlatAdam.flat_grad) instead of overwriting.                      */
 int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t nchunks, const float* P2, const float* Pdb2,
                             int32_t nchunks2, float s1, float s2, float* dW, float* db, int32_t Fout, int32_t Fin,
-                            int32_t K, void* stream);
+                            int32_t K, int32_t accumulate, void* stream);
 int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b, int32_t tps_b,
                          int32_t rows_b, int32_t B, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,

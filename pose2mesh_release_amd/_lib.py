@@ -41,7 +41,7 @@ HIP_SYMBOLS = {
                                     _i32, _vp]),
     "p2m_weight_eff": (_c.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "p2m_weight_grad_unpack2": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _i32, _i32, _i32,
-                                           _vp]),
+                                           _i32, _vp]),
     "p2m_bn_finalize_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
                                         _vp, _vp, _vp, _i32, _vp]),
     "p2m_cheb_gemm_fused": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32,

@@ -1878,11 +1878,11 @@ extern "C" int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N,
 
 extern "C" int p2m_weight_grad_unpack2(const float* P, const float* Pdb, int32_t nchunks, const float* P2,
                                        const float* Pdb2, int32_t nchunks2, float s1, float s2, float* dW, float* db,
-                                       int32_t Fout, int32_t Fin, int32_t K, void* stream) {
+                                       int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, void* stream) {
   P2M_CHECK_ARG(P && P2 && dW && Fout > 0 && Fin > 0 && K == 3 && nchunks > 0 && nchunks2 > 0, "null pointer or bad shape");
   long tot = (long)Fout * Fin * K;
   hipLaunchKernelGGL(k_weight_grad_unpack, dim3(cdiv(tot, 32)), dim3(32 * UNP_CG), 0, (hipStream_t)stream, P, Pdb, nchunks,
-                     dW, db, Fout, Fin, K, 0, 1, K * Fout, P2, Pdb2, nchunks2, s1, s2);
+                     dW, db, Fout, Fin, K, accumulate, 1, K * Fout, P2, Pdb2, nchunks2, s1, s2);
   return check_launch("weight_grad_unpack2");
 }
 

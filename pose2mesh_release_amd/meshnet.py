@@ -305,6 +305,20 @@ class _MeshNetFn(torch.autograd.Function):
         grads = [None] * ctx.n_params
         nblk = len(net.CL_F)
         J = net.num_joint
+
+        def tgt(*names):
+            """In-place gradient accumulation (Pose2Mesh.accumulate_grads_in_place): the parameters' .grad tensors when
+            every one of them is a usable fp32 buffer (e.g. views into optim.FlatAdam.flat_grad), else None."""
+            if not net._direct_grad:
+                return None
+            out = []
+            for n in names:
+                gbuf = params[P[n]].grad
+                if gbuf is None or gbuf.dtype != torch.float32 or not gbuf.is_contiguous() \
+                        or gbuf.device != grad_out.device:
+                    return None
+                out.append(gbuf)
+            return out
         G = grad_out.contiguous().float().view(-1, net.num_mesh_output_chan)   # grad wrt current block output
         g_cur = G
         keep = []          # tensors read by the side stream: kept alive until the join at the end of backward
@@ -338,8 +352,12 @@ class _MeshNetFn(torch.autograd.Function):
                     dU = G.view(B, fw.shape[0])
                     h = ctx.fc_saved
                     Pw, Pb, nch = ops.gemm_tn([h], fw.shape[1], 0, dU, B, fw.shape[0])
-                    dW, db = ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
-                    grads[P["fc.weight"]], grads[P["fc.bias"]] = dW, db
+                    tg = tgt("fc.weight", "fc.bias")
+                    if tg is not None:
+                        ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1, dW=tg[0], db=tg[1])
+                    else:
+                        grads[P["fc.weight"]], grads[P["fc.bias"]] = \
+                            ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
                     fwx = wc.get("fc_bwd", fw, lambda: ops.weight_split(fw)
                                  if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
                     (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False, Bx=fwx)
@@ -363,8 +381,12 @@ class _MeshNetFn(torch.autograd.Function):
             # ---- BN + ReLU backward -> gy
             if L.has_bn:
                 gamma = params[P[f"bn.{L.ci}.weight"]]
-                gy, dgamma, dbeta = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout)
-                grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = dgamma, dbeta
+                tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
+                if tg is not None:
+                    gy, _, _ = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, dgamma=tg[0], dbeta=tg[1])
+                else:
+                    gy, dgamma, dbeta = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout)
+                    grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = dgamma, dbeta
             else:
                 gy = g_cur
             has_res = L.first_in_block and 1 <= L.block <= nblk - 2
@@ -394,10 +416,12 @@ class _MeshNetFn(torch.autograd.Function):
                 with side_ctx(keep, X, gy, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
+                    tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
-                                                     L.Fin)
+                                                     L.Fin, *(tg or ()))
                     keep.extend((Pw, Pb, Pw2, Pb2))
-                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                if tg is None:
+                    grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, Pw2, Pb2, E1, E2, dXf
             elif _bwd_forward_form(L):
                 # backward in FORWARD form (L symmetric): E = basis(gy), dX = [gy|E1|E2] W3 with the residual
@@ -410,9 +434,14 @@ class _MeshNetFn(torch.autograd.Function):
                                            addend=G if fuse_res else None, pair_out=bool(x_shift), Bx=W3x)
                 with side_ctx(keep, X, gy, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
-                    dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
+                    tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                    if tg is not None:
+                        ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, dW=tg[0], db=tg[1], layout=1)
+                    else:
+                        dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                     keep.extend((Pw, Pb))
-                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                if tg is None:
+                    grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
             else:
                 if T1 is None:          # forward was fused: rebuild the (small) basis for this odd-shaped layer
@@ -495,6 +524,7 @@ class Pose2Mesh(nn.Module):
         self._layers = layers
         self._graph_cache = ops.GraphCache(graph_L)
         self._weight_cache = ops.WeightCache()
+        self._direct_grad = False
         self._infer_real_only = False
         self._out_perm, self._out_nv, self._out_scale, self._out_index = None, 0, 1.0, {}
         self._tap = None        # tests set this to a list to receive (conv index, y_raw, bn scale, bn shift) per layer
@@ -516,6 +546,15 @@ class Pose2Mesh(nn.Module):
         scale = np.sqrt(2.0 / (Fin + Fout))
         W.uniform_(-scale, scale)
         return W
+
+    def accumulate_grads_in_place(self, enable=True):
+        """Opt-in for training loops that own the gradient buffers (optim.FlatAdam / FlatRMSprop): the backward adds
+        the weight / bias / BatchNorm gradients straight into the parameters' existing .grad tensors (views of the flat
+        gradient buffer) and reports None to autograd, instead of returning ~60 temporaries that autograd then adds
+        with one small kernel each.  Same values; `loss.backward()` only -- torch.autograd.grad() on these parameters
+        would see no gradient, which is why this is not the default."""
+        self._direct_grad = bool(enable)
+        return self
 
     def set_inference(self, real_only=True, perm_reverse=None, nv=None, scale=1.0):
         """Opt-in inference fast path, used in eval() under torch.no_grad() only (the Tester, lib/core/base.py:196;

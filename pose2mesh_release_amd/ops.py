@@ -393,11 +393,14 @@ def weight_eff(Wt, Ka, N, a, b):
     return We
 
 
-def weight_grad_unpack2(P, Pdb, nch, P2, Pdb2, nch2, s1, s2, Fout, Fin):
-    dW = torch.empty((Fout, Fin * 3), device=P.device, dtype=torch.float32)
-    db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
+def weight_grad_unpack2(P, Pdb, nch, P2, Pdb2, nch2, s1, s2, Fout, Fin, dW=None, db=None):
+    """dW/db given: ACCUMULATE into them (the parameter's .grad, e.g. a slice of the flat gradient buffer)."""
+    acc = 1 if dW is not None else 0
+    if dW is None:
+        dW = torch.empty((Fout, Fin * 3), device=P.device, dtype=torch.float32)
+        db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
     check(_lib.hip().p2m_weight_grad_unpack2(_p(P), _p(Pdb), nch, _p(P2), _p(Pdb2), nch2, float(s1), float(s2), _p(dW),
-                                             _p(db), Fout, Fin, 3, _stream()), "p2m_weight_grad_unpack2")
+                                             _p(db), Fout, Fin, 3, acc, _stream()), "p2m_weight_grad_unpack2")
     return dW, db
 
 
@@ -568,22 +571,25 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F):
     return x
 
 
-def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F):
-    """Returns (gy, dgamma, dbeta)."""
+def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None):
+    """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad)."""
     lib = _lib.hip()
     nblk = int(lib.p2m_bn_bwd_blocks(M, F))
     part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
-    dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
+    acc = 1 if dgamma is not None else 0
+    if dgamma is None:
+        dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
+        dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
     check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
                                 int(relu), _p(part), M, F, _stream()), "p2m_bn_bwd_reduce")
-    check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgb[0]), _p(dgb[1]), _p(coef), 0, F, _stream()),
+    check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     gy = torch.empty((M, F), device=y.device, dtype=torch.float32)
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
                                _p(coef) if training else None, int(relu), _p(gy), M, F, _stream()),
           "p2m_bn_bwd_apply")
-    return gy, dgb[0], dgb[1]
+    return gy, dgamma, dbeta
 
 
 def pair_sum(x, Mout, F):

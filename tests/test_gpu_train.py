@@ -114,3 +114,26 @@ def test_fused_mesh_loss_matches_stock_losses(hip_libs):
     assert (cam2.grad - ref_grad).abs().max() <= 2e-5 * ref_grad.abs().max()
     fake = np.setdiff1d(np.arange(V0), perm_rev[:nv])
     assert float(cam2.grad[:, torch.as_tensor(fake, device="cuda")].abs().max()) == 0.0
+
+
+def test_in_place_gradient_accumulation_is_bitwise_the_autograd_path(hip_libs):
+    """Pose2Mesh.accumulate_grads_in_place: weight / bias / BatchNorm gradients written straight into the flat gradient
+    buffer by the unpack / finalize kernels == the tensors autograd would have added, and they ADD to what is there."""
+    import helpers
+    from pose2mesh_release_amd import meshnet, optim
+    gL, _, _ = helpers.golden_graphs("human36")
+    flats = []
+    for direct in (False, True):
+        net = meshnet.get_model(5, 3, gL, mano=False)
+        net.load_state_dict(helpers.numpy_state(net.state_dict(), 3))
+        net = net.cuda().train()
+        opt = optim.FlatAdam(net.parameters(), lr=1e-3)
+        net.accumulate_grads_in_place(direct)
+        x = helpers.meshnet_input(3, 17, seed=4).cuda()
+        w = torch.randn(3, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(1)).cuda()
+        for rep in range(2):                       # second backward without zero_grad: gradients must accumulate
+            (net(x) * w).sum().backward()
+        torch.cuda.synchronize()
+        flats.append(opt.flat_grad.clone())
+    assert torch.equal(flats[0], flats[1])
+    assert float(flats[0].abs().max()) > 0
