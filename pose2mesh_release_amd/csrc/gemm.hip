@@ -16,6 +16,7 @@
 // 64); each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles; K chunk 32 (f32) or 16 (bf16 slices) per barrier,
 // global -> registers -> LDS staging with register prefetch, two blocks per CU.
 #include <cstdlib>
+#include <type_traits>
 
 #include "p2m_common.h"
 
@@ -335,6 +336,23 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 }
 __device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | hi_elem; }
 
+// Four consecutive-k values -> their three slices, packed (two dwords = four bf16 per slice).  Bit for bit what
+// split3 + pack_hi produce, with fewer VALU instructions: v_perm_b32 takes the HIGH halves of two registers in one
+// instruction, so the slices need no masking before they are packed - only the two remainders need the masked value
+// (4.5 instructions per element instead of ~6; the contraction is issue-bound, every staging instruction delays an
+// MFMA of the co-resident wave).
+__device__ __forceinline__ unsigned hi_pair(float lo_elem, float hi_elem) {   // (bits(lo) >> 16) | (bits(hi) & 0xFFFF0000)
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float low_part(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+__device__ __forceinline__ void split3_pack4(float x0, float x1, float x2, float x3, u32x2& ph, u32x2& pm, u32x2& pl) {
+  const float r0 = low_part(x0), r1 = low_part(x1), r2 = low_part(x2), r3 = low_part(x3);
+  const float s0 = low_part(r0), s1 = low_part(r1), s2 = low_part(r2), s3 = low_part(r3);
+  ph = u32x2{hi_pair(x0, x1), hi_pair(x2, x3)};
+  pm = u32x2{hi_pair(r0, r1), hi_pair(r2, r3)};
+  pl = u32x2{hi_pair(s0, s1), hi_pair(s2, s3)};
+}
+
 template <int BN, int KB, bool EXTRA, bool ROWS = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
   constexpr int NS = 3;          // slices per operand
@@ -431,15 +449,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
     for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(ra[ps]));
 #pragma unroll
     for (int ps = 0; ps < APASS; ps++) {
-      unsigned h[4], m[4], l[4];
-      split3(ra[ps][0], h[0], m[0], l[0]);
-      split3(ra[ps][1], h[1], m[1], l[1]);
-      split3(ra[ps][2], h[2], m[2], l[2]);
-      split3(ra[ps][3], h[3], m[3], l[3]);
+      u32x2 ph, pm, pl;
+      split3_pack4(ra[ps][0], ra[ps][1], ra[ps][2], ra[ps][3], ph, pm, pl);
       unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
-      *reinterpret_cast<u32x2*>(d) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-      *reinterpret_cast<u32x2*>(d + BM * LDX) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-      *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+      *reinterpret_cast<u32x2*>(d) = ph;
+      *reinterpret_cast<u32x2*>(d + BM * LDX) = pm;
+      *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = pl;
     }
     unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
     *reinterpret_cast<u32x4*>(d) = rb[0];
@@ -620,25 +635,38 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
     __builtin_amdgcn_s_setprio(P2M_PRODUCER_PRIO);
 #endif
     const int a_row = pt / (KB / 4), a_k4 = (pt % (KB / 4)) * 4;
-    long off0[APASS], off12[APASS];
+    // Addresses = wave-uniform 64-bit base (plane + first row of this block's sample / tile, + k0 per chunk: SALU) +
+    // per-thread 32-BIT byte offset inside that sample / tile (fixed for the whole kernel): the loads take the
+    // `global_load v, v_off, s[base]` form and the chunk loop carries no 64-bit vector address arithmetic - the
+    // contraction is issue-bound, every VALU instruction of a staging wave delays an MFMA of the wave it shares a SIMD with
+    unsigned voff0[APASS], voff12[APASS];
+    long sbase0, sbase12;              // element offsets of the block's first row in plane 0 / planes 1,2
+    if (ROWS) {
+      sbase0 = (((long)rs_b * g.V) >> g.a0_shift) * g.Ka;        // V is even whenever a0_shift = 1
+      sbase12 = (g.compact ? (long)rs_b * g.nset : (long)rs_b * g.V) * g.Ka;
+    } else {
+      sbase0 = (m0 >> g.a0_shift) * g.Ka;                         // m0 is a multiple of 128
+      sbase12 = m0 * g.Ka;
+    }
 #pragma unroll
     for (int ps = 0; ps < APASS; ps++) {
-      long rf, rc;
+      int lf, lc;                        // row relative to the block's base row, in plane 0 / planes 1,2
       if (ROWS) {
         int i = rs_i0 + ps * AROWS + a_row;
         if (i >= g.nset) i = g.nset - 1;
-        rf = (long)rs_b * g.V + g.ids[i];
-        rc = g.compact ? (long)rs_b * g.nset + i : rf;
+        lf = g.ids[i];
+        lc = g.compact ? i : lf;
       } else {
-        rf = m0 + ps * AROWS + a_row;
+        long rf = m0 + ps * AROWS + a_row;
         if (rf >= g.M) rf = g.M - 1;
-        rc = rf;
+        lf = (int)(rf - m0);
+        lc = lf;
       }
-      off0[ps] = (rf >> g.a0_shift) * g.Ka + a_k4;
-      off12[ps] = rc * g.Ka + a_k4;
+      voff0[ps] = (unsigned)(((lf >> g.a0_shift) * g.Ka + a_k4) * 4);
+      voff12[ps] = (unsigned)((lc * g.Ka + a_k4) * 4);
     }
     const int b_n = (pt % (BN * 2)) >> 1, b_half = (pt & 1) * 8;
-    const unsigned short* bx_base = g.Bx + ((long)(n0 + b_n) * 16 + b_half);
+    const unsigned bx_voff = (unsigned)((((n0 + b_n) * 16) + b_half) * 2);       // bytes inside one slice of one chunk
     const long bx_slice = (long)g.Npad * 16;
 
     f32x4 ra[NST][APASS];
@@ -655,17 +683,19 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
     auto load_chunk = [&](int kc, f32x4 (&a)[APASS], u32x4 (&b)[NS]) {
       const int p = kc / cpp;
       const int k0 = (kc - p * cpp) * KB;
-      const float* Ap = g.A[p] + k0;
+      const char* Ab = reinterpret_cast<const char*>(g.A[p] + (p == 0 ? sbase0 : sbase12) + k0);     // uniform
       if (!(P2M_ABLATE & 1)) {
 #pragma unroll
         for (int ps = 0; ps < APASS; ps++)
-          a[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
+          a[ps] = *reinterpret_cast<const f32x4*>(Ab + (p == 0 ? voff0[ps] : voff12[ps]));
       }
-      const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
+      const char* src0 = reinterpret_cast<const char*>(g.Bx + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice));   // uniform
+      const char* src1 = src0 + 2 * bx_slice;
+      const char* src2 = src1 + 2 * bx_slice;
       if (!(P2M_ABLATE & 2)) {
-        b[0] = *reinterpret_cast<const u32x4*>(src);
-        b[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
-        b[2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
+        b[0] = *reinterpret_cast<const u32x4*>(src0 + bx_voff);
+        b[1] = *reinterpret_cast<const u32x4*>(src1 + bx_voff);
+        b[2] = *reinterpret_cast<const u32x4*>(src2 + bx_voff);
       }
     };
     auto store_chunk = [&](int kc, f32x4 (&a)[APASS], const u32x4 (&b)[NS]) {
@@ -676,21 +706,19 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       P2M_STAMP(0, kc - AHEAD, 1);            // the A loads of this chunk have arrived
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
-        unsigned h[4], m[4], l[4];
+        u32x2 ph, pm, pl;
         if (P2M_ABLATE & 4) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) { h[e] = __float_as_uint(a[ps][e]); m[e] = h[e]; l[e] = h[e]; }
+          ph = u32x2{__float_as_uint(a[ps][0]), __float_as_uint(a[ps][2])};
+          pm = ph;
+          pl = ph;
         } else {
-          split3(a[ps][0], h[0], m[0], l[0]);
-          split3(a[ps][1], h[1], m[1], l[1]);
-          split3(a[ps][2], h[2], m[2], l[2]);
-          split3(a[ps][3], h[3], m[3], l[3]);
+          split3_pack4(a[ps][0], a[ps][1], a[ps][2], a[ps][3], ph, pm, pl);
         }
         if (P2M_ABLATE & 8) continue;
         unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
-        *reinterpret_cast<u32x2*>(d) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-        *reinterpret_cast<u32x2*>(d + BM * LDX) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-        *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+        *reinterpret_cast<u32x2*>(d) = ph;
+        *reinterpret_cast<u32x2*>(d + BM * LDX) = pm;
+        *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = pl;
       }
       if (P2M_ABLATE & 8) return;
       P2M_STAMP(0, kc - AHEAD, 5);            // A slices computed and their LDS stores issued
@@ -1164,12 +1192,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bx(TnArgs g) {
     unsigned short* d = dst + buf * buf_stride;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      unsigned h[4], m[4], l[4];
-#pragma unroll
-      for (int ps = 0; ps < 4; ps++) split3(x[ps][e], h[ps], m[ps], l[ps]);
-      *reinterpret_cast<u32x2*>(d + e * LDX) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+      u32x2 ph, pm, pl;
+      split3_pack4(x[0][e], x[1][e], x[2][e], x[3][e], ph, pm, pl);
+      *reinterpret_cast<u32x2*>(d + e * LDX) = ph;
+      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = pm;
+      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = pl;
     }
   };
   auto compute = [&](int cur) {
@@ -1312,8 +1339,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // staging role of this thread: a 4-row x 4-column block of the A tile (t < 128) or of the G tile
-  const bool is_a = pt < 128;
+  // staging role of this thread: a 4-row x 4-column block of the A tile (pt < 128) or of the G tile.  The role is
+  // wave-uniform (waves 4,5 stage A, waves 6,7 stage G): readfirstlane tells the compiler so, and the role-dependent
+  // code becomes scalar branches instead of exec-masked ones
+  const bool is_a = __builtin_amdgcn_readfirstlane((int)(pt < 128)) != 0;
   const int st = pt & 127;
   const int rq = st & 3;                                   // row quad of the 16-row stage
   const int c4 = is_a ? (st >> 2) : (st >> 2) % (BN / 4);  // column quad (BN = 64: the upper threads duplicate)
@@ -1347,8 +1376,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   }
   const int buf_stride = is_a ? A_BUF : G_BUF;
   const int* idp = ROWS ? g.ids + r_begin + rq * 4 : nullptr;
-  const long row_base = ROWS ? (long)rs_b * g.V : 0;
-  const long crow_base = ROWS ? (long)rs_b * g.nset : 0;
+  // Addresses: per-thread 64-bit base (plane + column + the first row of this block's sample / chunk), fixed for the
+  // whole kernel, plus a 32-bit byte offset per load = (row relative to that base >> shift) * pitch * 4: three 32-bit
+  // VALU instructions and one 64-bit add per load instead of the 64-bit multiply-add chain.  base rows are even
+  // (V is even whenever shift = 1; chunk_rows is a multiple of 16), so (base + rel) >> shift == (base >> shift) + (rel >> shift).
+  const long base_row = ROWS ? (compact_rows ? (long)rs_b * g.nset + r_begin : (long)rs_b * g.V) : r_begin;
+  const char* srcb = reinterpret_cast<const char*>(src + (base_row >> shift) * pitch);
+  const unsigned pitch4 = (unsigned)pitch * 4u;
+  const int nrows_m1 = (int)(r_end - r_begin) - 1;
 
   f32x4 x0[4], x1[4];       // two register stages (native vector types: no scratch)
   i32x4 id0 = {0, 0, 0, 0}, id1 = {0, 0, 0, 0};
@@ -1357,37 +1392,45 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   auto load_ids = [&](int kc, i32x4& id) {
     if (ROWS) id = *reinterpret_cast<const i32x4*>(idp + (long)kc * RK);
   };
-  auto load_stage = [&](int kc, f32x4 (&x)[4], const i32x4& id) {
+  // CLAMP = false: every row of the stage exists (steady state); true: rows past the end are clamped to the last one
+  auto load_stage = [&](int kc, f32x4 (&x)[4], const i32x4& id, auto clamp_tag) {
+    constexpr bool CLAMP = decltype(clamp_tag)::value;
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
-      long r = r_begin + (long)kc * RK + rq * 4 + ps;
-      if (r >= r_end) r = r_end - 1;
-      long row;
-      if (ROWS) row = compact_rows ? crow_base + r : row_base + id[ps];
-      else row = r;
-      x[ps] = *reinterpret_cast<const f32x4*>(src + (row >> shift) * pitch);
+      int rel = kc * RK + rq * 4 + ps;                     // row relative to r_begin
+      if (CLAMP && rel > nrows_m1) rel = nrows_m1;
+      if (ROWS && !compact_rows) rel = id[ps];             // vertex id inside the sample (slack entries: vertex 0)
+      const unsigned off = __umul24((unsigned)(rel >> shift), pitch4);
+      x[ps] = *reinterpret_cast<const f32x4*>(srcb + off);
     }
   };
-  auto store_stage = [&](int buf, int kc, f32x4 (&x)[4]) {
+  // TAIL = true: rows past the end of the chunk are zeroed before they are used
+  auto store_stage = [&](int buf, int kc, f32x4 (&x)[4], auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) asm volatile("" : "+v"(x[ps]));     // see k_gemm_planes_bx
-    const long rlast = r_end - (r_begin + (long)kc * RK + rq * 4);        // rows of this quad that exist
+    if (TAIL) {
+      const int rlast = nrows_m1 + 1 - (kc * RK + rq * 4);             // rows of this quad that exist
 #pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-      if (ps >= rlast) x[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dbs += x[ps];
+      for (int ps = 0; ps < 4; ps++)
+        if (ps >= rlast) x[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!is_a) {                                                        // bias gradient: column sums of G (scalar branch)
+#pragma unroll
+      for (int ps = 0; ps < 4; ps++) dbs += x[ps];
     }
     unsigned short* d = dst + buf * buf_stride;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      unsigned h[4], m[4], l[4];
-#pragma unroll
-      for (int ps = 0; ps < 4; ps++) split3(x[ps][e], h[ps], m[ps], l[ps]);
-      *reinterpret_cast<u32x2*>(d + e * LDX) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+      u32x2 ph, pm, pl;
+      split3_pack4(x[0][e], x[1][e], x[2][e], x[3][e], ph, pm, pl);
+      *reinterpret_cast<u32x2*>(d + e * LDX) = ph;
+      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = pm;
+      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = pl;
     }
   };
+  using std::false_type;
+  using std::true_type;
   auto compute = [&](int cur) {
     const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
     const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + l31) * LDX + lhi * 8;
@@ -1425,32 +1468,40 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       // kc (consumers: MFMAs of stage kc) the producers store stage kc+1 and refill its set with stage kc+3.
       load_ids(0, id0);
       load_ids(1, id1);
-      load_stage(0, x0, id0);
+      load_stage(0, x0, id0, true_type{});
       load_ids(2, id0);
-      load_stage(nst > 1 ? 1 : 0, x1, id1);
+      load_stage(nst > 1 ? 1 : 0, x1, id1, true_type{});
       load_ids(3, id1);
-      store_stage(0, 0, x0);
-      load_stage(nst > 2 ? 2 : nst - 1, x0, id0);
+      store_stage(0, 0, x0, true_type{});
+      load_stage(nst > 2 ? 2 : nst - 1, x0, id0, true_type{});
       load_ids(4, id0);
       lds_barrier();
       int kc = 0;
-      for (; kc + 4 < nst; kc += 2) {            // steady state: stages kc+3, kc+4 exist, loads unconditional
-        store_stage(1, kc + 1, x1);
-        load_stage(kc + 3, x1, id1);
+      // steady state: stages up to kc+4 are FULL stages (the possibly partial last stage nst-1 is left to the tail), so
+      // neither the loads nor the stores carry clamps, zeroing or conditions
+      for (; kc + 5 < nst; kc += 2) {
+        store_stage(1, kc + 1, x1, false_type{});
+        load_stage(kc + 3, x1, id1, false_type{});
         load_ids(kc + 5, id1);
         lds_barrier();
-        store_stage(0, kc + 2, x0);
-        load_stage(kc + 4, x0, id0);
+        store_stage(0, kc + 2, x0, false_type{});
+        load_stage(kc + 4, x0, id0, false_type{});
         load_ids(kc + 6, id0);
         lds_barrier();
       }
       for (; kc < nst; kc += 2) {                // tail: same rotation, range-checked
-        if (kc + 1 < nst) store_stage(1, kc + 1, x1);
-        if (kc + 3 < nst) load_stage(kc + 3, x1, id1);
+        if (kc + 1 < nst) store_stage(1, kc + 1, x1, true_type{});
+        if (kc + 3 < nst) {
+          load_stage(kc + 3, x1, id1, true_type{});
+          load_ids(kc + 5, id1);
+        }
         lds_barrier();
         if (kc + 1 < nst) {
-          if (kc + 2 < nst) store_stage(0, kc + 2, x0);
-          if (kc + 4 < nst) load_stage(kc + 4, x0, id0);
+          if (kc + 2 < nst) store_stage(0, kc + 2, x0, true_type{});
+          if (kc + 4 < nst) {
+            load_stage(kc + 4, x0, id0, true_type{});
+            load_ids(kc + 6, id0);
+          }
           lds_barrier();
         }
       }
