@@ -8,7 +8,8 @@
  *
  * Conventions
  *  - plain C symbols, device pointers + sizes + hipStream_t (passed as void*); the library never
- *    allocates caller-visible device memory except the immutable per-level graph handle;
+ *    allocates caller-visible device memory except the immutable per-level graph handle (internally it keeps one small
+ *    scratch buffer per (device, stream) for the two-stage BatchNorm finalize, allocated on first use);
  *  - all matrices fp32 row-major; a "row" is one (sample, vertex) pair, r = b*V + v;
  *  - return 0 on success, negative p2m_status on error; p2m_last_error_string() has the detail;
  *    nothing throws across the boundary;

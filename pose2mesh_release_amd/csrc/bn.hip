@@ -5,6 +5,10 @@
 // F.interpolate(mode='linear') along the feature axis + residual add (meshnet.py:109-110,114-115),
 // nn.Upsample(scale_factor=2) (meshnet.py:71-78; here virtual: consumers index r>>1).
 // All of these are streaming HBM-bound passes: float4 per lane, one row group of F/4 lanes per row.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "p2m_common.h"
 
 namespace p2m {
@@ -12,8 +16,14 @@ namespace p2m {
 // ---- statistics finalize --------------------------------------------------------------------
 // stats[tile][0][n] = sum, stats[tile][1][n] = sum (y - tile_mean)^2.  sum y^2 over a tile is
 // M2 + sum^2/n; tile-centred partials make the double-precision E[y^2]-E[y]^2 benign.
-constexpr int FIN_CG = 8;     // columns per block
-constexpr int FIN_RG = 128;   // tile groups per block
+// Two stages.  Stage 1 (k_bn_partial): a block owns 32 adjacent columns (one 128-byte run per tile row: coalesced) and
+// one of FIN_SPLITS slices of the tile range; 8 row groups per block, reduced through LDS; double-precision partials.
+// Stage 2 (k_bn_finalize): one thread per column adds the FIN_SPLITS partials in a fixed order and writes the
+// coefficients.  Deterministic (no atomics).  The single-stage form read 4-byte words at a 2N*4-byte stride from
+// N/8 blocks only: ~35 us per call for the fine levels, 40 calls per step.
+constexpr int FIN_COLS = 32;    // columns per stage-1 block
+constexpr int FIN_RG = 8;       // tile-row groups per stage-1 block
+constexpr int FIN_SPLITS = 48;  // slices of the tile range
 // Up to two segments of partials (e.g. the real-vertex and the fake-vertex launch of one conv); inside a segment the
 // tiles repeat with period `tps` over `seg_rows` rows (row-set launches tile every sample separately).
 struct StatSeg {
@@ -21,57 +31,72 @@ struct StatSeg {
   int ntiles, tps;
   long seg_rows;
 };
-__global__ __launch_bounds__(FIN_CG * FIN_RG) void k_bn_finalize(StatSeg sg0, StatSeg sg1, long M,
-                                                                  int tile_rows, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float* running_mean,
-                                                                  float* running_var, float momentum, float eps,
-                                                                  float* mean_o, float* invstd_o, float* scale_o,
-                                                                  float* shift_o, int N) {
-  __shared__ double s1[FIN_RG][FIN_CG];
-  __shared__ double s2[FIN_RG][FIN_CG];
-  const int cg = threadIdx.x % FIN_CG, rg = threadIdx.x / FIN_CG;
-  const int n = blockIdx.x * FIN_CG + cg;
+__global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, StatSeg sg1, int tile_rows, int N,
+                                                                  double* __restrict__ part) {
+  __shared__ double s1[FIN_RG][FIN_COLS];
+  __shared__ double s2[FIN_RG][FIN_COLS];
+  const int c = threadIdx.x % FIN_COLS, rg = threadIdx.x / FIN_COLS;
+  const int n = blockIdx.x * FIN_COLS + c;
+  const int split = blockIdx.y;
   double a1 = 0.0, a2 = 0.0;
   if (n < N) {
     for (int sgi = 0; sgi < 2; sgi++) {
       const StatSeg sg = sgi == 0 ? sg0 : sg1;
       if (sg.stats == nullptr) continue;
-      for (int i = rg; i < sg.ntiles; i += FIN_RG) {
+      const int per = (sg.ntiles + FIN_SPLITS - 1) / FIN_SPLITS;
+      const int i0 = split * per;
+      int i1 = i0 + per;
+      if (i1 > sg.ntiles) i1 = sg.ntiles;
+      for (int i = i0 + rg; i < i1; i += FIN_RG) {
         long left = sg.seg_rows - (long)(i % sg.tps) * tile_rows;
-        double cnt = (double)(left < tile_rows ? left : tile_rows);
-        double s = (double)sg.stats[(long)i * 2 * N + n];
-        double m2 = (double)sg.stats[(long)i * 2 * N + N + n];
-        a1 += s;
-        a2 += m2 + s * s / cnt;
+        const double cnt = (double)(left < tile_rows ? left : tile_rows);
+        const double sm = (double)sg.stats[(long)i * 2 * N + n];
+        const double m2 = (double)sg.stats[(long)i * 2 * N + N + n];
+        a1 += sm;
+        a2 += m2 + sm * sm / cnt;
       }
     }
   }
-  s1[rg][cg] = a1;
-  s2[rg][cg] = a2;
+  s1[rg][c] = a1;
+  s2[rg][c] = a2;
   __syncthreads();
-  for (int st = FIN_RG / 2; st > 0; st >>= 1) {
-    if (rg < st) {
-      s1[rg][cg] += s1[rg + st][cg];
-      s2[rg][cg] += s2[rg + st][cg];
-    }
-    __syncthreads();
-  }
   if (rg == 0 && n < N) {
-    double mean = s1[0][cg] / (double)M;
-    double var = s2[0][cg] / (double)M - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    float meanf = (float)mean;
-    mean_o[n] = meanf;
-    invstd_o[n] = invstd;
-    float sc = gamma[n] * invstd;
-    scale_o[n] = sc;
-    shift_o[n] = beta[n] - meanf * sc;
-    if (running_mean != nullptr) {
-      double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-      running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * meanf;
-      running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < FIN_RG; q++) {
+      t1 += s1[q][c];
+      t2 += s2[q][c];
     }
+    part[((long)split * 2) * N + n] = t1;
+    part[((long)split * 2 + 1) * N + n] = t2;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bn_finalize(const double* __restrict__ part, long M,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* running_mean, float* running_var, float momentum, float eps,
+                                                    float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int N) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int sp = 0; sp < FIN_SPLITS; sp++) {
+    t1 += part[((long)sp * 2) * N + n];
+    t2 += part[((long)sp * 2 + 1) * N + n];
+  }
+  const double mean = t1 / (double)M;
+  double var = t2 / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  mean_o[n] = meanf;
+  invstd_o[n] = invstd;
+  const float sc = gamma[n] * invstd;
+  scale_o[n] = sc;
+  shift_o[n] = beta[n] - meanf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * meanf;
+    running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
   }
 }
 
@@ -303,27 +328,38 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
   gy[idx] = fmaf(k, go, fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long M, float* dgamma, float* dbeta,
-                                  float* coef, int accumulate, int F) {
-  // one wave per column: lanes stride over blocks
-  const int c = blockIdx.x;
-  const int lane = threadIdx.x;
+// block = 32 adjacent columns (128-byte coalesced reads of one partial row) x 16 row groups over the nblk partial rows
+constexpr int BFIN_COLS = 32, BFIN_RG = 16;
+__global__ __launch_bounds__(BFIN_COLS * BFIN_RG) void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long M,
+                                                                         float* dgamma, float* dbeta, float* coef,
+                                                                         int accumulate, int F) {
+  __shared__ double s0[BFIN_RG][BFIN_COLS];
+  __shared__ double s1[BFIN_RG][BFIN_COLS];
+  const int cc = threadIdx.x % BFIN_COLS, rg = threadIdx.x / BFIN_COLS;
+  const int c = blockIdx.x * BFIN_COLS + cc;
   double a0 = 0.0, a1 = 0.0;
-  for (int i = lane; i < nblk; i += 64) {
-    a0 += (double)part[(long)i * 2 * F + c];
-    a1 += (double)part[(long)i * 2 * F + F + c];
+  if (c < F) {
+    for (int i = rg; i < nblk; i += BFIN_RG) {
+      a0 += (double)part[(long)i * 2 * F + c];
+      a1 += (double)part[(long)i * 2 * F + F + c];
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    a0 += __shfl_xor(a0, o);
-    a1 += __shfl_xor(a1, o);
-  }
-  if (lane == 0) {
-    float db = (float)a0, dg = (float)a1;
+  s0[rg][cc] = a0;
+  s1[rg][cc] = a1;
+  __syncthreads();
+  if (rg == 0 && c < F) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < BFIN_RG; q++) {
+      t0 += s0[q][cc];
+      t1 += s1[q][cc];
+    }
+    const float db = (float)t0, dg = (float)t1;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
     if (coef) {
-      coef[c] = (float)(a0 / (double)M);
-      coef[F + c] = (float)(a1 / (double)M);
+      coef[c] = (float)(t0 / (double)M);
+      coef[F + c] = (float)(t1 / (double)M);
     }
   }
 }
@@ -443,6 +479,38 @@ __global__ __launch_bounds__(256) void k_lerp_bwd_add_half(const float* __restri
 
 using namespace p2m;
 
+// scratch of the two-stage finalize: FIN_SPLITS x 2 x N doubles, one buffer per (device, stream) - the calls of one
+// stream are ordered, so stage 1 of the next call cannot overtake stage 2 of the previous one.  Internal to the library
+// (never visible to the caller), allocated on first use, kept for the life of the process.
+namespace {
+constexpr int FIN_MAXN = 4096;
+std::map<std::pair<int, void*>, double*> g_fin;
+std::mutex g_fin_mu;
+double* fin_scratch(int N, void* stream) {
+  if (N > FIN_MAXN) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_fin_mu);
+  double*& buf = g_fin[{dev, stream}];
+  if (buf == nullptr && hipMalloc((void**)&buf, sizeof(double) * 2 * FIN_SPLITS * FIN_MAXN) != hipSuccess) buf = nullptr;
+  return buf;
+}
+int finalize_launch(const StatSeg& a, const StatSeg& b, long M, int tile_rows, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                    float* scale, float* shift, int N, hipStream_t s, const char* what) {
+  double* part = fin_scratch(N, (void*)s);
+  if (part == nullptr) {
+    set_error("%s: no scratch for %d columns (max %d) or hipMalloc failed", what, N, FIN_MAXN);
+    return P2M_ERR_NOMEM;
+  }
+  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(N, FIN_COLS), FIN_SPLITS), dim3(FIN_COLS * FIN_RG), 0, s, a, b, tile_rows, N,
+                     part);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, part, M, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, invstd, scale, shift, N);
+  return check_launch(what);
+}
+}  // namespace
+
 extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                float* invstd, float* scale, float* shift, int32_t N, int32_t tile_rows, void* stream) {
@@ -450,10 +518,8 @@ extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, co
   P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
   P2M_CHECK_ARG(tile_rows > 0 && ntiles == cdiv(M, tile_rows), "ntiles does not match M / tile_rows");
   StatSeg a{stats, ntiles, ntiles, (long)M}, b{nullptr, 0, 1, 0};
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, a, b,
-                     (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                     shift, N);
-  return check_launch("bn_finalize");
+  return finalize_launch(a, b, (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                         scale, shift, N, (hipStream_t)stream, "bn_finalize");
 }
 
 extern "C" int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b,
@@ -466,9 +532,8 @@ extern "C" int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t
   StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a};
   StatSeg b{stats_b, stats_b ? B * tps_b : 0, tps_b > 0 ? tps_b : 1, (long)rows_b};
   const long M = (long)B * ((long)rows_a + (stats_b ? (long)rows_b : 0));
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, FIN_CG)), dim3(FIN_CG * FIN_RG), 0, (hipStream_t)stream, a, b, M,
-                     tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N);
-  return check_launch("bn_finalize_rows");
+  return finalize_launch(a, b, M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                         shift, N, (hipStream_t)stream, "bn_finalize_rows");
 }
 
 extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
@@ -534,8 +599,8 @@ extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* s
 extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                                    float* coef, int32_t accumulate, int32_t F, void* stream) {
   P2M_CHECK_ARG(part && nblk > 0 && M > 0 && F > 0, "null pointer or empty shape");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(F), dim3(64), 0, (hipStream_t)stream, part, nblk, (long)M, dgamma, dbeta,
-                     coef, accumulate, F);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(F, BFIN_COLS)), dim3(BFIN_COLS * BFIN_RG), 0, (hipStream_t)stream, part,
+                     nblk, (long)M, dgamma, dbeta, coef, accumulate, F);
   return check_launch("bn_bwd_finalize");
 }
 
