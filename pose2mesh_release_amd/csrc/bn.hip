@@ -328,18 +328,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
   gy[idx] = fmaf(k, go, fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
 }
 
-// block = 32 adjacent columns (128-byte coalesced reads of one partial row) x 16 row groups over the nblk partial rows
-constexpr int BFIN_COLS = 32, BFIN_RG = 16;
-__global__ __launch_bounds__(BFIN_COLS * BFIN_RG) void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, long M,
-                                                                         float* dgamma, float* dbeta, float* coef,
-                                                                         int accumulate, int F) {
-  __shared__ double s0[BFIN_RG][BFIN_COLS];
-  __shared__ double s1[BFIN_RG][BFIN_COLS];
-  const int cc = threadIdx.x % BFIN_COLS, rg = threadIdx.x / BFIN_COLS;
-  const int c = blockIdx.x * BFIN_COLS + cc;
+// Two stages like the forward finalize.  Stage 1: block = 32 adjacent columns of BOTH partial kinds (128-byte coalesced
+// reads) x 8 row groups, one of FIN_SPLITS slices of the nblk partial rows; stage 2: one thread per column.
+__global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_bwd_partial(const float* __restrict__ part, int nblk, int F,
+                                                                      double* __restrict__ out) {
+  __shared__ double s0[FIN_RG][FIN_COLS];
+  __shared__ double s1[FIN_RG][FIN_COLS];
+  const int cc = threadIdx.x % FIN_COLS, rg = threadIdx.x / FIN_COLS;
+  const int c = blockIdx.x * FIN_COLS + cc;
+  const int split = blockIdx.y;
+  const int per = (nblk + FIN_SPLITS - 1) / FIN_SPLITS;
+  const int i0 = split * per;
+  int i1 = i0 + per;
+  if (i1 > nblk) i1 = nblk;
   double a0 = 0.0, a1 = 0.0;
   if (c < F) {
-    for (int i = rg; i < nblk; i += BFIN_RG) {
+    for (int i = i0 + rg; i < i1; i += FIN_RG) {
       a0 += (double)part[(long)i * 2 * F + c];
       a1 += (double)part[(long)i * 2 * F + F + c];
     }
@@ -350,17 +354,30 @@ __global__ __launch_bounds__(BFIN_COLS * BFIN_RG) void k_bn_bwd_finalize(const f
   if (rg == 0 && c < F) {
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < BFIN_RG; q++) {
+    for (int q = 0; q < FIN_RG; q++) {
       t0 += s0[q][cc];
       t1 += s1[q][cc];
     }
-    const float db = (float)t0, dg = (float)t1;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-    if (coef) {
-      coef[c] = (float)(t0 / (double)M);
-      coef[F + c] = (float)(t1 / (double)M);
-    }
+    out[((long)split * 2) * F + c] = t0;
+    out[((long)split * 2 + 1) * F + c] = t1;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bn_bwd_finalize(const double* __restrict__ part, long M, float* dgamma,
+                                                        float* dbeta, float* coef, int accumulate, int F) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= F) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int sp = 0; sp < FIN_SPLITS; sp++) {
+    t0 += part[((long)sp * 2) * F + c];
+    t1 += part[((long)sp * 2 + 1) * F + c];
+  }
+  const float db = (float)t0, dg = (float)t1;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  if (coef) {
+    coef[c] = (float)(t0 / (double)M);
+    coef[F + c] = (float)(t1 / (double)M);
   }
 }
 
@@ -479,9 +496,9 @@ __global__ __launch_bounds__(256) void k_lerp_bwd_add_half(const float* __restri
 
 using namespace p2m;
 
-// scratch of the two-stage finalize: FIN_SPLITS x 2 x N doubles, one buffer per (device, stream) - the calls of one
-// stream are ordered, so stage 1 of the next call cannot overtake stage 2 of the previous one.  Internal to the library
-// (never visible to the caller), allocated on first use, kept for the life of the process.
+// scratch of the two-stage finalize kernels: FIN_SPLITS x 2 x N doubles, one buffer per (device, stream) - the calls of
+// one stream are ordered, so stage 1 of the next call cannot overtake stage 2 of the previous one.  Internal to the
+// library (never visible to the caller), allocated on first use, kept for the life of the process.
 namespace {
 constexpr int FIN_MAXN = 4096;
 std::map<std::pair<int, void*>, double*> g_fin;
@@ -599,8 +616,16 @@ extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* s
 extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                                    float* coef, int32_t accumulate, int32_t F, void* stream) {
   P2M_CHECK_ARG(part && nblk > 0 && M > 0 && F > 0, "null pointer or empty shape");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(F, BFIN_COLS)), dim3(BFIN_COLS * BFIN_RG), 0, (hipStream_t)stream, part,
-                     nblk, (long)M, dgamma, dbeta, coef, accumulate, F);
+  hipStream_t s = (hipStream_t)stream;
+  double* scratch = fin_scratch(F, stream);
+  if (scratch == nullptr) {
+    set_error("p2m_bn_bwd_finalize: no scratch for %d columns (max %d) or hipMalloc failed", F, FIN_MAXN);
+    return P2M_ERR_NOMEM;
+  }
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(cdiv(F, FIN_COLS), FIN_SPLITS), dim3(FIN_COLS * FIN_RG), 0, s, part, nblk, F,
+                     scratch);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(F, 64)), dim3(64), 0, s, scratch, (long)M, dgamma, dbeta, coef,
+                     accumulate, F);
   return check_launch("bn_bwd_finalize");
 }
 
