@@ -201,12 +201,27 @@ int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t F
  * CSR row is the diagonal alone and identical for the whole level, so T1 = a x, T2 = b x and the contraction of
  * cheby_graph_conv.py:37 needs only K = Fin with W_eff = W0 + a W1 + b W2 -- 2/3 of the MFMA work on 30-40 % of the
  * rows disappears, and the basis planes are only formed (compactly, [B*n_real, F]) for real vertices.
- * Rows are selected by row_set: 1 = real vertices, 2 = fake vertices (sorted id lists baked in the handle); tensors
+ * Rows are selected by row_set: 1 = real vertices, 2 = fake vertices (sorted id lists baked in the handle; 3 / 4: the
+ * paired sets below, over V/2 rows); tensors
  * keep their (B, V, F) layout, only the launches iterate over the subset.  BatchNorm statistics still cover ALL
  * rows (the reference includes fake vertices, cheby_graph_conv.py:39): p2m_bn_finalize_rows merges both launches. */
 int p2m_graph_split_info(p2m_graph_t g, int32_t counts[2] /* n_real, n_fake */, float coef[2] /* a, b */);
 int p2m_cheb_basis_fwd_real(p2m_graph_t g, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
                             int32_t in_shift, void* stream);
+/* ---- paired operator: the backward of an un-pooled conv at the COARSE resolution ------------------------------
+ * A conv whose input was un-pooled x2 (meshnet.py:71-78,111) sees X_fine[r] = X_coarse[r >> 1], so with S = the
+ * pair-sum (the un-pool's transpose) and L symmetric:
+ *     dX_coarse = S ([g | L g | L2 g] W3) = [S g | S L g | S L2 g] W3,     dW = X_coarse^T [S g | S L g | S L2 g]
+ * -- both contractions run over V/2 rows.  The handle of the FINE level bakes S L and S L2 as one more tile plan
+ * (row c = merged row 2c + merged row 2c+1) and two more row sets over the coarse index space: row_set 3 = coarse
+ * vertices with at least one real child (compact plane order), row_set 4 = both children fake (S L g = a S g,
+ * S L2 g = b S g: effective weight, as for row_set 2).  counts = {0, 0}: no paired operator on this level.
+ * p2m_cheb_basis_pair: P1c = S L g, P2c = S L2 g over row_set 3, compact [B*counts[0], F]; g: [B*V, F];
+ * F = 32, 64 or a multiple of 128.  (S g itself is p2m_pair_sum.)                                                   */
+int p2m_graph_pair_info(p2m_graph_t g, int32_t counts[2] /* n_pair_real, n_pair_fake */);
+/* tiles of the LDS-staged basis kernel's plans: [in_shift 0, in_shift 1, paired]; 0 = no plan, the row kernel runs */
+int p2m_graph_plan_info(p2m_graph_t g, int32_t ntiles[3]);
+int p2m_cheb_basis_pair(p2m_graph_t g, const float* G, float* P1c, float* P2c, int32_t B, int32_t F, void* stream);
 /* C[b*V + ids[i], :] = [A0[..] | A1 | A2] Bm + bias (+ addend): A0 is read at the actual row (>> a0_shift), A1/A2 at
  * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.                  */
 int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,

@@ -470,6 +470,25 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
   return check_launch("cheb_basis_fwd");
 }
 
+extern "C" int p2m_cheb_basis_pair(p2m_graph_t gh, const float* G, float* P1c, float* P2c, int32_t B, int32_t F,
+                                   void* stream) {
+  P2M_CHECK_ARG(gh && G && P1c && P2c && F > 0, "null pointer or empty shape");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  const TilePlan& pl = g.plan[2];
+  P2M_CHECK_ARG(pl.ntiles > 0, "this level has no paired operator (p2m_graph_pair_info)");
+  P2M_CHECK_ARG(F == 32 || F == 64 || F % 128 == 0, "feature width must be 32, 64 or a multiple of 128");
+  if (B <= 0) return P2M_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int spb = 8;
+  const long x_rows = g.V;
+  const int nset = g.n_pair_real;
+  const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (F >= 128 ? F / 128 : 1), 8) * 8);
+  if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, G, P1c, P2c, B, F, x_rows, nset, spb);
+  else if (F == 64) hipLaunchKernelGGL(k_basis_tile<16>, grid, dim3(512), 0, s, pl, G, P1c, P2c, B, F, x_rows, nset, spb);
+  else hipLaunchKernelGGL(k_basis_tile<32>, grid, dim3(512), 0, s, pl, G, P1c, P2c, B, F, x_rows, nset, spb);
+  return check_launch("cheb_basis_pair");
+}
+
 extern "C" int p2m_cheb_basis_fwd_real(p2m_graph_t gh, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
                                        int32_t in_shift, void* stream) {
   P2M_CHECK_ARG(gh && X && T1c && T2c && F > 0, "null pointer or empty shape");

@@ -43,6 +43,73 @@ static int upload(const void* src, size_t bytes, void** dst) {
   return P2M_OK;
 }
 
+// rows of a sparse operator, flattened: (source row, a, b) per entry
+struct FlatRows {
+  std::vector<int> rp{0}, src;
+  std::vector<float> a, b;
+  void push(int s, float x, float y) { src.push_back(s); a.push_back(x); b.push_back(y); }
+  void end_row() { rp.push_back((int)src.size()); }
+  int n() const { return (int)rp.size() - 1; }
+};
+
+// Greedy tiles of consecutive rows (<= TILE_RMAX rows, <= TILE_UCAP distinct source rows, <= TILE_ECAP entries) for
+// k_basis_tile.  A row that does not fit a tile on its own leaves the plan empty (ntiles == 0: the row kernel stays in
+// charge).  Entry order = the order of `fr` (the merged-CSR order): the tile kernel's fmaf chain is the row kernel's.
+static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
+  std::vector<int> tile_row{0}, tile_u{0}, ucol, erow{0};
+  std::vector<float4> ent;
+  std::vector<int> local(nsrc, -1), uni;
+  const int n = fr.n();
+  int i = 0;
+  while (i < n) {
+    uni.clear();
+    int rows = 0, entries = 0;
+    while (i + rows < n && rows < TILE_RMAX) {
+      const int r = i + rows;
+      const size_t before = uni.size();
+      for (int j = fr.rp[r]; j < fr.rp[r + 1]; j++) {
+        const int s = fr.src[j];
+        if (local[s] < 0) { local[s] = 1; uni.push_back(s); }
+      }
+      const int len = fr.rp[r + 1] - fr.rp[r];
+      if (rows > 0 && ((int)uni.size() > TILE_UCAP || entries + len > TILE_ECAP)) {
+        for (size_t q = before; q < uni.size(); q++) local[uni[q]] = -1;   // undo this row
+        uni.resize(before);
+        break;
+      }
+      entries += len;
+      rows++;
+    }
+    if ((int)uni.size() > TILE_UCAP || entries > TILE_ECAP) return P2M_OK;   // a single row too large: no plan
+    std::sort(uni.begin(), uni.end());
+    for (size_t q = 0; q < uni.size(); q++) local[uni[q]] = (int)q;
+    for (int r = i; r < i + rows; r++) {
+      for (int j = fr.rp[r]; j < fr.rp[r + 1]; j++) {
+        float4 e4;
+        e4.x = fr.a[j]; e4.y = fr.b[j]; e4.w = 0.f;
+        const int lc = local[fr.src[j]];
+        memcpy(&e4.z, &lc, sizeof(int));
+        ent.push_back(e4);
+      }
+      erow.push_back((int)ent.size());
+    }
+    for (int c : uni) { ucol.push_back(c); local[c] = -1; }
+    i += rows;
+    tile_row.push_back(i);
+    tile_u.push_back((int)ucol.size());
+  }
+  if (tile_row.size() < 2) return P2M_OK;
+  int rc;
+  if ((rc = upload(tile_row.data(), sizeof(int) * tile_row.size(), (void**)&pl.tile_row)) != P2M_OK ||
+      (rc = upload(tile_u.data(), sizeof(int) * tile_u.size(), (void**)&pl.tile_u)) != P2M_OK ||
+      (rc = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
+      (rc = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
+      (rc = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK)
+    return rc;
+  pl.ntiles = (int)tile_row.size() - 1;
+  return P2M_OK;
+}
+
 }  // namespace p2m
 
 using namespace p2m;
@@ -115,67 +182,52 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   g->n_fake = (int)fake_ids.size();
   // tile plans of the LDS-staged basis kernel (levels with a real/fake split only; small levels keep the row kernel)
   if (g->n_fake > 0 && g->n_real >= 256) {
-    for (int sh = 0; sh < 2; sh++) {
+    int rc2 = P2M_OK;
+    for (int sh = 0; sh < 2 && rc2 == P2M_OK; sh++) {
       if (sh == 1 && (V & 1)) break;
-      std::vector<int> tile_row{0}, tile_u{0}, ucol, erow{0};
-      std::vector<float4> ent;
-      std::vector<int> local(V, -1), uni;
-      int i = 0;
-      const int n = g->n_real;
-      while (i < n) {
-        uni.clear();
-        int rows = 0, entries = 0;
-        while (i + rows < n && rows < TILE_RMAX) {
-          const int v = real_ids[i + rows];
-          const size_t before = uni.size();
-          for (int j = rp[v]; j < rp[v + 1]; j++) {
-            const int src = mc[j] >> sh;
-            if (local[src] < 0) { local[src] = 1; uni.push_back(src); }
-          }
-          const int len = rp[v + 1] - rp[v];
-          if (rows > 0 && ((int)uni.size() > TILE_UCAP || entries + len > TILE_ECAP)) {
-            for (size_t q = before; q < uni.size(); q++) local[uni[q]] = -1;   // undo this row
-            uni.resize(before);
-            break;
-          }
-          entries += len;
-          rows++;
-        }
-        if ((int)uni.size() > TILE_UCAP || entries > TILE_ECAP) {      // a single row too large for a tile
-          for (int c : uni) local[c] = -1;
-          tile_row.assign(1, 0);
-          break;
-        }
-        std::sort(uni.begin(), uni.end());
-        for (size_t q = 0; q < uni.size(); q++) local[uni[q]] = (int)q;
-        for (int r = 0; r < rows; r++) {
-          const int v = real_ids[i + r];
-          for (int j = rp[v]; j < rp[v + 1]; j++) {
-            float4 e4;
-            e4.x = ma[j]; e4.y = mb[j]; e4.w = 0.f;
-            const int lc = local[mc[j] >> sh];
-            memcpy(&e4.z, &lc, sizeof(int));
-            ent.push_back(e4);
-          }
-          erow.push_back((int)ent.size());
-        }
-        for (int c : uni) { ucol.push_back(c); local[c] = -1; }
-        i += rows;
-        tile_row.push_back(i);
-        tile_u.push_back((int)ucol.size());
+      FlatRows fr;
+      for (int v : real_ids) {
+        for (int j = rp[v]; j < rp[v + 1]; j++) fr.push(mc[j] >> sh, ma[j], mb[j]);
+        fr.end_row();
       }
-      if (tile_row.size() < 2) continue;                                 // no plan: the row kernel stays in charge
-      TilePlan& pl = g->plan[sh];
-      int rc2;
-      if ((rc2 = upload(tile_row.data(), sizeof(int) * tile_row.size(), (void**)&pl.tile_row)) != P2M_OK ||
-          (rc2 = upload(tile_u.data(), sizeof(int) * tile_u.size(), (void**)&pl.tile_u)) != P2M_OK ||
-          (rc2 = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
-          (rc2 = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
-          (rc2 = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK) {
-        p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
-        return rc2;
+      rc2 = build_tile_plan(fr, V >> sh, g->plan[sh]);
+    }
+    // PAIRED operator (plan[2]): row c = (merged row 2c) + (merged row 2c+1), over the coarse vertices with at least one
+    // real child.  S L g and S L2 g (S = the x2 un-pool's transpose, the pair-sum) in ONE pass over g: the backward
+    // of a conv whose input was un-pooled then runs both of its contractions at the COARSE resolution (meshnet.py).
+    if (rc2 == P2M_OK && !(V & 1)) {
+      std::vector<char> is_fake(V, 0);
+      for (int v : fake_ids) is_fake[v] = 1;
+      std::vector<int> preal, pfake;
+      FlatRows fr;
+      for (int c = 0; c < V / 2; c++) {
+        const int u = 2 * c, w = 2 * c + 1;
+        if (is_fake[u] && is_fake[w]) { pfake.push_back(c); continue; }
+        preal.push_back(c);
+        int i = rp[u], j = rp[w];
+        while (i < rp[u + 1] || j < rp[w + 1]) {                     // two sorted rows -> one, equal columns summed
+          const int ci = i < rp[u + 1] ? mc[i] : V, cj = j < rp[w + 1] ? mc[j] : V;
+          if (ci < cj) { fr.push(ci, ma[i], mb[i]); i++; }
+          else if (cj < ci) { fr.push(cj, ma[j], mb[j]); j++; }
+          else { fr.push(ci, (float)((double)ma[i] + (double)ma[j]), (float)((double)mb[i] + (double)mb[j])); i++; j++; }
+        }
+        fr.end_row();
       }
-      pl.ntiles = (int)tile_row.size() - 1;
+      if (preal.size() >= 128) {
+        rc2 = build_tile_plan(fr, V, g->plan[2]);
+        if (rc2 == P2M_OK && g->plan[2].ntiles > 0) {
+          g->n_pair_real = (int)preal.size();
+          g->n_pair_fake = (int)pfake.size();
+          preal.resize(preal.size() + 64, 0);
+          pfake.resize(pfake.size() + 64, 0);
+          if ((rc2 = upload(preal.data(), sizeof(int) * preal.size(), (void**)&g->pair_real_ids)) == P2M_OK)
+            rc2 = upload(pfake.data(), sizeof(int) * pfake.size(), (void**)&g->pair_fake_ids);
+        }
+      }
+    }
+    if (rc2 != P2M_OK) {
+      p2m_graph_destroy(reinterpret_cast<p2m_graph_t>(g));
+      return rc2;
     }
   }
   // 64 zero entries of slack: the pipelined kernels prefetch ids a few 16-row stages ahead without bounds checks
@@ -209,6 +261,8 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->b) (void)hipFree(g->b);
   if (g->real_ids) (void)hipFree(g->real_ids);
   if (g->fake_ids) (void)hipFree(g->fake_ids);
+  if (g->pair_real_ids) (void)hipFree(g->pair_real_ids);
+  if (g->pair_fake_ids) (void)hipFree(g->pair_fake_ids);
   for (TilePlan& pl : g->plan) {
     if (pl.tile_row) (void)hipFree(pl.tile_row);
     if (pl.tile_u) (void)hipFree(pl.tile_u);
@@ -237,6 +291,21 @@ extern "C" int p2m_graph_split_info(p2m_graph_t gh, int32_t counts[2], float coe
   counts[1] = g->n_fake;
   coef[0] = g->fake_a;
   coef[1] = g->fake_b;
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_pair_info(p2m_graph_t gh, int32_t counts[2]) {
+  P2M_CHECK_ARG(gh && counts, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  counts[0] = g->plan[2].ntiles > 0 ? g->n_pair_real : 0;
+  counts[1] = g->plan[2].ntiles > 0 ? g->n_pair_fake : 0;
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_plan_info(p2m_graph_t gh, int32_t ntiles[3]) {
+  P2M_CHECK_ARG(gh && ntiles, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  for (int i = 0; i < 3; i++) ntiles[i] = g->plan[i].ntiles;
   return P2M_OK;
 }
 

@@ -1792,7 +1792,7 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
-  P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
+  P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3, "plane count must be 1..3");
   P2M_CHECK_ARG(Ka > 0 && Ka % BK == 0 && N > 0 && N % 32 == 0, "Ka and N must be positive multiples of 32");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
@@ -1818,7 +1818,7 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
 
 // rows per sample tile count of a row set (for the BatchNorm finalize): tiles_per_sample = ceil(n / 128)
 extern "C" int32_t p2m_rows_tiles_per_sample(p2m_graph_t gh, int32_t row_set) {
-  if (!gh || (row_set != 1 && row_set != 2)) return 0;
+  if (!gh || !row_set_valid(row_set)) return 0;
   const Graph& gr = *reinterpret_cast<const Graph*>(gh);
   return cdiv(row_set_of(gr, row_set).n, BM);
 }
@@ -1876,7 +1876,7 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
                                 int32_t arith, void* stream) {
   P2M_CHECK_ARG(gh && A && G0 && P, "null pointer");
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3, "unknown arithmetic");
-  P2M_CHECK_ARG(row_set == 1 || row_set == 2, "row_set must be 1 (real vertices) or 2 (fake vertices)");
+  P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
   P2M_CHECK_ARG(nplanesG >= 1 && nplanesG <= 3 && splits >= 1, "plane count must be 1..3, splits >= 1");
   P2M_CHECK_ARG(Ka % 32 == 0 && Gc % 32 == 0, "Ka and Gc must be multiples of 32");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");

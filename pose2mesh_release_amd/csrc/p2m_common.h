@@ -51,7 +51,14 @@ struct Graph {
   int* real_ids = nullptr;   // [n_real]
   int* fake_ids = nullptr;   // [n_fake]
   float fake_a = 0.f, fake_b = 0.f;
-  TilePlan plan[2];          // [in_shift]; ntiles == 0: no plan (no real/fake split on this level)
+  TilePlan plan[3];          // [in_shift] and [2] = the paired operator; ntiles == 0: no plan
+  // Paired operator (plan[2]): output row c = merged row 2c + merged row 2c+1 of this level, i.e. S L and S L2 with S the
+  // pair-sum (the transpose of the x2 un-pool).  Defined over the V/2 vertices of the next-coarser level: those with at
+  // least one real child here (pair_real_ids, compact plane order) and those whose children are both fake
+  // (pair_fake_ids: S L g = fake_a S g, S L2 g = fake_b S g).
+  int n_pair_real = 0, n_pair_fake = 0;
+  int* pair_real_ids = nullptr;   // [n_pair_real]  coarse vertex ids, ascending
+  int* pair_fake_ids = nullptr;   // [n_pair_fake]
 };
 
 // Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)
@@ -60,11 +67,15 @@ struct RowSet {
   int n = 0;
   int V = 0;
 };
-static inline RowSet row_set_of(const Graph& g, int which) {   // 1 = real vertices, 2 = fake vertices
+// 1 = real vertices, 2 = fake vertices; 3 / 4 = the paired sets, over the V/2 rows of the next-coarser level
+static inline bool row_set_valid(int which) { return which >= 1 && which <= 4; }
+static inline RowSet row_set_of(const Graph& g, int which) {
   RowSet r;
-  r.V = g.V;
+  r.V = which >= 3 ? g.V / 2 : g.V;
   if (which == 1) { r.ids = g.real_ids; r.n = g.n_real; }
-  else { r.ids = g.fake_ids; r.n = g.n_fake; }
+  else if (which == 2) { r.ids = g.fake_ids; r.n = g.n_fake; }
+  else if (which == 3) { r.ids = g.pair_real_ids; r.n = g.n_pair_real; }
+  else { r.ids = g.pair_fake_ids; r.n = g.n_pair_fake; }
   return r;
 }
 

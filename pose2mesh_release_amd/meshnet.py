@@ -401,6 +401,29 @@ class _MeshNetFn(torch.autograd.Function):
                 dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
+            elif _bwd_forward_form(L) and gph.split and x_shift and gph.pair \
+                    and (L.Fout in (32, 64) or L.Fout % 128 == 0):
+                # the input was un-pooled (X_fine[r] = X[r >> 1]): with S = the pair-sum, dX = [S g | S L g | S L2 g] W3
+                # and dW = X^T [S g | S L g | S L2 g] -- both contractions run over V/2 rows; S L and S L2 are one
+                # baked operator (the level's paired tile plan), its rows split into "has a real child" / "both
+                # children fake" like the real / fake split of the forward
+                Mc = M >> 1
+                dX = torch.empty((Mc, L.Fin), device=gy.device, dtype=torch.float32)
+                add = ops.pair_sum(G, Mc, Fblk) if fuse_res else None
+                Wl = params[P[f"cl.{L.ci}.weight"]]
+                opb = wc.get((L.ci, "split_bwd"), Wl,
+                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
+                P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb)
+                with side_ctx(keep, X, P0, E1, E2):
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True)
+                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False)
+                    tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                    dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
+                                                     L.Fin, *(tg or ()))
+                    keep.extend((Pw, Pb, Pw2, Pb2))
+                if tg is None:
+                    grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                del Pw, Pb, Pw2, Pb2, P0, E1, E2, add
             elif _bwd_forward_form(L) and gph.split:
                 # forward-form backward, split into real / fake vertex launches (see the forward)
                 dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)

@@ -96,6 +96,9 @@ def _timed(name, work):
 
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
 DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
+# backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
+# with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
+PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
 
 
 class DeviceGraph:
@@ -132,6 +135,16 @@ class DeviceGraph:
         self.fake_a, self.fake_b = float(coef[0]), float(coef[1])
         # split the launches into real / fake vertices when it pays (big levels with many padding vertices)
         self.split = SPLIT_FAKE and self.V >= 512 and self.n_fake >= 0.15 * self.V
+        # paired operator (backward of un-pooled convs at the coarse resolution): row sets 3 / 4 over V/2 rows
+        check(_lib.hip().p2m_graph_pair_info(self.handle, ctypes.byref(cnt)), "p2m_graph_pair_info")
+        self.n_pair_real, self.n_pair_fake = int(cnt[0]), int(cnt[1])
+        self.pair = PAIR_BWD and self.split and self.n_pair_real > 0
+        nt = (ctypes.c_int32 * 3)()
+        check(_lib.hip().p2m_graph_plan_info(self.handle, ctypes.byref(nt)), "p2m_graph_plan_info")
+        self.plan_tiles = tuple(int(v) for v in nt)
+
+    def set_size(self, row_set):
+        return (self.n_real, self.n_fake, self.n_pair_real, self.n_pair_fake)[row_set - 1]
 
     def __del__(self):
         try:
@@ -308,7 +321,7 @@ def weight_split(Bm):
 def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None):
     """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None.
     Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
-    n = g.n_real if row_set == 1 else g.n_fake
+    n = g.set_size(row_set)
     st = None
     if stats:
         tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, row_set))
@@ -353,6 +366,27 @@ def split_operands(Bm, Ka, N, fake_a, fake_b):
     return weight_split(Bm), We, weight_split(We)
 
 
+def cheb_basis_pair(g, G, B, F):
+    """S L g and S L2 g (S = pair-sum) over the coarse vertices with a real child, compact [B*n_pair_real, F]."""
+    P1 = torch.empty((B * g.n_pair_real, F), device=G.device, dtype=torch.float32)
+    P2 = torch.empty((B * g.n_pair_real, F), device=G.device, dtype=torch.float32)
+    with _timed("cheb_basis_fwd", (4.0 * F * B * (g.V + 2.0 * g.n_pair_real), 12.0 * B * g.V * F)):
+        check(_lib.hip().p2m_cheb_basis_pair(g.handle, _p(_req(G, "G")), _p(P1), _p(P2), B, F, _stream()),
+              "p2m_cheb_basis_pair")
+    return P1, P2
+
+
+def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands):
+    """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
+    C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c)."""
+    P0 = pair_sum(Gy, B * (g.V // 2), Ka)
+    P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
+    Bx, We, Wex = operands
+    gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
+    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
+    return P0, P1c, P2c
+
+
 def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None):
     """One split contraction: basis planes of the real vertices, the real-vertex GEMM (K = 3*Ka), then the fake-vertex
     GEMM (K = Ka, W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's
@@ -371,7 +405,7 @@ TN_TARGET_BLOCKS = 768
 
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
     """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks)."""
-    n = g.n_real if row_set == 1 else g.n_fake
+    n = g.set_size(row_set)
     N = len(G) * Gc
     ntiles = ((Ka + 127) // 128) * ((N + 127) // 128)
     splits = max(1, -(-TN_TARGET_BLOCKS // (B * ntiles)))

@@ -27,6 +27,22 @@ def _rand_graph(V, seed, fake_frac=0.3):
     return (L / 3.0 - sp.identity(V)).tocsr()
 
 
+def _band_graph(V, seed, fake_frac=0.4):
+    """Bounded-degree variant (ring + two chords over the real vertices, then a random renumbering of ALL vertices so the
+    isolated fake vertices end up anywhere, as in a coarsening tree): every merged row fits a tile of the LDS basis kernel."""
+    nreal = max(8, int(V * (1 - fake_frac)))
+    i = np.arange(nreal)
+    rows = np.concatenate([i, (i + 1) % nreal, i, (i + 5) % nreal, i, (i + 17) % nreal])
+    cols = np.concatenate([(i + 1) % nreal, i, (i + 5) % nreal, i, (i + 17) % nreal, i])
+    A = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(V, V)).tocsr()
+    A.data[:] = 1.0
+    d = np.asarray(A.sum(axis=0)).ravel() + np.spacing(np.float64(0))
+    Dm = sp.diags(1 / np.sqrt(d))
+    L = (sp.identity(V) - Dm @ A @ Dm) / 3.0 - sp.identity(V)
+    perm = np.random.default_rng(seed).permutation(V)
+    return L.tocsr()[perm][:, perm].tocsr()
+
+
 @pytest.fixture(scope="module")
 def ops(hip_libs):
     from pose2mesh_release_amd import ops as o
@@ -348,9 +364,9 @@ def test_bf16x3_error_is_fp32_class(ops, monkeypatch, M, Ka, N):
 def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
     """k_basis_tile (LDS-staged union of the neighbourhoods of a tile of real rows) keeps the merged-CSR order and
     the fmaf chain of the row kernel: the compact planes equal the real rows of the full planes bit for bit."""
-    L = _rand_graph(V, 100 + V + shift, fake_frac=0.4)
+    L = _band_graph(V, 100 + V + shift)
     g = ops.DeviceGraph(L, "cuda:0")
-    assert g.n_fake > 0 and g.n_real >= 256
+    assert g.n_fake > 0 and g.n_real >= 256 and g.plan_tiles[shift] > 0      # the tile kernel is what runs
     gen = torch.Generator().manual_seed(V + Fdim)
     X = torch.randn(B * (V >> shift), Fdim, generator=gen).cuda()
     T1, T2 = ops.cheb_basis_fwd(g, X, B, Fdim, shift)
@@ -360,6 +376,50 @@ def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
     ref1 = T1.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
     ref2 = T2.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
     assert torch.equal(T1c, ref1) and torch.equal(T2c, ref2)
+
+
+@pytest.mark.parametrize("V,Fin,Fout,B,fuse", [(1472, 128, 64, 3, True), (736, 256, 128, 5, False),
+                                               (2944, 64, 256, 2, True)])
+def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, V, Fin, Fout, B, fuse):
+    """Backward of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"): S L g / S L2 g from the
+    paired tile plan, row sets 3 / 4, against the fine-resolution backward followed by the pair-sum."""
+    L = _band_graph(V, 31 + V)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert g.plan_tiles[2] > 0 and g.pair and g.n_pair_real + g.n_pair_fake == V // 2 and g.n_pair_fake > 0
+    real = np.zeros(V, bool)
+    real[_real_ids(L)] = True
+    pr = np.where(real[0::2] | real[1::2])[0]
+    assert pr.size == g.n_pair_real
+    gen = torch.Generator().manual_seed(V + Fout)
+    M, Mc = B * V, B * V // 2
+    gy = torch.randn(M, Fout, generator=gen).cuda()
+    Xc = torch.randn(Mc, Fin, generator=gen).cuda()
+    W3 = (torch.randn(3 * Fout, Fin, generator=gen) / 16).cuda()
+    Gres = torch.randn(M, Fin, generator=gen).cuda() if fuse else None
+    # fine resolution
+    E1, E2 = ops.cheb_basis_fwd(g, gy, B, Fout, 0)
+    (dXf,), _ = ops.gemm_planes([gy, E1, E2], Fout, 0, W3, None, M, Fin, 1, False, addend=Gres)
+    dX_ref = ops.pair_sum(dXf, Mc, Fin)
+    Pw, Pb, nch = ops.gemm_tn([Xc], Fin, 1, [gy, E1, E2], M, 3 * Fout)
+    dW_ref, db_ref = ops.weight_grad_unpack(Pw, Pb, nch, Fout, Fin, 3, layout=1)
+    # the planes themselves
+    P1c, P2c = ops.cheb_basis_pair(g, gy, B, Fout)
+    pri = torch.as_tensor(pr, device="cuda")
+    for Pc, E in ((P1c, E1), (P2c, E2)):
+        ref = ops.pair_sum(E, Mc, Fout).view(B, V // 2, Fout)[:, pri].reshape(-1, Fout)
+        assert (Pc - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
+    # coarse resolution
+    opb = ops.split_operands(W3, Fout, Fin, g.fake_a, g.fake_b)
+    dX = torch.full((Mc, Fin), float("nan"), device="cuda")
+    add = ops.pair_sum(Gres, Mc, Fin) if fuse else None
+    P0, P1c, P2c = ops.conv_pair(g, B, gy, Fout, W3, add, dX, Fin, opb)
+    assert torch.isfinite(dX).all()
+    assert (dX - dX_ref).abs().max() < 2e-5 * max(1.0, dX_ref.abs().max().item())
+    Q1, Qb1, n1 = ops.gemm_tn_rows(g, 3, B, Xc, Fin, 0, [P0, P1c, P2c], Fout, True)
+    Q2, Qb2, n2 = ops.gemm_tn_rows(g, 4, B, Xc, Fin, 0, [P0], Fout, False)
+    dW, db = ops.weight_grad_unpack2(Q1, Qb1, n1, Q2, Qb2, n2, g.fake_a, g.fake_b, Fout, Fin)
+    assert (dW - dW_ref).abs().max() < 1e-4 * max(1.0, dW_ref.abs().max().item())
+    assert (db - db_ref).abs().max() < 1e-3
 
 
 def _real_ids(L):
