@@ -186,9 +186,12 @@ int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const
                       int64_t M, int32_t F, void* stream);
 int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                         float* coef, int32_t accumulate, int32_t F, void* stream);
+/* pair_gx / pair_gy (optional, [M/2, F]; M even, F in {32,64,128,256}): by-products pair_gx[q] = gx[2q] + gx[2q+1] and
+ * pair_gy[q] = gy[2q] + gy[2q+1] -- the pair-sums the backward of an un-pooled conv needs (residual gradient for the
+ * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.               */
 int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                      const float* mean, const float* invstd, const float* gamma, const float* coef,
-                     int32_t relu, float* gy, int64_t M, int32_t F, void* stream);
+                     int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F, void* stream);
 
 /* out[p, f] = in[2p, f] + in[2p+1, f]   (backward of the x2 nearest un-pool, meshnet.py:74) */
 int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* stream);

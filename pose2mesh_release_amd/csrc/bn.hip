@@ -437,6 +437,78 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// The same pass with each thread owning PAIRS of adjacent rows (2q, 2q+1), so that the pair-sums the backward of an
+// un-pooled conv needs come out as by-products instead of separate passes: pair_gx[q] = gx[2q] + gx[2q+1] (the residual
+// gradient handed to the coarser level) and / or pair_gy[q] = gy[2q] + gy[2q+1] (plane S g of the paired operator).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restrict__ gx, const float* __restrict__ y,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                             int relu, float* __restrict__ gy, float* __restrict__ pair_gx,
+                                                             float* __restrict__ pair_gy, long Mp) {
+  constexpr int F = LPR * 4;
+  constexpr int RP = 256 / LPR;
+  const int t = threadIdx.x;
+  const int rloc = t / LPR, f = (t % LPR) * 4;
+  float sc[4], sh[4], k[4], a0[4], a1[4], mu[4], is[4], ga[4];
+  *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + f);
+  *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + f);
+  *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(mean + f);
+  *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(invstd + f);
+  *reinterpret_cast<float4*>(ga) = *reinterpret_cast<const float4*>(gamma + f);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    k[i] = ga[i] * is[i];
+    const float c0 = coef ? coef[f + i] : 0.f, c1 = coef ? coef[F + f + i] : 0.f;
+    a1[i] = -k[i] * c1 * is[i];
+    a0[i] = -k[i] * c0;
+  }
+  const long p0 = (long)blockIdx.x * (APPLY_ROWS_PER_BLOCK / 2);
+  long p1 = p0 + APPLY_ROWS_PER_BLOCK / 2;
+  if (p1 > Mp) p1 = Mp;
+  for (long pb = p0 + rloc; pb < p1; pb += 2 * RP) {        // 2 pairs = 4 rows per pass: 8 loads in flight per thread
+    float g[4][4], v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      long q = pb + (long)(u >> 1) * RP;
+      if (q >= p1) q = p1 - 1;
+      const long r = 2 * q + (u & 1);
+      *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
+      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const long q = pb + (long)h * RP;
+      if (q >= p1) break;
+      float o[2][4];
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
+        const int u = 2 * h + w;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float go = g[u][i];
+          if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
+          o[w][i] = fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+        }
+        *reinterpret_cast<float4*>(gy + (2 * q + w) * F + f) = *reinterpret_cast<float4*>(o[w]);
+      }
+      if (pair_gx) {
+        float sx[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) sx[i] = g[2 * h][i] + g[2 * h + 1][i];
+        *reinterpret_cast<float4*>(pair_gx + q * F + f) = *reinterpret_cast<float4*>(sx);
+      }
+      if (pair_gy) {
+        float sy[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) sy[i] = o[0][i] + o[1][i];
+        *reinterpret_cast<float4*>(pair_gy + q * F + f) = *reinterpret_cast<float4*>(sy);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F) {
   const int F4 = F >> 2;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -631,9 +703,23 @@ extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, f
 
 extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* gamma, const float* coef,
-                                int32_t relu, float* gy, int64_t M, int32_t F, void* stream) {
+                                int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
+                                void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
   hipStream_t s = (hipStream_t)stream;
+  if (pair_gx || pair_gy) {
+    P2M_CHECK_ARG(M % 2 == 0 && (F == 32 || F == 64 || F == 128 || F == 256),
+                  "pair-sum by-products need an even row count and F in {32, 64, 128, 256}");
+    const long Mp = M / 2;
+    const int gridp = cdiv(Mp, APPLY_ROWS_PER_BLOCK / 2);
+    switch (F) {
+      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
+      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
+      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
+      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
+    }
+    return check_launch("bn_bwd_apply(pairs)");
+  }
   const int grid = cdiv(M, APPLY_ROWS_PER_BLOCK);
   switch (F) {
     case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;

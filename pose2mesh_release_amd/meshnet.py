@@ -341,6 +341,7 @@ class _MeshNetFn(torch.autograd.Function):
                 if side is not None:
                     self.cm.__exit__(*a)
                 return False
+        Gs_block = None    # S G of the current block (pair-sum of the gradient w.r.t. the block output), when produced
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
@@ -378,20 +379,37 @@ class _MeshNetFn(torch.autograd.Function):
                 saved[L.ci] = None
                 g_cur = dX
                 continue
-            # ---- BN + ReLU backward -> gy
-            if L.has_bn:
-                gamma = params[P[f"bn.{L.ci}.weight"]]
-                tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
-                if tg is not None:
-                    gy, _, _ = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, dgamma=tg[0], dbeta=tg[1])
-                else:
-                    gy, dgamma, dbeta = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout)
-                    grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = dgamma, dbeta
-            else:
-                gy = g_cur
             has_res = L.first_in_block and 1 <= L.block <= nblk - 2
             Fblk = net.CL_F[L.block][-1]
             fuse_res = has_res and (L.Fin == Fblk)
+            pair_path = _bwd_forward_form(L) and gph.split and x_shift and gph.pair \
+                and (L.Fout in (32, 64) or L.Fout % 128 == 0) and not ops.fused_supported(L.Fout, L.Fin)
+            # pair-sums this block's first conv will need come out of the BatchNorm-backward pass as by-products:
+            # S G (the residual gradient at the coarser resolution) when G is read as g_cur by the block's last conv,
+            # S gy (plane 0 of the paired operator) when the first conv's own gy is written
+            want_Gs = want_P0 = False
+            if L.has_bn and M % 2 == 0 and L.Fout in (32, 64, 128, 256):
+                if L.last_in_block and not L.first_in_block:
+                    F0 = net._layers[net._block_first[L.block]]
+                    want_Gs = bool(saved[F0.ci][1]) and 1 <= F0.block <= nblk - 2 and L.Fout == Fblk
+                want_P0 = pair_path
+            # ---- BN + ReLU backward -> gy
+            P0 = None
+            if L.has_bn:
+                gamma = params[P[f"bn.{L.ci}.weight"]]
+                tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
+                kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
+                res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
+                                      pair_out=want_P0, **kw)
+                gy = res[0]
+                if tg is None:
+                    grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
+                if want_Gs:
+                    Gs_block = res[3]
+                if want_P0:
+                    P0 = res[4]
+            else:
+                gy = g_cur
             if ops.fused_supported(L.Fout, L.Fin):
                 # dX = [gy | L gy | L2 gy] W3 in one kernel (L symmetric); its gathered planes give
                 # dW = X^T [gy | L gy | L2 gy] without ever forming the basis of X
@@ -401,19 +419,18 @@ class _MeshNetFn(torch.autograd.Function):
                 dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                 grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
-            elif _bwd_forward_form(L) and gph.split and x_shift and gph.pair \
-                    and (L.Fout in (32, 64) or L.Fout % 128 == 0):
+            elif pair_path:
                 # the input was un-pooled (X_fine[r] = X[r >> 1]): with S = the pair-sum, dX = [S g | S L g | S L2 g] W3
                 # and dW = X^T [S g | S L g | S L2 g] -- both contractions run over V/2 rows; S L and S L2 are one
                 # baked operator (the level's paired tile plan), its rows split into "has a real child" / "both
                 # children fake" like the real / fake split of the forward
                 Mc = M >> 1
                 dX = torch.empty((Mc, L.Fin), device=gy.device, dtype=torch.float32)
-                add = ops.pair_sum(G, Mc, Fblk) if fuse_res else None
+                add = (Gs_block if Gs_block is not None else ops.pair_sum(G, Mc, Fblk)) if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb)
+                P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0)
                 with side_ctx(keep, X, P0, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False)
@@ -476,12 +493,13 @@ class _MeshNetFn(torch.autograd.Function):
                 d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
                 dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
             if has_res and not fuse_res:                              # transpose of the feature resize
-                Gs = ops.pair_sum(G, M >> 1, Fblk) if x_shift else G
+                Gs = (Gs_block if Gs_block is not None else ops.pair_sum(G, M >> 1, Fblk)) if x_shift else G
                 ops.lerp_bwd_add(Gs, dX, M >> x_shift, Fblk, L.Fin)
             saved[L.ci] = None
             g_cur = dX
             if L.first_in_block:
                 G = dX
+                Gs_block = None
         if side is not None:
             main_stream.wait_stream(side)      # join: all weight gradients are complete before autograd consumes them
         keep.clear()
@@ -545,6 +563,7 @@ class Pose2Mesh(nn.Module):
         self.cl = nn.ModuleList(cl)
         self.bn = nn.ModuleList(bn)
         self._layers = layers
+        self._block_first = {L.block: i for i, L in enumerate(layers) if L.first_in_block}
         self._graph_cache = ops.GraphCache(graph_L)
         self._weight_cache = ops.WeightCache()
         self._direct_grad = False

@@ -376,10 +376,12 @@ def cheb_basis_pair(g, G, B, F):
     return P1, P2
 
 
-def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands):
+def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
     """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
-    C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c)."""
-    P0 = pair_sum(Gy, B * (g.V // 2), Ka)
+    C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
+    P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
+    if P0 is None:
+        P0 = pair_sum(Gy, B * (g.V // 2), Ka)
     P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
     Bx, We, Wex = operands
     gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
@@ -605,8 +607,10 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F):
     return x
 
 
-def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None):
-    """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad)."""
+def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False):
+    """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
+    pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
+    (gy, dgamma, dbeta, pair_gx or None, pair_gy or None)."""
     lib = _lib.hip()
     nblk = int(lib.p2m_bn_bwd_blocks(M, F))
     part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
@@ -620,9 +624,13 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None)
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     gy = torch.empty((M, F), device=y.device, dtype=torch.float32)
+    pgx = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
+    pgy = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
-                               _p(coef) if training else None, int(relu), _p(gy), M, F, _stream()),
+                               _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, _stream()),
           "p2m_bn_bwd_apply")
+    if pair_in or pair_out:
+        return gy, dgamma, dbeta, pgx, pgy
     return gy, dgamma, dbeta
 
 

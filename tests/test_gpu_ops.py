@@ -188,6 +188,12 @@ def test_bn_relu_residual_fwd_bwd(ops, M, Fd, Fres, rshift, training):
     assert (gy.cpu() - yd.grad).abs().max() < 2e-5 * max(1.0, yd.grad.abs().max().item())
     assert (dgamma.cpu() - gd.grad).abs().max() < 1e-5 * max(1.0, gd.grad.abs().max().item()) * np.sqrt(M)
     assert (dbeta.cpu() - bd.grad).abs().max() < 1e-5 * max(1.0, bd.grad.abs().max().item()) * np.sqrt(M)
+    if M % 2 == 0 and Fd in (32, 64, 128, 256):
+        # the pair-sum by-products of the apply pass: same gy bit for bit, pair_gx = S gx, pair_gy = S gy
+        gy2, _, _, pgx, pgy = ops.bn_relu_bwd(gx.cuda(), yc, co, gamma.cuda(), True, training, M, Fd, pair_in=True,
+                                              pair_out=True)
+        assert torch.equal(gy2, gy)
+        assert torch.equal(pgx, ops.pair_sum(gx.cuda(), M // 2, Fd)) and torch.equal(pgy, ops.pair_sum(gy, M // 2, Fd))
     # residual transpose
     G = gx.cuda()
     Mr = M >> rshift if rshift else M

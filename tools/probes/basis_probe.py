@@ -44,5 +44,12 @@ for lvl, F, shift in CASES:
     tot_bytes += moved
     print(f"V={g.V:6d} real={g.n_real:5d} F={F:3d} shift={shift}: {ms:7.3f} ms  {moved / ms / 1e6:7.0f} GB/s moved", flush=True)
     del X
+    if g.pair and shift == 0:
+        # the paired operator (S L g, S L2 g over the coarse vertices with a real child): same source rows, half the planes
+        G = torch.randn(B * g.V, F, device="cuda")
+        ms = bench(lambda: ops.cheb_basis_pair(g, G, B, F))
+        moved = 4.0 * B * F * (g.V + 2.0 * g.n_pair_real)
+        print(f"V={g.V:6d} pair={g.n_pair_real:5d} F={F:3d} paired : {ms:7.3f} ms  {moved / ms / 1e6:7.0f} GB/s moved", flush=True)
+        del G
 print(f"TOTAL {tot_ms:.3f} ms  {tot_bytes / tot_ms / 1e6:.0f} GB/s moved   [TILE_W={os.environ.get('P2M_BASIS_TILE_W', '1')} "
       f"SPB={os.environ.get('P2M_BASIS_SPB', '8')} TILED={os.environ.get('P2M_BASIS_TILED', '1')}]")
