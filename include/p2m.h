@@ -181,9 +181,11 @@ int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32
  *   finalize: dgamma, dbeta (accumulate!=0 adds), coef[0][f]=dbeta/M, coef[1][f]=dgamma/M
  *   apply:    gy = gamma*invstd*(go - coef0 - yhat*coef1)   (training)   |   gamma*invstd*go (eval, coef NULL) */
 int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F);
+/* classes (optional graph handle with p2m_graph_set_classes; NULL = every row counts): holes are skipped by the
+ * reduction, and the apply pass adds the constant term of a representative once per class member.                  */
 int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
                       const float* mean, const float* invstd, int32_t relu, float* part,
-                      int64_t M, int32_t F, void* stream);
+                      int64_t M, int32_t F, p2m_graph_t classes, void* stream);
 int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                         float* coef, int32_t accumulate, int32_t F, void* stream);
 /* pair_gx / pair_gy (optional, [M/2, F]; M even, F in {32,64,128,256}): by-products pair_gx[q] = gx[2q] + gx[2q+1] and
@@ -191,10 +193,12 @@ int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamm
  * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.               */
 int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                      const float* mean, const float* invstd, const float* gamma, const float* coef,
-                     int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F, void* stream);
+                     int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
+                     p2m_graph_t classes, void* stream);
 
 /* out[p, f] = in[2p, f] + in[2p+1, f]   (backward of the x2 nearest un-pool, meshnet.py:74) */
-int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* stream);
+int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, p2m_graph_t classes /* of `in`'s level, or NULL */,
+                 void* stream);
 /* dst[r, i] += sum_j w(j,i) g[r, j]: transpose of the feature-axis resize (meshnet.py:109,114);
  * g: [M, F], dst: [M, Fres].                                                                   */
 int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t Fres, void* stream);
@@ -250,6 +254,34 @@ int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, co
                          int32_t rows_b, int32_t B, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                          float* shift, int32_t N, void* stream);
+
+/* Same, for the two launches of one split conv, with the sizes (and, with classes, the weights) taken from the handle. */
+int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* stats_fake, int32_t B,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                          int32_t N, void* stream);
+
+/* ---- classes of identical fake rows ------------------------------------------------------------------------
+ * Inside the coarse-to-fine stack every descendant of a fake vertex is fake, isolated and produced by the same per-row
+ * arithmetic from the same un-pooled value (meshnet.py:71-78: both children copy the parent): in the tree order the
+ * descendants of one fake vertex at a finer level are an aligned run of 2^j bitwise IDENTICAL rows.  The caller, who
+ * knows how many un-pool steps lie above a level, declares these runs with rep_of[V] (host array: the first row of the
+ * run for its members, v itself for everything else).  Afterwards the handle's fake row sets (2 and 4) list only the
+ * representatives, the other members ("holes") are never written nor read:
+ *   forward   BatchNorm statistics count a representative once per member (p2m_stats_rows_w + p2m_bn_finalize_split);
+ *             p2m_cheb_combine_small (the final conv) fills the holes of its OUTPUT with the representative's value;
+ *   backward  a representative carries the SUM of its class's gradients -- everything downstream (BatchNorm backward,
+ *             contractions, pair-sums, the weight gradient) is linear in it; p2m_class_reduce forms that sum from the
+ *             incoming gradient, the BatchNorm-backward passes take the handle (`classes`) to skip holes and to add
+ *             the constant term once per member.
+ * Results are those of the full computation (fp32 round-off class: the statistics' summation order changes).       */
+int p2m_graph_fake_ids(p2m_graph_t g, int32_t* out /* host, n_fake entries */);
+int p2m_graph_set_classes(p2m_graph_t g, const int32_t* rep_of /* host, V entries */);
+int p2m_graph_class_info(p2m_graph_t g, int32_t counts[3] /* has classes, representatives, all fake vertices */);
+/* weighted BatchNorm partials of the representatives of y [B*V, N]: stats [B * ceil(n_rep/128)][2][N] */
+int p2m_stats_rows_w(p2m_graph_t g, const float* y, int32_t B, int32_t N, float* stats, void* stream);
+/* out[r] = sum of in over the class of r (representatives), in[r] (real vertices), 0 (holes); in, out: [B*V, F] */
+int p2m_class_reduce(p2m_graph_t g, const float* in, float* out, int32_t B, int32_t F, void* stream);
 
 /* ---- fused Chebyshev convolution: recurrence + contraction in ONE persistent kernel -------------
  *   C[r, :] = [ A[r] | (L A)[r] | (L2 A)[r] ] * Bm (+ bias) (+ addend[r]),   r = b*V + v, M = B*V rows

@@ -47,6 +47,13 @@ HIP_SYMBOLS = {
                                            _i32, _vp]),
     "p2m_bn_finalize_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp,
                                         _vp, _vp, _vp, _i32, _vp]),
+    "p2m_bn_finalize_split": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
+                                         _vp]),
+    "p2m_graph_fake_ids": (_c.c_int, [_vp, _vp]),
+    "p2m_graph_set_classes": (_c.c_int, [_vp, _vp]),
+    "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
+    "p2m_stats_rows_w": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "p2m_class_reduce": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "p2m_cheb_gemm_fused": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32,
                                        _vp]),
     "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
@@ -63,10 +70,11 @@ HIP_SYMBOLS = {
     "p2m_bn_eval_coeffs": (_c.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "p2m_bn_bwd_blocks": (_i32, [_i64, _i32]),
-    "p2m_bn_bwd_reduce": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "p2m_bn_bwd_reduce": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     "p2m_bn_bwd_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_bn_bwd_apply": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "p2m_pair_sum": (_c.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "p2m_bn_bwd_apply": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp,
+                                    _vp]),
+    "p2m_pair_sum": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "p2m_lerp_bwd_add": (_c.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "p2m_mesh_loss_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "p2m_mesh_loss": (_c.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -220,11 +220,13 @@ __global__ __launch_bounds__(256) void k_combine_small(Graph g, const float* __r
   const int i = (int)(idx - (long)b * n);
   const int row = ids ? ids[i] : i;
   const long base = (long)b * g.V * ldp;             // sample offset in P
-  const float* p0 = P + base + (long)row * ldp;
+  // classes (Graph::rep_of): a hole is never computed upstream; its output is its representative's, recomputed here
+  const int src = g.rep_of ? g.rep_of[row] : row;
+  const float* p0 = P + base + (long)src * ldp;
   float acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; c++) acc[c] = p0[c] + (bias ? bias[c] : 0.f);
-  for (int j = g.rowptr[row]; j < g.rowptr[row + 1]; j++) {
+  for (int j = g.rowptr[src]; j < g.rowptr[src + 1]; j++) {
     const float* q = P + base + (long)g.col[j] * ldp;
     const float a = g.a[j], bb = g.b[j];
 #pragma unroll

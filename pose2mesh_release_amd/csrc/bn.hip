@@ -30,6 +30,7 @@ struct StatSeg {
   const float* stats;
   int ntiles, tps;
   long seg_rows;
+  const float* tile_w;   // optional [tps]: total weight of each tile (weighted partials of class representatives)
 };
 __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, StatSeg sg1, int tile_rows, int N,
                                                                   double* __restrict__ part) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, S
       if (i1 > sg.ntiles) i1 = sg.ntiles;
       for (int i = i0 + rg; i < i1; i += FIN_RG) {
         long left = sg.seg_rows - (long)(i % sg.tps) * tile_rows;
-        const double cnt = (double)(left < tile_rows ? left : tile_rows);
+        const double cnt = sg.tile_w ? (double)sg.tile_w[i % sg.tps] : (double)(left < tile_rows ? left : tile_rows);
         const double sm = (double)sg.stats[(long)i * 2 * N + n];
         const double m2 = (double)sg.stats[(long)i * 2 * N + N + n];
         a1 += sm;
@@ -224,6 +225,74 @@ __global__ void k_bn_act_fwd_generic(const float* __restrict__ y, const float* _
   x[idx] = v;
 }
 
+// ---- weighted statistics of class representatives ---------------------------------------------
+// One block per (sample, tile of 128 entries of the id list): st[tile][0][n] = sum w y, st[tile][1][n] = sum w (y - m)^2
+// with m the tile's weighted mean -- the same tile-centred form the contraction epilogue emits, a row counting w times.
+__global__ __launch_bounds__(256) void k_stats_rows_w(const float* __restrict__ y, const int* __restrict__ ids,
+                                                       const float* __restrict__ wts, int n, int V, int tps, int N,
+                                                       float* __restrict__ st) {
+  __shared__ double red[8][32];
+  const int b = blockIdx.x / tps, tile = blockIdx.x - b * tps;
+  const int i0 = tile * 128;
+  int i1 = i0 + 128;
+  if (i1 > n) i1 = n;
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (int n0 = 0; n0 < N; n0 += 32) {
+    const int col = n0 + c;
+    double sw = 0.0, s1 = 0.0;
+    if (col < N)
+      for (int i = i0 + rg; i < i1; i += 8) {
+        const double wv = (double)wts[i];
+        sw += wv;
+        s1 += wv * (double)y[((long)b * V + ids[i]) * N + col];
+      }
+    red[rg][c] = s1;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) tot += red[q][c];
+    __syncthreads();
+    red[rg][c] = sw;
+    __syncthreads();
+    double wtot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) wtot += red[q][c];
+    __syncthreads();
+    const double mean = wtot > 0.0 ? tot / wtot : 0.0;
+    double m2 = 0.0;
+    if (col < N)
+      for (int i = i0 + rg; i < i1; i += 8) {
+        const double d = (double)y[((long)b * V + ids[i]) * N + col] - mean;
+        m2 += (double)wts[i] * d * d;
+      }
+    red[rg][c] = m2;
+    __syncthreads();
+    if (rg == 0 && col < N) {
+      double t2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) t2 += red[q][c];
+      st[(long)blockIdx.x * 2 * N + col] = (float)tot;
+      st[(long)blockIdx.x * 2 * N + N + col] = (float)t2;
+    }
+    __syncthreads();
+  }
+}
+
+// out[r] = sum of in over the class of r (representatives: w[v] consecutive rows starting at r), in[r] for real
+// vertices, 0 for holes: the gradient a representative carries is the SUM over its class.
+__global__ __launch_bounds__(256) void k_class_reduce(const float* __restrict__ in, const float* __restrict__ w,
+                                                       float* __restrict__ out, long M, int V, int F) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * F) return;
+  const long r = idx / F;
+  const int f = (int)(idx - r * F);
+  const int v = (int)(r % V);
+  const int m = (int)w[v];
+  float s = 0.f;
+  for (int k = 0; k < m; k++) s += in[(r + k) * F + f];
+  out[idx] = s;
+}
+
 // ---- backward ---------------------------------------------------------------------------------
 constexpr int BWD_ROWS_PER_BLOCK = 512;
 
@@ -231,7 +300,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ gx, const float* __restrict__ y,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int relu, float* __restrict__ part, long M) {
+                                                        int relu, float* __restrict__ part, long M,
+                                                        const float* __restrict__ w, int V) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   __shared__ float red[2][RP][F];
@@ -257,6 +327,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (rb + (long)u * RP >= r1) break;
+      // holes (w == 0) hold no data: they are skipped, not multiplied (their bits may be NaN)
+      if (w != nullptr && w[(unsigned)(rb + (long)u * RP) % (unsigned)V] == 0.f) continue;
       float4 g = gq[u];
       const float4 v = vq[u];
       if (relu) {
@@ -290,7 +362,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_generic(const float* __re
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
-                                                                float* __restrict__ part, long M, int F) {
+                                                                float* __restrict__ part, long M, int F,
+                                                                const float* __restrict__ w, int V) {
   const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
   long r1 = r0 + BWD_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
@@ -298,6 +371,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_generic(const float* __re
     const float sc = scale[f], sh = shift[f], mu = mean[f], is = invstd[f];
     float s0 = 0.f, s1 = 0.f;
     for (long r = r0; r < r1; r++) {
+      if (w != nullptr && w[r % V] == 0.f) continue;
       const float v = y[r * F + f];
       float g = gx[r * F + f];
       if (relu && fmaf(v, sc, sh) <= 0.f) g = 0.f;
@@ -316,7 +390,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ coef, int relu,
-                                                               float* __restrict__ gy, long M, int F) {
+                                                               float* __restrict__ gy, long M, int F,
+                                                               const float* __restrict__ w, int V) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * F) return;
   const int f = (int)(idx % F);
@@ -325,7 +400,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
   if (relu && fmaf(v, scale[f], shift[f]) <= 0.f) go = 0.f;
   const float k = gamma[f] * invstd[f];
   const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
-  gy[idx] = fmaf(k, go, fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
+  const float wr = w ? w[(idx / F) % V] : 1.f;
+  gy[idx] = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
 }
 
 // Two stages like the forward finalize.  Stage 1: block = 32 adjacent columns of BOTH partial kinds (128-byte coalesced
@@ -389,7 +465,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ coef,
-                                                       int relu, float* __restrict__ gy, long M) {
+                                                       int relu, float* __restrict__ gy, long M,
+                                                       const float* __restrict__ w, int V) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
@@ -425,12 +502,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     for (int u = 0; u < 4; u++) {
       const long r = rb + (long)u * RP;
       if (r >= r1) break;
+      // classes: the constant term enters once per class member (a representative carries the class sum)
+      const float wr = w ? w[(unsigned)r % (unsigned)V] : 1.f;
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         float go = g[u][i];
         if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-        o[i] = fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+        o[i] = w ? fmaf(k[i], go, wr * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                 : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
       }
       *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
     }
@@ -446,7 +526,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ coef,
                                                              int relu, float* __restrict__ gy, float* __restrict__ pair_gx,
-                                                             float* __restrict__ pair_gy, long Mp) {
+                                                             float* __restrict__ pair_gy, long Mp,
+                                                             const float* __restrict__ w, int V) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
@@ -481,35 +562,43 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
     for (int h = 0; h < 2; h++) {
       const long q = pb + (long)h * RP;
       if (q >= p1) break;
-      float o[2][4];
+      float o[2][4], wr[2] = {1.f, 1.f};
+      if (w != nullptr) {
+        const unsigned v0 = (unsigned)(2 * q) % (unsigned)V;          // V is even: 2q and 2q+1 are rows of the same sample
+        wr[0] = w[v0];
+        wr[1] = w[v0 + 1];
+      }
 #pragma unroll
-      for (int w = 0; w < 2; w++) {
-        const int u = 2 * h + w;
+      for (int c = 0; c < 2; c++) {
+        const int u = 2 * h + c;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           float go = g[u][i];
           if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-          o[w][i] = fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+          o[c][i] = w ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                      : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
         }
-        *reinterpret_cast<float4*>(gy + (2 * q + w) * F + f) = *reinterpret_cast<float4*>(o[w]);
+        *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
       }
+      // holes (w == 0) hold no data: selected out of the pair-sums, not multiplied (their bits may be NaN)
       if (pair_gx) {
         float sx[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) sx[i] = g[2 * h][i] + g[2 * h + 1][i];
+        for (int i = 0; i < 4; i++) sx[i] = (wr[0] != 0.f ? g[2 * h][i] : 0.f) + (wr[1] != 0.f ? g[2 * h + 1][i] : 0.f);
         *reinterpret_cast<float4*>(pair_gx + q * F + f) = *reinterpret_cast<float4*>(sx);
       }
       if (pair_gy) {
         float sy[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) sy[i] = o[0][i] + o[1][i];
+        for (int i = 0; i < 4; i++) sy[i] = (wr[0] != 0.f ? o[0][i] : 0.f) + (wr[1] != 0.f ? o[1][i] : 0.f);
         *reinterpret_cast<float4*>(pair_gy + q * F + f) = *reinterpret_cast<float4*>(sy);
       }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F) {
+__global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F,
+                                                   const float* __restrict__ w, int V) {
   const int F4 = F >> 2;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mout * F4) return;
@@ -517,6 +606,11 @@ __global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, 
   int f = (int)(idx - p * F4) * 4;
   float4 a = *reinterpret_cast<const float4*>(in + (2 * p) * F + f);
   float4 b = *reinterpret_cast<const float4*>(in + (2 * p + 1) * F + f);
+  if (w != nullptr) {                                 // classes: holes hold no data
+    const unsigned v0 = (unsigned)(2 * p) % (unsigned)V;
+    if (w[v0] == 0.f) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w[v0 + 1] == 0.f) b = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   *reinterpret_cast<float4*>(out + p * F + f) = a;
 }
@@ -606,23 +700,46 @@ extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, co
   P2M_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift && N > 0 && M > 0, "null pointer or empty shape");
   P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
   P2M_CHECK_ARG(tile_rows > 0 && ntiles == cdiv(M, tile_rows), "ntiles does not match M / tile_rows");
-  StatSeg a{stats, ntiles, ntiles, (long)M}, b{nullptr, 0, 1, 0};
+  StatSeg a{stats, ntiles, ntiles, (long)M, nullptr}, b{nullptr, 0, 1, 0, nullptr};
   return finalize_launch(a, b, (long)M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                          scale, shift, N, (hipStream_t)stream, "bn_finalize");
+}
+
+static int finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b,
+                         int32_t tps_b, int32_t rows_b, const float* tile_w_b, int32_t B,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, float* mean, float* invstd, float* scale,
+                         float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(stats_a && gamma && beta && mean && invstd && scale && shift && N > 0 && B > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+  const int tile_rows = p2m_stats_tile_rows();
+  StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a, nullptr};
+  StatSeg b{stats_b, stats_b ? B * tps_b : 0, tps_b > 0 ? tps_b : 1, (long)rows_b, stats_b ? tile_w_b : nullptr};
+  const long M = (long)B * ((long)rows_a + (stats_b ? (long)rows_b : 0));
+  return finalize_launch(a, b, M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                         shift, N, (hipStream_t)stream, "bn_finalize_rows");
 }
 
 extern "C" int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b,
                                     int32_t tps_b, int32_t rows_b, int32_t B, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                     float* invstd, float* scale, float* shift, int32_t N, void* stream) {
-  P2M_CHECK_ARG(stats_a && gamma && beta && mean && invstd && scale && shift && N > 0 && B > 0, "null pointer or empty shape");
-  P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
+  return finalize_rows(stats_a, tps_a, rows_a, stats_b, tps_b, rows_b, nullptr, B, gamma, beta, running_mean,
+                       running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
+}
+
+// the two launches of one split conv, sizes and (with classes) the tile weights of the representatives from the handle
+extern "C" int p2m_bn_finalize_split(p2m_graph_t gh, const float* stats_real, const float* stats_fake, int32_t B,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, float* mean, float* invstd, float* scale,
+                                     float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(gh, "null graph");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
   const int tile_rows = p2m_stats_tile_rows();
-  StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a};
-  StatSeg b{stats_b, stats_b ? B * tps_b : 0, tps_b > 0 ? tps_b : 1, (long)rows_b};
-  const long M = (long)B * ((long)rows_a + (stats_b ? (long)rows_b : 0));
-  return finalize_launch(a, b, M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                         shift, N, (hipStream_t)stream, "bn_finalize_rows");
+  const int rows_fake = g.w ? g.n_fake_all : g.n_fake;      // with classes: the statistics count every fake vertex
+  return finalize_rows(stats_real, cdiv(g.n_real, tile_rows), g.n_real, g.n_fake > 0 ? stats_fake : nullptr,
+                       cdiv(g.n_fake, tile_rows), rows_fake, g.w ? g.fake_tile_w : nullptr, B, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
 }
 
 extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
@@ -668,19 +785,35 @@ extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
   return cdiv(M, BWD_ROWS_PER_BLOCK);
 }
 
+// classes of a level (optional handle): the weight table and the vertex count the rows repeat with
+static bool class_table(p2m_graph_t gh, int64_t M, const float** w, int* V) {
+  *w = nullptr;
+  *V = 1;
+  if (gh == nullptr) return true;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.w == nullptr) return true;
+  if (M % g.V != 0 || M >= (1LL << 32)) return false;
+  *w = g.w;
+  *V = g.V;
+  return true;
+}
+
 extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, int32_t relu, float* part, int64_t M,
-                                 int32_t F, void* stream) {
+                                 int32_t F, p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && M > 0 && F > 0, "null pointer or empty shape");
+  const float* w;
+  int V;
+  P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
   hipStream_t s = (hipStream_t)stream;
   const int grid = p2m_bn_bwd_blocks(M, F);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, F);
+      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, F, w, V);
   }
   return check_launch("bn_bwd_reduce");
 }
@@ -704,8 +837,12 @@ extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, f
 extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* gamma, const float* coef,
                                 int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
-                                void* stream) {
+                                p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
+  const float* w;
+  int V;
+  P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
+  P2M_CHECK_ARG(w == nullptr || !(pair_gx || pair_gy) || V % 2 == 0, "pair-sums with classes need an even vertex count");
   hipStream_t s = (hipStream_t)stream;
   if (pair_gx || pair_gy) {
     P2M_CHECK_ARG(M % 2 == 0 && (F == 32 || F == 64 || F == 128 || F == 256),
@@ -713,30 +850,55 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
     const long Mp = M / 2;
     const int gridp = cdiv(Mp, APPLY_ROWS_PER_BLOCK / 2);
     switch (F) {
-      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
-      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
-      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
-      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp); break;
+      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
+      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
+      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
+      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
     }
     return check_launch("bn_bwd_apply(pairs)");
   }
   const int grid = cdiv(M, APPLY_ROWS_PER_BLOCK);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv((long)M * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, F);
+      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv((long)M * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, F, w, V);
   }
   return check_launch("bn_bwd_apply");
 }
 
-extern "C" int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, void* stream) {
+extern "C" int p2m_stats_rows_w(p2m_graph_t gh, const float* y, int32_t B, int32_t N, float* stats, void* stream) {
+  P2M_CHECK_ARG(gh && y && stats && N > 0, "null pointer or empty shape");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  P2M_CHECK_ARG(g.w != nullptr, "the handle has no classes (p2m_graph_set_classes)");
+  if (B <= 0 || g.n_fake == 0) return P2M_OK;
+  const int tps = cdiv(g.n_fake, 128);
+  hipLaunchKernelGGL(k_stats_rows_w, dim3(B * tps), dim3(256), 0, (hipStream_t)stream, y, g.fake_ids, g.fake_wts,
+                     g.n_fake, g.V, tps, N, stats);
+  return check_launch("stats_rows_w");
+}
+
+extern "C" int p2m_class_reduce(p2m_graph_t gh, const float* in, float* out, int32_t B, int32_t F, void* stream) {
+  P2M_CHECK_ARG(gh && in && out && F > 0, "null pointer or empty shape");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  P2M_CHECK_ARG(g.w != nullptr, "the handle has no classes (p2m_graph_set_classes)");
+  if (B <= 0) return P2M_OK;
+  const long M = (long)B * g.V;
+  hipLaunchKernelGGL(k_class_reduce, dim3(cdiv(M * F, 256)), dim3(256), 0, (hipStream_t)stream, in, g.w, out, M, g.V, F);
+  return check_launch("class_reduce");
+}
+
+extern "C" int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(in && out && F > 0 && F % 4 == 0, "null pointer or feature width not a multiple of 4");
   if (Mout <= 0) return P2M_OK;
+  const float* w;
+  int V;
+  P2M_CHECK_ARG(class_table(classes, 2 * Mout, &w, &V) && (w == nullptr || V % 2 == 0),
+                "row count is not a multiple of the level's (even) vertex count");
   long tot = Mout * (F / 4);
-  hipLaunchKernelGGL(k_pair_sum, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long)Mout, F);
+  hipLaunchKernelGGL(k_pair_sum, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long)Mout, F, w, V);
   return check_launch("pair_sum");
 }
 

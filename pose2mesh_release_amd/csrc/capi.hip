@@ -263,6 +263,10 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->fake_ids) (void)hipFree(g->fake_ids);
   if (g->pair_real_ids) (void)hipFree(g->pair_real_ids);
   if (g->pair_fake_ids) (void)hipFree(g->pair_fake_ids);
+  if (g->w) (void)hipFree(g->w);
+  if (g->rep_of) (void)hipFree(g->rep_of);
+  if (g->fake_wts) (void)hipFree(g->fake_wts);
+  if (g->fake_tile_w) (void)hipFree(g->fake_tile_w);
   for (TilePlan& pl : g->plan) {
     if (pl.tile_row) (void)hipFree(pl.tile_row);
     if (pl.tile_u) (void)hipFree(pl.tile_u);
@@ -299,6 +303,85 @@ extern "C" int p2m_graph_pair_info(p2m_graph_t gh, int32_t counts[2]) {
   const Graph* g = reinterpret_cast<const Graph*>(gh);
   counts[0] = g->plan[2].ntiles > 0 ? g->n_pair_real : 0;
   counts[1] = g->plan[2].ntiles > 0 ? g->n_pair_fake : 0;
+  return P2M_OK;
+}
+
+// ---- classes of identical fake rows ------------------------------------------------------------------------------
+extern "C" int p2m_graph_fake_ids(p2m_graph_t gh, int32_t* out) {
+  P2M_CHECK_ARG(gh && out, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  if (g->n_fake == 0) return P2M_OK;
+  hipError_t e = hipMemcpy(out, g->fake_ids, sizeof(int) * g->n_fake, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); return P2M_ERR_HIP; }
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
+  P2M_CHECK_ARG(gh && rep_of, "null pointer");
+  Graph* g = reinterpret_cast<Graph*>(gh);
+  P2M_CHECK_ARG(g->w == nullptr, "classes already set on this handle");
+  const int V = g->V;
+  std::vector<int> fake(g->n_fake);
+  if (g->n_fake) (void)hipMemcpy(fake.data(), g->fake_ids, sizeof(int) * g->n_fake, hipMemcpyDeviceToHost);
+  std::vector<char> is_fake(V, 0);
+  for (int v : fake) is_fake[v] = 1;
+  std::vector<float> w(V, 1.f);
+  std::vector<int> cnt(V, 0);
+  for (int v = 0; v < V; v++) {
+    const int r = rep_of[v];
+    P2M_CHECK_ARG(r >= 0 && r <= v && rep_of[r] == r, "rep_of must point at the first row of a class");
+    P2M_CHECK_ARG(r == v || (is_fake[v] && is_fake[r]), "only fake vertices can share a class");
+    cnt[r]++;
+  }
+  for (int v = 0; v < V; v++)          // a class is a run of consecutive rows
+    if (rep_of[v] != v) P2M_CHECK_ARG(rep_of[v - 1] == rep_of[v], "a class must be a run of consecutive rows");
+  std::vector<int> reps, pfake;
+  std::vector<float> wts;
+  for (int v : fake) {
+    if (rep_of[v] == v) { reps.push_back(v); wts.push_back((float)cnt[v]); w[v] = (float)cnt[v]; }
+    else w[v] = 0.f;
+  }
+  if (!(V & 1))
+    for (int c = 0; c < V / 2; c++)
+      // 2c+1 is then either a hole of 2c's class or (on the coarsest level of the chain) a class of its own
+      if (is_fake[2 * c] && is_fake[2 * c + 1] && rep_of[2 * c] == 2 * c) pfake.push_back(c);
+  const int n_rep = (int)reps.size();
+  std::vector<float> tile_w(cdiv(n_rep > 0 ? n_rep : 1, 128), 0.f);
+  for (int i = 0; i < n_rep; i++) tile_w[i / 128] += wts[i];
+  g->n_fake_all = g->n_fake;
+  const int n_pf = (int)pfake.size();
+  reps.resize(reps.size() + 64, 0);
+  wts.resize(wts.size() + 64, 0.f);
+  pfake.resize(pfake.size() + 64, 0);
+  std::vector<int> rep_v(rep_of, rep_of + V);
+  int *d_reps = nullptr, *d_pf = nullptr;
+  int rc;
+  if ((rc = upload(reps.data(), sizeof(int) * reps.size(), (void**)&d_reps)) != P2M_OK ||
+      (rc = upload(pfake.data(), sizeof(int) * pfake.size(), (void**)&d_pf)) != P2M_OK ||
+      (rc = upload(wts.data(), sizeof(float) * wts.size(), (void**)&g->fake_wts)) != P2M_OK ||
+      (rc = upload(tile_w.data(), sizeof(float) * tile_w.size(), (void**)&g->fake_tile_w)) != P2M_OK ||
+      (rc = upload(rep_v.data(), sizeof(int) * V, (void**)&g->rep_of)) != P2M_OK ||
+      (rc = upload(w.data(), sizeof(float) * V, (void**)&g->w)) != P2M_OK)
+    return rc;
+  (void)hipFree(g->fake_ids);
+  g->fake_ids = d_reps;
+  g->n_fake = n_rep;
+  if (g->pair_fake_ids) {
+    (void)hipFree(g->pair_fake_ids);
+    g->pair_fake_ids = d_pf;
+    g->n_pair_fake = n_pf;
+  } else {
+    (void)hipFree(d_pf);
+  }
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_class_info(p2m_graph_t gh, int32_t counts[3]) {
+  P2M_CHECK_ARG(gh && counts, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  counts[0] = g->w ? 1 : 0;
+  counts[1] = g->n_fake;                                  // representatives (or all fake vertices without classes)
+  counts[2] = g->w ? g->n_fake_all : g->n_fake;
   return P2M_OK;
 }
 

@@ -59,6 +59,21 @@ struct Graph {
   int n_pair_real = 0, n_pair_fake = 0;
   int* pair_real_ids = nullptr;   // [n_pair_real]  coarse vertex ids, ascending
   int* pair_fake_ids = nullptr;   // [n_pair_fake]
+  // Classes of IDENTICAL fake rows (p2m_graph_set_classes).  All descendants of a fake vertex of a coarser level are fake,
+  // isolated, and went through the same per-row arithmetic from the same un-pooled value: they are bitwise equal, and
+  // in the tree order they form an aligned block of 2^j consecutive rows.  Only the first row of a block (the
+  // representative) is computed; the others ("holes") are never written nor read.  After set_classes: fake_ids /
+  // pair_fake_ids list representatives only, and
+  //   w[v]      = 1 (real vertex), class size (representative), 0 (hole)             -- nullptr: no classes
+  //   rep_of[v] = representative of v's class (v itself for real vertices and representatives)
+  //   fake_wts  = class size per entry of fake_ids;  fake_tile_w = the sums of fake_wts over 128-entry tiles
+  // Forward: statistics count a representative w times.  Backward: a representative carries the SUM of its class's
+  // gradients (everything downstream is linear in it).
+  float* w = nullptr;
+  int* rep_of = nullptr;
+  float* fake_wts = nullptr;
+  float* fake_tile_w = nullptr;
+  int n_fake_all = 0;             // fake vertices of the level (representatives + holes)
 };
 
 // Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)

@@ -205,7 +205,12 @@ class _MeshNetFn(torch.autograd.Function):
             if _narrow(L):
                 # final 64 -> 3 conv by linearity: project to 9 columns on the MFMA first, then combine sparsely
                 Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
-                (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False, Bx=Wpx)
+                if g.classes:       # holes of `cur` hold no data: project the live rows only; the combine fills the holes
+                    Pm = torch.empty((M, 32), device=cur.device, dtype=torch.float32)
+                    for rs in (1, 2):
+                        ops.gemm_planes_rows(g, rs, B, [cur], L.Fin, cur_shift, False, Wp, None, None, Pm, 32, Bx=Wpx)
+                else:
+                    (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False, Bx=Wpx)
                 out = ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
                 del Pm
                 if keep:
@@ -259,7 +264,11 @@ class _MeshNetFn(torch.autograd.Function):
                     resid = block_in
                 out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout)
                 if net._tap is not None:          # test hook: raw conv output + BN scale/shift of every ReLU layer
-                    net._tap.append((L.ci, y, co[2], co[3]))
+                    yt = y
+                    if g.classes and g.split:     # holes are never computed: show the class value, as the full net has it
+                        rep = torch.as_tensor(net._class_rep[L.graph], device=y.device, dtype=torch.long)
+                        yt = y.view(B, g.V, L.Fout)[:, rep].reshape(M, L.Fout)
+                    net._tap.append((L.ci, yt, co[2], co[3]))
             else:
                 out = y                                               # final conv: no BN, no ReLU (:52-55,99)
             if keep:
@@ -320,6 +329,9 @@ class _MeshNetFn(torch.autograd.Function):
                 out.append(gbuf)
             return out
         G = grad_out.contiguous().float().view(-1, net.num_mesh_output_chan)   # grad wrt current block output
+        g_out = graphs[net._layers[-1].graph]
+        if g_out.classes:      # class-sum form: a representative carries the gradient of its whole class, holes nothing
+            G = ops.class_reduce(g_out, G, B, net.num_mesh_output_chan)
         g_cur = G
         keep = []          # tensors read by the side stream: kept alive until the join at the end of backward
         main_stream = torch.cuda.current_stream()
@@ -367,15 +379,26 @@ class _MeshNetFn(torch.autograd.Function):
             if _narrow(L):
                 Wp = W2
                 E = ops.cheb_expand_small(gph, g_cur, L.Fout, 32, B)
-                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
-                dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1)
+                if gph.classes:     # live rows only (row sets 1 / 2): the holes of X and E hold no data
+                    dW32 = db32 = None
+                    for rs in (1, 2):
+                        Pw, Pb, nch = ops.gemm_tn_rows(gph, rs, B, X, L.Fin, x_shift, [E], 32, False)
+                        dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1, dW=dW32, db=db32)
+                else:
+                    Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
+                    dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1)
                 nco = K_CHEB * L.Fout
                 grads[P[f"cl.{L.ci}.weight"]] = dW32[:nco].view(K_CHEB, L.Fout, L.Fin).permute(1, 2, 0) \
                     .reshape(L.Fout, L.Fin * K_CHEB).contiguous()
                 grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 Wpt, Wptx = wc.get((L.ci, "narrow_bwd"), Wl, lambda: _transposed_operands(Wp))
-                (dX,), _ = ops.gemm_planes([E], 32, 0, Wpt, None, M, L.Fin, 1, False, Bx=Wptx)
+                if gph.classes:
+                    dX = torch.empty((M, L.Fin), device=E.device, dtype=torch.float32)
+                    for rs in (1, 2):
+                        ops.gemm_planes_rows(gph, rs, B, [E], 32, 0, False, Wpt, None, None, dX, L.Fin, Bx=Wptx)
+                else:
+                    (dX,), _ = ops.gemm_planes([E], 32, 0, Wpt, None, M, L.Fin, 1, False, Bx=Wptx)
                 saved[L.ci] = None
                 g_cur = dX
                 continue
@@ -400,7 +423,7 @@ class _MeshNetFn(torch.autograd.Function):
                 tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
                 res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
-                                      pair_out=want_P0, **kw)
+                                      pair_out=want_P0, classes=gph, **kw)
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
@@ -425,8 +448,11 @@ class _MeshNetFn(torch.autograd.Function):
                 # baked operator (the level's paired tile plan), its rows split into "has a real child" / "both
                 # children fake" like the real / fake split of the forward
                 Mc = M >> 1
-                dX = torch.empty((Mc, L.Fin), device=gy.device, dtype=torch.float32)
-                add = (Gs_block if Gs_block is not None else ops.pair_sum(G, Mc, Fblk)) if fuse_res else None
+                # classes: the rows of hole parents are not written; a coarser level that runs full-row kernels needs
+                # them to be zero (a hole carries no gradient), a split one never reads them
+                coarse_full = gph.classes and not graphs[net._layers[L.ci - 1].graph].split
+                dX = (torch.zeros if coarse_full else torch.empty)((Mc, L.Fin), device=gy.device, dtype=torch.float32)
+                add = (Gs_block if Gs_block is not None else ops.pair_sum(G, Mc, Fblk, classes=gph)) if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
@@ -493,7 +519,7 @@ class _MeshNetFn(torch.autograd.Function):
                 d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
                 dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
             if has_res and not fuse_res:                              # transpose of the feature resize
-                Gs = (Gs_block if Gs_block is not None else ops.pair_sum(G, M >> 1, Fblk)) if x_shift else G
+                Gs = (Gs_block if Gs_block is not None else ops.pair_sum(G, M >> 1, Fblk, classes=gph)) if x_shift else G
                 ops.lerp_bwd_add(Gs, dX, M >> x_shift, Fblk, L.Fin)
             saved[L.ci] = None
             g_cur = dX
@@ -564,7 +590,8 @@ class Pose2Mesh(nn.Module):
         self.bn = nn.ModuleList(bn)
         self._layers = layers
         self._block_first = {L.block: i for i, L in enumerate(layers) if L.first_in_block}
-        self._graph_cache = ops.GraphCache(graph_L)
+        self._class_rep = {}
+        self._graph_cache = ops.GraphCache(graph_L, class_plan=self._class_plan)
         self._weight_cache = ops.WeightCache()
         self._direct_grad = False
         self._infer_real_only = False
@@ -572,6 +599,45 @@ class Pose2Mesh(nn.Module):
         self._tap = None        # tests set this to a list to receive (conv index, y_raw, bn scale, bn shift) per layer
         names, _ = self._param_list()
         self._param_index = {n: i for i, n in enumerate(names)}
+
+    def _class_plan(self, graphs):
+        """{graph index: un-pool steps above that level} when runs of identical fake rows may be declared on the levels
+        of the un-pool chain (include/p2m.h "classes"; ops.CLASSES), else None.  Conditions: the split levels are the
+        finest ones, every conv on them runs through the row-set paths (so no full-row kernel ever reads a hole), the
+        backward of every un-pooled conv on them has the paired operator, and the fake vertices of consecutive levels
+        agree with the tree (a vertex is fake iff both of its children are)."""
+        nblk = len(self.CL_F)
+        chain = [self._layers[self._block_first[b]].graph for b in range(1, nblk - 1)]      # coarse -> fine
+        if not any(graphs[gi].split for gi in chain):
+            return None
+        seen = False
+        for gi in chain:
+            if graphs[gi].split:
+                seen = True
+            elif seen:
+                return None
+        for L in self._layers:
+            g = graphs[L.graph]
+            if L.graph not in chain or not g.split or _narrow(L):
+                continue
+            if not _bwd_forward_form(L) or ops.fused_supported(L.Fin, L.Fout) or ops.fused_supported(L.Fout, L.Fin):
+                return None
+            if L.first_in_block and 2 <= L.block <= nblk - 2 \
+                    and not (g.pair and (L.Fout in (32, 64) or L.Fout % 128 == 0)):
+                return None
+        masks = []
+        for gi in chain:
+            m = np.zeros(graphs[gi].V, dtype=bool)
+            m[graphs[gi].fake_ids_host()] = True
+            masks.append(m)
+        for k in range(len(chain) - 1):
+            if graphs[chain[k + 1]].V != 2 * graphs[chain[k]].V \
+                    or not np.array_equal(masks[k], masks[k + 1][0::2] & masks[k + 1][1::2]):
+                return None
+        plan = {gi: k for k, gi in enumerate(chain)}
+        for gi, depth in plan.items():
+            self._class_rep[gi] = ops.class_representatives(graphs[gi].V, np.where(masks[chain.index(gi)])[0], depth)[0]
+        return plan
 
     def _param_list(self):
         names, params = ["fc.weight", "fc.bias"], [self.fc.weight, self.fc.bias]

@@ -99,6 +99,9 @@ DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
 PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
+# classes of identical fake rows inside the coarse-to-fine stack (include/p2m.h): only one representative of every run of
+# identical padding rows is computed; 0 = every row (the A/B form)
+CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 
 
 class DeviceGraph:
@@ -143,8 +146,30 @@ class DeviceGraph:
         check(_lib.hip().p2m_graph_plan_info(self.handle, ctypes.byref(nt)), "p2m_graph_plan_info")
         self.plan_tiles = tuple(int(v) for v in nt)
 
+        self.classes = False
+        self.n_fake_all = self.n_fake
+
     def set_size(self, row_set):
         return (self.n_real, self.n_fake, self.n_pair_real, self.n_pair_fake)[row_set - 1]
+
+    def fake_ids_host(self):
+        out = np.zeros(max(self.n_fake, 1), dtype=np.int32)
+        check(_lib.hip().p2m_graph_fake_ids(self.handle, out.ctypes.data_as(_vp)), "p2m_graph_fake_ids")
+        return out[:self.n_fake]
+
+    def set_classes(self, rep_of):
+        """Declare the runs of identical fake rows (include/p2m.h "classes"): afterwards row sets 2 / 4 hold the
+        representatives only."""
+        rep = np.ascontiguousarray(rep_of, dtype=np.int32)
+        if rep.shape != (self.V,):
+            raise P2MError("rep_of must have one entry per vertex")
+        with torch.cuda.device(self.device):
+            check(_lib.hip().p2m_graph_set_classes(self.handle, rep.ctypes.data_as(_vp)), "p2m_graph_set_classes")
+        c3, c2 = (ctypes.c_int32 * 3)(), (ctypes.c_int32 * 2)()
+        check(_lib.hip().p2m_graph_class_info(self.handle, ctypes.byref(c3)), "p2m_graph_class_info")
+        self.classes, self.n_fake, self.n_fake_all = bool(c3[0]), int(c3[1]), int(c3[2])
+        check(_lib.hip().p2m_graph_pair_info(self.handle, ctypes.byref(c2)), "p2m_graph_pair_info")
+        self.n_pair_real, self.n_pair_fake = int(c2[0]), int(c2[1])
 
     def __del__(self):
         try:
@@ -155,12 +180,30 @@ class DeviceGraph:
             pass
 
 
+def class_representatives(V, fake_ids, depth):
+    """rep_of[V] for a level with `depth` un-pool steps above it in the stack: the maximal aligned runs of 2^j <= 2^depth
+    all-fake rows are the descendants of ONE fake vertex j levels up, hence identical (include/p2m.h "classes")."""
+    fake = np.zeros(V, dtype=bool)
+    fake[np.asarray(fake_ids, dtype=np.int64)] = True
+    rep = np.arange(V, dtype=np.int32)
+    for j in range(1, depth + 1):
+        bs = 1 << j
+        if V % bs:
+            break
+        for blk in np.where(fake.reshape(V // bs, bs).all(axis=1))[0]:
+            rep[blk * bs:(blk + 1) * bs] = blk * bs
+    return rep, fake
+
+
 class GraphCache:
     """Per-device DeviceGraph lists for a list of scipy Laplacians (thread-safe: nn.DataParallel
-    calls forward from one thread per GPU on replicas that share this object)."""
+    calls forward from one thread per GPU on replicas that share this object).
+    class_plan: optional callable(list of DeviceGraph) -> {graph index: depth} deciding, once the handles exist, on which
+    levels runs of identical fake rows are declared (the caller knows the un-pool chain)."""
 
-    def __init__(self, laplacians):
+    def __init__(self, laplacians, class_plan=None):
         self.laplacians = list(laplacians)
+        self.class_plan = class_plan
         self._per_device = {}
         self._lock = threading.Lock()
 
@@ -172,6 +215,10 @@ class GraphCache:
                 g = self._per_device.get(key)
                 if g is None:
                     g = [DeviceGraph(L, torch.device("cuda", key)) for L in self.laplacians]
+                    if self.class_plan is not None and CLASSES:
+                        for gi, depth in (self.class_plan(g) or {}).items():
+                            rep, _ = class_representatives(g[gi].V, g[gi].fake_ids_host(), depth)
+                            g[gi].set_classes(rep)
                     self._per_device[key] = g
         return g
 
@@ -323,6 +370,7 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
     n = g.set_size(row_set)
     st = None
+    weighted = stats and row_set == 2 and g.classes     # representatives count once per class member: separate pass
     if stats:
         tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, row_set))
         st = torch.empty((B * tps, 2, N), device=C.device, dtype=torch.float32)
@@ -335,9 +383,11 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
                                               _p(Bx if Bx is not None else weight_split(Bm)),
                                               _p(bias if bias is None else _req(bias, "bias")),
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
-                                              _p(st), _p(None if act is None else act[0]),
+                                              _p(None if weighted else st), _p(None if act is None else act[0]),
                                               _p(None if act is None else act[1]), int(bool(act and act[2])),
                                               _stream()), "p2m_gemm_planes_rows")
+    if weighted and n > 0:
+        check(_lib.hip().p2m_stats_rows_w(g.handle, _p(C), B, N, _p(st), _stream()), "p2m_stats_rows_w")
     return st
 
 
@@ -381,7 +431,7 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
     C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
     P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
     if P0 is None:
-        P0 = pair_sum(Gy, B * (g.V // 2), Ka)
+        P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
     P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
     Bx, We, Wex = operands
     gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
@@ -443,12 +493,10 @@ def weight_grad_unpack2(P, Pdb, nch, P2, Pdb2, nch2, s1, s2, Fout, Fin, dW=None,
 def bn_finalize_rows(g, B, st_real, st_fake, gamma, beta, running_mean, running_var, momentum, eps):
     N = gamma.shape[0]
     co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
-    lib = _lib.hip()
-    check(lib.p2m_bn_finalize_rows(_p(st_real), int(lib.p2m_rows_tiles_per_sample(g.handle, 1)), g.n_real,
-                                   _p(st_fake), int(lib.p2m_rows_tiles_per_sample(g.handle, 2)), g.n_fake, B,
-                                   _p(_req(gamma, "bn.weight")), _p(_req(beta, "bn.bias")), _p(running_mean),
-                                   _p(running_var), float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]),
-                                   _p(co[3]), N, _stream()), "p2m_bn_finalize_rows")
+    check(_lib.hip().p2m_bn_finalize_split(g.handle, _p(st_real), _p(st_fake), B, _p(_req(gamma, "bn.weight")),
+                                           _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
+                                           float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
+                                           _stream()), "p2m_bn_finalize_split")
     return co
 
 
@@ -607,7 +655,8 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F):
     return x
 
 
-def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False):
+def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False,
+                classes=None):
     """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
     pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
     (gy, dgamma, dbeta, pair_gx or None, pair_gy or None)."""
@@ -619,24 +668,34 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None,
         dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
         dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
+    cls = classes.handle if (classes is not None and classes.classes) else None
     check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
-                                int(relu), _p(part), M, F, _stream()), "p2m_bn_bwd_reduce")
+                                int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     gy = torch.empty((M, F), device=y.device, dtype=torch.float32)
     pgx = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
     pgy = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
-                               _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, _stream()),
-          "p2m_bn_bwd_apply")
+                               _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, cls,
+                               _stream()), "p2m_bn_bwd_apply")
     if pair_in or pair_out:
         return gy, dgamma, dbeta, pgx, pgy
     return gy, dgamma, dbeta
 
 
-def pair_sum(x, Mout, F):
+def pair_sum(x, Mout, F, classes=None):
+    """classes: the DeviceGraph of x's level when it has classes (holes are left out of the sums)."""
     out = torch.empty((Mout, F), device=x.device, dtype=torch.float32)
-    check(_lib.hip().p2m_pair_sum(_p(_req(x, "in")), _p(out), Mout, F, _stream()), "p2m_pair_sum")
+    cls = classes.handle if (classes is not None and classes.classes) else None
+    check(_lib.hip().p2m_pair_sum(_p(_req(x, "in")), _p(out), Mout, F, cls, _stream()), "p2m_pair_sum")
+    return out
+
+
+def class_reduce(g, G, B, F):
+    """Gradient in class-sum form: representatives get the sum over their class, holes 0 (include/p2m.h "classes")."""
+    out = torch.empty_like(G)
+    check(_lib.hip().p2m_class_reduce(g.handle, _p(_req(G, "G")), _p(out), B, F, _stream()), "p2m_class_reduce")
     return out
 
 
