@@ -174,7 +174,7 @@ int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * (meshnet.py:109,114).                                                                        */
 int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                    const float* resid, int32_t Fres, int32_t res_shift,
-                   float* x, int64_t M, int32_t F, void* stream);
+                   float* x, int64_t M, int32_t F, p2m_graph_t classes /* or NULL: holes are skipped */, void* stream);
 /* backward through ReLU + BatchNorm (train: batch statistics; eval: running statistics).
  *   go = gx * (y*scale+shift > 0 or !relu)
  *   reduce:   part[blk][0][f] = sum go, part[blk][1][f] = sum go * yhat       (nblk = p2m_bn_bwd_blocks(M,F))

@@ -130,19 +130,27 @@ constexpr int ACT_UNROLL = 4;
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
                                                      const float* __restrict__ resid, int Fres, int res_shift,
-                                                     float* __restrict__ x, long M, int F) {
+                                                     float* __restrict__ x, long M, int F,
+                                                     const float* __restrict__ w, int V) {
   const int F4 = F >> 2;
   const int rpb = 256 / F4;                                  // rows per block pass
   const int f = (threadIdx.x % F4) * 4;
   const long rbase = (long)blockIdx.x * rpb * ACT_UNROLL + threadIdx.x / F4;
   float4 v[ACT_UNROLL], q[ACT_UNROLL];
+  bool live[ACT_UNROLL];
   const bool same = resid != nullptr && Fres == F;
 #pragma unroll
   for (int u = 0; u < ACT_UNROLL; u++) {
     long r = rbase + (long)u * rpb;
     if (r >= M) r = M - 1;                                   // clamped: keeps the loads unconditional
-    v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
-    if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
+    // classes: holes (w == 0) hold no data and nobody reads them -- neither loaded nor stored
+    live[u] = w == nullptr || w[(unsigned)r % (unsigned)V] != 0.f;
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    q[u] = v[u];
+    if (live[u]) {
+      v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+      if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
+    }
   }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (scale != nullptr) {
@@ -153,24 +161,25 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y,
   for (int u = 0; u < ACT_UNROLL; u++) {
     const long r = rbase + (long)u * rpb;
     if (r >= M) break;
-    float4 w = v[u];
+    if (!live[u]) continue;
+    float4 o = v[u];
     if (scale != nullptr) {
-      w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
-      w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+      o.x = fmaf(o.x, sc.x, sh.x); o.y = fmaf(o.y, sc.y, sh.y);
+      o.z = fmaf(o.z, sc.z, sh.z); o.w = fmaf(o.w, sc.w, sh.w);
     }
     if (relu) {
-      w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     if (same) {
-      w.x += q[u].x; w.y += q[u].y; w.z += q[u].z; w.w += q[u].w;
+      o.x += q[u].x; o.y += q[u].y; o.z += q[u].z; o.w += q[u].w;
     } else if (resid != nullptr) {
       const float* rr = resid + (r >> res_shift) * Fres;
-      w.x += lerp_feat(rr, Fres, F, f);
-      w.y += lerp_feat(rr, Fres, F, f + 1);
-      w.z += lerp_feat(rr, Fres, F, f + 2);
-      w.w += lerp_feat(rr, Fres, F, f + 3);
+      o.x += lerp_feat(rr, Fres, F, f);
+      o.y += lerp_feat(rr, Fres, F, f + 1);
+      o.z += lerp_feat(rr, Fres, F, f + 2);
+      o.w += lerp_feat(rr, Fres, F, f + 3);
     }
-    *reinterpret_cast<float4*>(x + r * F + f) = w;
+    *reinterpret_cast<float4*>(x + r * F + f) = o;
   }
 }
 
@@ -317,18 +326,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   if (r1 > M) r1 = M;
   for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
     float4 gq[4], vq[4];
+    bool live[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       long r = rb + (long)u * RP;
       if (r >= r1) r = r1 - 1;
-      gq[u] = *reinterpret_cast<const float4*>(gx + r * F + f);
-      vq[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+      // holes (w == 0) hold no data: they are skipped -- not loaded, not multiplied (their bits may be NaN)
+      live[u] = w == nullptr || w[(unsigned)r % (unsigned)V] != 0.f;
+      if (live[u]) {
+        gq[u] = *reinterpret_cast<const float4*>(gx + r * F + f);
+        vq[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (rb + (long)u * RP >= r1) break;
-      // holes (w == 0) hold no data: they are skipped, not multiplied (their bits may be NaN)
-      if (w != nullptr && w[(unsigned)(rb + (long)u * RP) % (unsigned)V] == 0.f) continue;
+      if (!live[u]) continue;
       float4 g = gq[u];
       const float4 v = vq[u];
       if (relu) {
@@ -490,20 +503,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   long r1 = r0 + APPLY_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
   for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
-    float g[4][4], v[4][4];
+    float g[4][4], v[4][4], wq[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       long r = rb + (long)u * RP;
       if (r >= r1) r = r1 - 1;
-      *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
-      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+      wq[u] = w ? w[(unsigned)r % (unsigned)V] : 1.f;
+      if (wq[u] != 0.f) {                                   // holes: neither loaded nor stored
+        *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
+        *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const long r = rb + (long)u * RP;
       if (r >= r1) break;
       // classes: the constant term enters once per class member (a representative carries the class sum)
-      const float wr = w ? w[(unsigned)r % (unsigned)V] : 1.f;
+      const float wr = wq[u];
+      if (wr == 0.f) continue;
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -549,25 +566,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
   long p1 = p0 + APPLY_ROWS_PER_BLOCK / 2;
   if (p1 > Mp) p1 = Mp;
   for (long pb = p0 + rloc; pb < p1; pb += 2 * RP) {        // 2 pairs = 4 rows per pass: 8 loads in flight per thread
-    float g[4][4], v[4][4];
+    float g[4][4], v[4][4], wq[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       long q = pb + (long)(u >> 1) * RP;
       if (q >= p1) q = p1 - 1;
       const long r = 2 * q + (u & 1);
-      *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
-      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+      wq[u] = w ? w[(unsigned)r % (unsigned)V] : 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) g[u][i] = v[u][i] = 0.f;
+      if (wq[u] != 0.f) {                                   // holes: neither loaded nor stored
+        *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
+        *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const long q = pb + (long)h * RP;
       if (q >= p1) break;
-      float o[2][4], wr[2] = {1.f, 1.f};
-      if (w != nullptr) {
-        const unsigned v0 = (unsigned)(2 * q) % (unsigned)V;          // V is even: 2q and 2q+1 are rows of the same sample
-        wr[0] = w[v0];
-        wr[1] = w[v0 + 1];
-      }
+      float o[2][4];
+      const float wr[2] = {wq[2 * h], wq[2 * h + 1]};    // V is even: 2q and 2q+1 are rows of the same sample
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const int u = 2 * h + c;
@@ -577,21 +595,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
           if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
           o[c][i] = w ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
                       : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+          if (wr[c] == 0.f) o[c][i] = 0.f;                // a hole: no data (its g / v registers were zeroed above)
         }
-        *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
+        if (wr[c] != 0.f) *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
       }
-      // holes (w == 0) hold no data: selected out of the pair-sums, not multiplied (their bits may be NaN)
-      if (pair_gx) {
-        float sx[4];
+      // the pair-sums leave the holes out; a pair of two holes (a hole parent) is not written at all
+      if (wr[0] != 0.f || wr[1] != 0.f) {
+        if (pair_gx) {
+          float sx[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) sx[i] = (wr[0] != 0.f ? g[2 * h][i] : 0.f) + (wr[1] != 0.f ? g[2 * h + 1][i] : 0.f);
-        *reinterpret_cast<float4*>(pair_gx + q * F + f) = *reinterpret_cast<float4*>(sx);
-      }
-      if (pair_gy) {
-        float sy[4];
+          for (int i = 0; i < 4; i++) sx[i] = g[2 * h][i] + g[2 * h + 1][i];
+          *reinterpret_cast<float4*>(pair_gx + q * F + f) = *reinterpret_cast<float4*>(sx);
+        }
+        if (pair_gy) {
+          float sy[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) sy[i] = (wr[0] != 0.f ? o[0][i] : 0.f) + (wr[1] != 0.f ? o[1][i] : 0.f);
-        *reinterpret_cast<float4*>(pair_gy + q * F + f) = *reinterpret_cast<float4*>(sy);
+          for (int i = 0; i < 4; i++) sy[i] = o[0][i] + o[1][i];
+          *reinterpret_cast<float4*>(pair_gy + q * F + f) = *reinterpret_cast<float4*>(sy);
+        }
       }
     }
   }
@@ -661,6 +682,20 @@ __global__ __launch_bounds__(256) void k_lerp_bwd_add_half(const float* __restri
 }  // namespace p2m
 
 using namespace p2m;
+
+// classes of a level (optional handle): the weight table and the vertex count the rows repeat with
+static bool class_table(p2m_graph_t gh, int64_t M, const float** w, int* V) {
+  *w = nullptr;
+  *V = 1;
+  if (gh == nullptr) return true;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.w == nullptr) return true;
+  if (M % g.V != 0 || M >= (1LL << 32)) return false;
+  *w = g.w;
+  *V = g.V;
+  return true;
+}
+
 
 // scratch of the two-stage finalize kernels: FIN_SPLITS x 2 x N doubles, one buffer per (device, stream) - the calls of
 // one stream are ordered, so stage 1 of the next call cannot overtake stage 2 of the previous one.  Internal to the
@@ -754,7 +789,7 @@ extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const f
 
 extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                               const float* resid, int32_t Fres, int32_t res_shift, float* x, int64_t M, int32_t F,
-                              void* stream) {
+                              p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(y && x && F > 0, "null pointer or empty shape");
   P2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale/shift must both be given or both NULL");
   P2M_CHECK_ARG(resid == nullptr || Fres > 0, "Fres must be positive with a residual");
@@ -765,8 +800,11 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
     const int F4 = F / 4;
     if (F4 <= 256 && 256 % F4 == 0) {
       const long rows_per_block = (long)(256 / F4) * ACT_UNROLL;
+      const float* w;
+      int V;
+      P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
       hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
-                         Fres, res_shift, x, (long)M, F);
+                         Fres, res_shift, x, (long)M, F, w, V);
     } else {
       long tot = M * F4;
       hipLaunchKernelGGL(k_bn_act_fwd_v4, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
@@ -783,19 +821,6 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
 extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
   (void)F;
   return cdiv(M, BWD_ROWS_PER_BLOCK);
-}
-
-// classes of a level (optional handle): the weight table and the vertex count the rows repeat with
-static bool class_table(p2m_graph_t gh, int64_t M, const float** w, int* V) {
-  *w = nullptr;
-  *V = 1;
-  if (gh == nullptr) return true;
-  const Graph& g = *reinterpret_cast<const Graph*>(gh);
-  if (g.w == nullptr) return true;
-  if (M % g.V != 0 || M >= (1LL << 32)) return false;
-  *w = g.w;
-  *V = g.V;
-  return true;
 }
 
 extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,

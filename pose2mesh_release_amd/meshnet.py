@@ -262,7 +262,8 @@ class _MeshNetFn(torch.autograd.Function):
                 resid = None
                 if L.last_in_block and 1 <= L.block <= nblk - 2:       # meshnet.py:108-115
                     resid = block_in
-                out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout)
+                out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout,
+                                     classes=g if (g.classes and split) else None)
                 if net._tap is not None:          # test hook: raw conv output + BN scale/shift of every ReLU layer
                     yt = y
                     if g.classes and g.split:     # holes are never computed: show the class value, as the full net has it
@@ -423,7 +424,7 @@ class _MeshNetFn(torch.autograd.Function):
                 tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
                 res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
-                                      pair_out=want_P0, classes=gph, **kw)
+                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, **kw)
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]

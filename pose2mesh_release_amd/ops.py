@@ -645,21 +645,25 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F):
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None):
+    """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped)."""
     x = torch.empty((M, F), device=y.device, dtype=torch.float32)
     sc = None if co is None else co[2]
     sh = None if co is None else co[3]
+    cls = classes.handle if (classes is not None and classes.classes) else None
     check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
                                     _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),
-                                    _p(x), M, F, _stream()), "p2m_bn_act_fwd")
+                                    _p(x), M, F, cls, _stream()), "p2m_bn_act_fwd")
     return x
 
 
 def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False,
-                classes=None):
+                classes=None, zero_holes=False):
     """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
     pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
-    (gy, dgamma, dbeta, pair_gx or None, pair_gy or None)."""
+    (gy, dgamma, dbeta, pair_gx or None, pair_gy or None).
+    classes: the level's DeviceGraph (include/p2m.h "classes"): holes are skipped -- not read, not written; zero_holes:
+    the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows)."""
     lib = _lib.hip()
     nblk = int(lib.p2m_bn_bwd_blocks(M, F))
     part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
@@ -673,9 +677,10 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None,
                                 int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
-    gy = torch.empty((M, F), device=y.device, dtype=torch.float32)
-    pgx = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
-    pgy = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
+    alloc = torch.zeros if (zero_holes and cls is not None) else torch.empty
+    gy = alloc((M, F), device=y.device, dtype=torch.float32)
+    pgx = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
+    pgy = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
                                _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, cls,
                                _stream()), "p2m_bn_bwd_apply")

@@ -54,3 +54,13 @@ def test_cpu_tensors_fail_loudly(hip_libs):
     net = meshnet.get_model(5, 3, gL)
     with pytest.raises(P2MError):
         net(torch.zeros(2, J, 5))
+
+
+def test_class_representatives_cpu_logic():
+    from pose2mesh_release_amd import ops as o
+    fake = [2, 3, 4, 5, 6, 7, 9, 12, 13, 14, 15]
+    rep, m = o.class_representatives(16, fake, 2)
+    assert rep.tolist() == [0, 1, 2, 2, 4, 4, 4, 4, 8, 9, 10, 11, 12, 12, 12, 12]
+    rep1, _ = o.class_representatives(16, fake, 1)
+    assert rep1.tolist() == [0, 1, 2, 2, 4, 4, 6, 6, 8, 9, 10, 11, 12, 12, 14, 14]
+    assert o.class_representatives(16, fake, 0)[0].tolist() == list(range(16))

@@ -428,6 +428,85 @@ def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, V, Fin, Fo
     assert (db - db_ref).abs().max() < 1e-3
 
 
+def test_classes_of_identical_fake_rows(ops):
+    """include/p2m.h "classes": with runs of identical fake rows declared, the kernels that see them give what the full
+    computation gives -- weighted statistics, class-sum gradients, holes neither read (they are NaN here) nor needed."""
+    V, F, B = 1472, 128, 3
+    L = _band_graph(V, 77, fake_frac=0.55)
+    g = ops.DeviceGraph(L, "cuda:0")
+    fake = g.fake_ids_host()
+    rep, fmask = ops.class_representatives(V, fake, 3)
+    sizes = np.bincount(rep, minlength=V)
+    assert (sizes > 1).sum() > 20 and sizes.max() >= 4            # the test graph has real classes
+    n_fake_all = g.n_fake
+    g.set_classes(rep)
+    assert g.classes and g.n_fake == int(((rep == np.arange(V)) & fmask).sum()) and g.n_fake_all == n_fake_all
+    hole = torch.as_tensor(rep != np.arange(V), device="cuda")
+    rep_t = torch.as_tensor(rep, device="cuda", dtype=torch.long)
+    gen = torch.Generator().manual_seed(5)
+    M = B * V
+    # a FULL tensor whose class members are identical, and its holed twin
+    y_full = (torch.randn(B, V, F, generator=gen) * 1.5 + 0.3).cuda()[:, rep_t].contiguous()
+    y_hole = y_full.clone()
+    y_hole[:, hole] = float("nan")
+    # --- forward statistics: real-row tiles (as the contraction epilogue emits them) + weighted representative tiles
+    real = torch.as_tensor(np.where(~fmask)[0], device="cuda")
+    tr = ops.stats_tile_rows()
+    tps = (real.numel() + tr - 1) // tr
+    st_real = torch.empty(B * tps, 2, F, device="cuda")
+    for b in range(B):
+        for t in range(tps):
+            blk = y_full[b, real[t * tr:(t + 1) * tr]].double()
+            st_real[b * tps + t, 0] = blk.sum(0).float()
+            st_real[b * tps + t, 1] = ((blk - blk.mean(0)) ** 2).sum(0).float()
+    ntf = (g.n_fake + tr - 1) // tr
+    st_fake = torch.empty(B * ntf, 2, F, device="cuda")
+    from pose2mesh_release_amd import _lib
+    _lib.check(_lib.hip().p2m_stats_rows_w(g.handle, y_hole.data_ptr(), B, F, st_fake.data_ptr(), None), "stats_rows_w")
+    gamma, beta = (torch.rand(F, generator=gen) + 0.5).cuda(), (torch.randn(F, generator=gen) * 0.1).cuda()
+    co = ops.bn_finalize_rows(g, B, st_real, st_fake, gamma, beta, None, None, 0.1, 1e-5)
+    yd = y_full.view(M, F).double()
+    assert (co[0].double() - yd.mean(0)).abs().max() < 1e-6
+    assert (co[1].double() - 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-5
+    # --- forward activation skips the holes
+    x_full = ops.bn_act_fwd(y_full.view(M, F), co, True, None, 0, 0, M, F)
+    x_hole = ops.bn_act_fwd(y_hole.view(M, F), co, True, None, 0, 0, M, F, classes=g)
+    live = ~hole.repeat(B)
+    assert torch.equal(x_hole[live], x_full[live])
+    # --- backward: per-member gradients on the full side, class sums on the holed side
+    gx_full = torch.randn(M, F, generator=gen).cuda()
+    gx_cls = ops.class_reduce(g, gx_full, B, F)
+    assert torch.equal(gx_cls.view(B, V, F)[:, real], gx_full.view(B, V, F)[:, real])
+    assert float(gx_cls.view(B, V, F)[:, hole].abs().max()) == 0.0
+    gx_cls.view(B, V, F)[:, hole] = float("nan")
+    gy_full, dg_full, db_full = ops.bn_relu_bwd(gx_full, y_full.view(M, F), co, gamma, True, True, M, F)
+    gy, dg, db, pgx, pgy = ops.bn_relu_bwd(gx_cls, y_hole.view(M, F), co, gamma, True, True, M, F, pair_in=True,
+                                           pair_out=True, classes=g, zero_holes=True)
+    assert (dg - dg_full).abs().max() < 2e-5 * max(1.0, dg_full.abs().max().item()) * np.sqrt(M)
+    assert (db - db_full).abs().max() < 2e-5 * max(1.0, db_full.abs().max().item()) * np.sqrt(M)
+    ref_cls = ops.class_reduce(g, gy_full, B, F)                  # class sums of the full result
+    assert torch.isfinite(gy).all() and float(gy.view(B, V, F)[:, hole].abs().max()) == 0.0
+    # the statistics differ in summation order only -> the coefficients, hence gy, to round-off
+    assert (gy - ref_cls).abs().max() < 5e-5 * max(1.0, ref_cls.abs().max().item())
+    # pair-sums leave the holes out: S(class sums) = the class sums one level up (a class halves, its sum stays)
+    both = fmask[0::2] & fmask[1::2]
+    rep_c = np.where(both, rep[0::2] // 2, np.arange(V // 2))
+    rc = torch.as_tensor(rep_c, device="cuda", dtype=torch.long)
+    live_c = torch.as_tensor(rep_c == np.arange(V // 2), device="cuda")
+
+    def coarse_class_sums(t):
+        out = torch.zeros(B, V // 2, F, device="cuda", dtype=torch.float64)
+        out.index_add_(1, rc, ops.pair_sum(t, M // 2, F).view(B, V // 2, F).double())
+        return out[:, live_c]
+    assert (pgy.view(B, V // 2, F)[:, live_c].double() - coarse_class_sums(gy_full)).abs().max() \
+        < 1e-4 * max(1.0, ref_cls.abs().max().item())
+    assert (pgx.view(B, V // 2, F)[:, live_c].double() - coarse_class_sums(gx_full)).abs().max() < 1e-5
+    assert float(pgy.view(B, V // 2, F)[:, ~live_c].abs().max()) == 0.0          # hole parents: untouched zeros
+    gy.view(B, V, F)[:, hole] = float("nan")
+    assert torch.equal(ops.pair_sum(gy, M // 2, F, classes=g).view(B, V // 2, F)[:, live_c],
+                       pgy.view(B, V // 2, F)[:, live_c])
+
+
 def _real_ids(L):
     """Vertices whose row is not the lone diagonal (the complement of the isolated padding vertices)."""
     L = L.tocsr()
