@@ -237,6 +237,15 @@ int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float*
                          int32_t N, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
                          void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
+/* The same contraction when C is the gradient flowing into a BatchNorm + ReLU layer (a backward step's dX): bn_y = that
+ * layer's raw input [rows of C][N], bn_co = its coefficients [4][N] (mean, invstd, scale, shift: the layout
+ * p2m_bn_finalize* writes), bn_part = [B * p2m_rows_tiles_per_sample][2][N].  The epilogue also emits the partials
+ * p2m_bn_bwd_reduce would (sum g, sum g*yhat with g = C masked by the ReLU) -- that separate pass over C and bn_y is
+ * then skipped; p2m_bn_bwd_finalize consumes bn_part.                                                              */
+int p2m_gemm_planes_rows_bnbwd(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                               const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
+                               const float* Bm, const void* Bsplit, const float* addend, float* C, int32_t N,
+                               const float* bn_y, const float* bn_co, float* bn_part, void* stream);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,

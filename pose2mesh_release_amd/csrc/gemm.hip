@@ -57,6 +57,16 @@ struct GemmArgs {
   // split-bf16 mode (k_gemm_planes_bx): Bx[k / 16][s][n][k % 16], s < 3, n < Npad, k < Ktot = nplanesA * Ka
   const unsigned short* Bx;
   int Npad, Ktot;
+  // optional (EXTRA kernels): the result C is the gradient w.r.t. the output of a BatchNorm + ReLU layer whose raw
+  // input is bn_y [rows of C][N]; the reduction pass of that layer's backward rides in this epilogue:
+  //   bn_part[tile][0][n] = sum_rows g,  bn_part[tile][1][n] = sum_rows g (y - mean) invstd,   g = C masked by the ReLU
+  // (the partial layout of k_bn_bwd_reduce, consumed by p2m_bn_bwd_finalize).
+  const float* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  float* bn_part;
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -123,6 +133,51 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         }
       }
     }
+  if (EXTRA && g.bn_part != nullptr) {
+    // BatchNorm-backward reduction of the layer that produced this contraction's input rows (see GemmArgs::bn_y)
+    float* red = smem;  // [2 (kind)][2 (wm)][BN]
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = ncol[j];
+      float s0 = 0.f, s1 = 0.f;
+      if (n < g.N) {
+        const float bsc = g.bn_scale[n], bsh = g.bn_shift[n], bmu = g.bn_mean[n], bis = g.bn_invstd[n];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const long row = ROWS ? (long)rowtab[ml] : m0 + ml;
+            const bool rok = ROWS ? (row >= 0) : (row < g.M);
+            if (rok) {
+              const float yv = g.bn_y[row * g.N + n];
+              const float gv = fmaf(yv, bsc, bsh) > 0.f ? acc[i][j][r] : 0.f;
+              s0 += gv;
+              s1 = fmaf(gv, (yv - bmu) * bis, s1);
+            }
+          }
+      }
+      s0 += __shfl_xor(s0, 32);
+      s1 += __shfl_xor(s1, 32);
+      if (lhi == 0) {
+        red[wm * BN + wn * WTN + j * 32 + l31] = s0;
+        red[2 * BN + wm * BN + wn * WTN + j * 32 + l31] = s1;
+      }
+    }
+    __syncthreads();
+    if (wm == 0 && lhi == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int cl = wn * WTN + j * 32 + l31;
+        const int n = n0 + cl;
+        if (n < g.N) {
+          float* pt = g.bn_part + (long)mt * 2 * g.N;
+          pt[n] = red[cl] + red[BN + cl];
+          pt[g.N + n] = red[2 * BN + cl] + red[3 * BN + cl];
+        }
+      }
+    }
+  }
   if (g.stats == nullptr) return;
 
   // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
@@ -838,10 +893,13 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
 #endif
   if (!producer) {
     gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
-  } else if (g.stats != nullptr) {              // the three block barriers of the statistics reduction
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
+  } else {
+    if (EXTRA && g.bn_part != nullptr) __syncthreads();   // the block barrier of the BatchNorm-backward reduction
+    if (g.stats != nullptr) {                   // the three block barriers of the statistics reduction
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+    }
   }
 }
 
@@ -1655,13 +1713,24 @@ __global__ __launch_bounds__(32 * UNP_CG) void k_weight_grad_unpack(
     const long o = (long)fout * Fin * K + (long)fin * K + k;
     dW[o] = accumulate ? dW[o] + (float)r : (float)r;
   }
-  // bias gradient: the first blocks also reduce Pdb (one thread per output feature)
-  if (db != nullptr && Pdb != nullptr && cg == 0 && idx < Fout) {
+  // bias gradient: the first blocks also reduce Pdb (one output feature per lane, the chunks spread over the UNP_CG
+  // lane groups and merged through LDS: a single thread walking all chunks was the kernel's long pole)
+  if (db != nullptr && Pdb != nullptr && (long)blockIdx.x * 32 < Fout) {      // block-uniform
+    __syncthreads();
     double r = 0.0;
-    for (int c = 0; c < nchunks; c++) r += (double)Pdb[(long)c * pdb_stride + idx];
-    if (Pdb2 != nullptr)
-      for (int c2 = 0; c2 < nchunks2; c2++) r += (double)Pdb2[(long)c2 * Fout + idx];
-    db[idx] = accumulate ? db[idx] + (float)r : (float)r;
+    if (idx < Fout) {
+      for (int c = cg; c < nchunks; c += UNP_CG) r += (double)Pdb[(long)c * pdb_stride + idx];
+      if (Pdb2 != nullptr)
+        for (int c2 = cg; c2 < nchunks2; c2 += UNP_CG) r += (double)Pdb2[(long)c2 * Fout + idx];
+    }
+    red[cg][e] = r;
+    __syncthreads();
+    if (cg == 0 && idx < Fout) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < UNP_CG; q++) t += red[q][e];
+      db[idx] = accumulate ? db[idx] + (float)t : (float)t;
+    }
   }
 }
 
@@ -1756,6 +1825,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   P2M_CHECK_ARG((addend == nullptr && !pair_out) || nplanesC == 1, "addend / pair_out need a single output plane");
   P2M_CHECK_ARG(!(pair_out && stats), "pair_out and stats are mutually exclusive");
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = pair_out; g.stats = stats; g.M = M;
+  g.bn_y = g.bn_scale = g.bn_shift = g.bn_mean = g.bn_invstd = nullptr; g.bn_part = nullptr;
   g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
@@ -1784,12 +1854,16 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   return check_launch("gemm_planes");
 }
 
-extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
-                                    const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
-                                    const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
-                                    const float* act_shift, int32_t act_relu, void* stream) {
+static int gemm_planes_rows_impl(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                                const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
+                                int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
+                                const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
+                                const float* act_shift, int32_t act_relu, const float* bn_y, const float* bn_co,
+                                float* bn_part, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
+  P2M_CHECK_ARG((bn_y == nullptr) == (bn_part == nullptr) && (bn_y == nullptr) == (bn_co == nullptr),
+                "bn_y / bn_co / bn_part must all be given or all NULL");
+  P2M_CHECK_ARG(!(bn_part && (stats || act_scale || act_relu)), "the BatchNorm-backward reduction excludes stats / activation");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
@@ -1812,8 +1886,33 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   g.Ktot = nplanesA * Ka;
   g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
   g.ntm = B * g.tps;
-  launch_gemm_planes<true>(g, addend != nullptr, (hipStream_t)stream);
+  g.bn_y = bn_y; g.bn_part = bn_part;
+  g.bn_mean = bn_co; g.bn_invstd = bn_co ? bn_co + N : nullptr;
+  g.bn_scale = bn_co ? bn_co + 2 * N : nullptr; g.bn_shift = bn_co ? bn_co + 3 * N : nullptr;
+  launch_gemm_planes<true>(g, addend != nullptr || bn_part != nullptr, (hipStream_t)stream);
   return check_launch("gemm_planes_rows");
+}
+
+extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                                    const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
+                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
+                                    const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
+                                    const float* act_shift, int32_t act_relu, void* stream) {
+  return gemm_planes_rows_impl(gh, row_set, B, A0, A1, A2, nplanesA, Ka, a0_shift, planes_compact, Bm, Bsplit, bias,
+                               addend, C, N, stats, act_scale, act_shift, act_relu, nullptr, nullptr, nullptr, stream);
+}
+
+// The dX contraction of a backward step whose result feeds a BatchNorm + ReLU layer: bn_y = that layer's raw input
+// [rows of C][N], bn_co = its coefficients [4][N] (mean, invstd, scale, shift as p2m_bn_finalize* writes them), bn_part =
+// [B * p2m_rows_tiles_per_sample(g, row_set)][2][N] partials in the layout p2m_bn_bwd_finalize reads (the separate
+// p2m_bn_bwd_reduce pass over C and bn_y is then not needed).
+extern "C" int p2m_gemm_planes_rows_bnbwd(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
+                                          int32_t planes_compact, const float* Bm, const void* Bsplit,
+                                          const float* addend, float* C, int32_t N, const float* bn_y,
+                                          const float* bn_co, float* bn_part, void* stream) {
+  return gemm_planes_rows_impl(gh, row_set, B, A0, A1, A2, nplanesA, Ka, a0_shift, planes_compact, Bm, Bsplit, nullptr,
+                               addend, C, N, nullptr, nullptr, nullptr, 0, bn_y, bn_co, bn_part, stream);
 }
 
 // rows per sample tile count of a row set (for the BatchNorm finalize): tiles_per_sample = ceil(n / 128)

@@ -355,6 +355,7 @@ class _MeshNetFn(torch.autograd.Function):
                     self.cm.__exit__(*a)
                 return False
         Gs_block = None    # S G of the current block (pair-sum of the gradient w.r.t. the block output), when produced
+        bn_part = None     # backward-reduction partials of the NEXT conv to be processed, when its dX contraction made them
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
@@ -411,6 +412,14 @@ class _MeshNetFn(torch.autograd.Function):
             # pair-sums this block's first conv will need come out of the BatchNorm-backward pass as by-products:
             # S G (the residual gradient at the coarser resolution) when G is read as g_cur by the block's last conv,
             # S gy (plane 0 of the paired operator) when the first conv's own gy is written
+            # dX of this conv is the gradient flowing into the previous conv's BatchNorm + ReLU (same tensor, nothing
+            # added afterwards): that layer's backward reduction then rides in the epilogue of the dX contraction
+            prev = net._layers[L.ci - 1] if L.ci > 0 else None
+            bn_next = None
+            if ops.BN_BWD_IN_EPILOGUE and prev is not None and prev.has_bn and _bwd_forward_form(L) and gph.split \
+                    and not ops.fused_supported(L.Fout, L.Fin) and not (has_res and not fuse_res) \
+                    and (prev.block == L.block or L.block >= 2) and (pair_path or not x_shift):
+                bn_next = (saved[prev.ci][4], saved[prev.ci][5])           # (y, co) of the previous conv
             want_Gs = want_P0 = False
             if L.has_bn and M % 2 == 0 and L.Fout in (32, 64, 128, 256):
                 if L.last_in_block and not L.first_in_block:
@@ -424,7 +433,8 @@ class _MeshNetFn(torch.autograd.Function):
                 tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
                 res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
-                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, **kw)
+                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, part=bn_part, **kw)
+                bn_part = None
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
@@ -457,7 +467,7 @@ class _MeshNetFn(torch.autograd.Function):
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0)
+                P0, E1, E2, bn_part = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0, bn=bn_next)
                 with side_ctx(keep, X, P0, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False)
@@ -475,8 +485,8 @@ class _MeshNetFn(torch.autograd.Function):
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                E1, E2, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a, gph.fake_b,
-                                              operands=opb)
+                E1, E2, bn_part, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
+                                                    gph.fake_b, operands=opb, bn=bn_next)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers

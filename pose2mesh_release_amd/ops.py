@@ -99,6 +99,10 @@ DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
 PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
+# the BatchNorm-backward reduction of a layer in the epilogue of the contraction that produces its incoming gradient
+# (p2m_gemm_planes_rows_bnbwd).  OFF by default: measured 5 330 vs 5 660 meshes/s -- the epilogue's 4-byte reads of the
+# layer's raw input cost the contraction more (+4.5 ms) than the separate streaming pass they replace (3.3 ms)
+BN_BWD_IN_EPILOGUE = _os.environ.get("P2M_BN_BWD_EPILOGUE", "0") == "1"
 # classes of identical fake rows inside the coarse-to-fine stack (include/p2m.h): only one representative of every run of
 # identical padding rows is computed; 0 = every row (the A/B form)
 CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
@@ -365,9 +369,12 @@ def weight_split(Bm):
     return Bx
 
 
-def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None):
+def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None,
+                     bn=None):
     """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None.
-    Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
+    Bx: the pre-split copy of Bm (weight_split) when the caller has it cached.
+    bn = (y, co, part): C is the gradient flowing into the BatchNorm + ReLU layer with raw input y and coefficients co;
+    the epilogue also writes that layer's backward-reduction partials into part[B * tiles][2][N] (bn_part_rows)."""
     n = g.set_size(row_set)
     st = None
     weighted = stats and row_set == 2 and g.classes     # representatives count once per class member: separate pass
@@ -377,6 +384,14 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     fl = 2.0 * B * n * len(A) * Ka * N
     # algorithmic HBM bytes: every A plane row once, the output once (weights come from L2)
+    if bn is not None:
+        with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + 2 * N))):
+            check(_lib.hip().p2m_gemm_planes_rows_bnbwd(
+                g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift, int(compact), _p(_req(Bm, "B")),
+                _p(Bx if Bx is not None else weight_split(Bm)), _p(addend if addend is None else _req(addend, "addend")),
+                _p(C), N, _p(_req(bn[0], "bn y")), _p(_req(bn[1], "bn coefficients")), _p(bn[2]), _stream()),
+                "p2m_gemm_planes_rows_bnbwd")
+        return None
     with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + N))):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
                                               int(compact), _p(_req(Bm, "B")),
@@ -426,7 +441,16 @@ def cheb_basis_pair(g, G, B, F):
     return P1, P2
 
 
-def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
+def bn_part_rows(g, sets, B, N, device):
+    """Partials buffer of a BatchNorm-backward reduction fused into the two row-set launches of one contraction:
+    (whole buffer, slice of the first set, slice of the second set)."""
+    lib = _lib.hip()
+    t = [B * int(lib.p2m_rows_tiles_per_sample(g.handle, rs)) if g.set_size(rs) > 0 else 0 for rs in sets]
+    part = torch.empty((t[0] + t[1], 2, N), device=device, dtype=torch.float32)
+    return part, part[:t[0]], part[t[0]:]
+
+
+def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, bn=None):
     """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
     C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
     P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
@@ -434,17 +458,27 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
         P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
     P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
     Bx, We, Wex = operands
-    gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
-    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
-    return P0, P1c, P2c
+    part, pa, pb = bn_part_rows(g, (3, 4), B, N, C.device) if bn is not None else (None, None, None)
+    gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx,
+                     bn=None if bn is None else (bn[0], bn[1], pa))
+    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex,
+                     bn=None if bn is None else (bn[0], bn[1], pb))
+    return P0, P1c, P2c, part
 
 
-def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None):
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, bn=None):
     """One split contraction: basis planes of the real vertices, the real-vertex GEMM (K = 3*Ka), then the fake-vertex
     GEMM (K = Ka, W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's
     basis on a side stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake)."""
     T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
+    if bn is not None:          # backward use: bn = (y, co) of the layer C flows into; returns the reduction partials
+        part, pa, pb = bn_part_rows(g, (1, 2), B, N, C.device)
+        gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, False, Bx=Bx,
+                         bn=(bn[0], bn[1], pa))
+        gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, False, Bx=Wex,
+                         bn=(bn[0], bn[1], pb))
+        return T1c, T2c, part, None
     st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx)
     st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
     return T1c, T2c, st1, st2
@@ -658,23 +692,28 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None):
 
 
 def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False,
-                classes=None, zero_holes=False):
+                classes=None, zero_holes=False, part=None):
     """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
     pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
     (gy, dgamma, dbeta, pair_gx or None, pair_gy or None).
     classes: the level's DeviceGraph (include/p2m.h "classes"): holes are skipped -- not read, not written; zero_holes:
     the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows)."""
     lib = _lib.hip()
-    nblk = int(lib.p2m_bn_bwd_blocks(M, F))
-    part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
+    have_part = part is not None        # the reduction already ran in the epilogue of the contraction that produced gx
+    if have_part:
+        nblk = part.shape[0]
+    else:
+        nblk = int(lib.p2m_bn_bwd_blocks(M, F))
+        part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
     acc = 1 if dgamma is not None else 0
     if dgamma is None:
         dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
         dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
     cls = classes.handle if (classes is not None and classes.classes) else None
-    check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
-                                int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
+    if not have_part:
+        check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
+                                    int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     alloc = torch.zeros if (zero_holes and cls is not None) else torch.empty
