@@ -197,6 +197,36 @@ def test_configs2_default_vs_independent_kernel_set(hip_libs, tmp_path):
     assert err <= VERTEX_TOL
 
 
+@pytest.mark.parametrize("env,fwd_bitwise", [({"P2M_CLASSES": "0"}, False), ({"P2M_PAIR_BWD": "0"}, True),
+                                             ({"P2M_BN_BWD_EPILOGUE": "1"}, True)])
+def test_algebraic_shortcuts_against_their_plain_forms(hip_libs, tmp_path, env, fwd_bitwise):
+    """The default path's exact algebraic shortcuts -- classes of identical fake rows (only one representative of a run of
+    identical padding rows is computed), the backward of un-pooled convs at the coarse resolution -- and the opt-in
+    epilogue form of the BatchNorm-backward reduction, each against the same network with the knob flipped (child
+    process; human36, B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
+    out = str(tmp_path / "plain.npz")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, "human36", "3", "train",
+                        "13", "21", "5"], env=dict(os.environ, P2M_TEST_TAP="1", **env), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = np.load(out)
+    hip = _hip_run("human36", 3, "train", 13, 21, 5, tap=True)
+    o = hip["out"].cpu().numpy()
+    if fwd_bitwise and "P2M_PAIR_BWD" not in env:
+        assert np.array_equal(o, ref["out"])                 # the forward is untouched by a backward-only knob
+    assert helpers.max_vertex_l2(hip["out"].cpu(), ref["out"]) <= 1e-5
+    nflip = 0
+    for k in (k for k in hip if k.startswith("mask::")):
+        nflip += int(np.unpackbits(np.packbits(hip[k].cpu().numpy().reshape(-1)) ^ ref[k]).sum())
+    grads_h = {k[6:]: v for k, v in hip.items() if k.startswith("grad::")}
+    grads_r = {k[6:]: ref[k] for k in ref.files if k.startswith("grad::")}
+    # identical masks -> round-off only; a few flipped kink elements -> the 1e-2 that count explains (test (c))
+    _compare_grads(grads_h, grads_r, 5e-5 if nflip == 0 else 1e-2, "ab_" + "_".join(env), True)
+    for k in ref.files:
+        if k.startswith("state::"):
+            assert np.abs(hip[k].cpu().numpy() - ref[k]).max() < 1e-5, k
+
+
 def test_train_mode_is_bitwise_repeatable(hip_libs):
     """(e) BN partial merge + side-stream dW + row-set split: two identical fwd+bwd give identical bits."""
     a = _hip_run("human36", 4, "train", 7, 8, 9)
