@@ -235,6 +235,9 @@ def cpu_baseline(joint_set, budget_s, edge_loss=True, batch=32, mode="train"):
     what = "train steps (fwd + 5 losses + bwd + Adam)" if mode == "train" else "eval forwards + Tester epilogue"
     return {"value": round(B * n / dt, 3), "unit": "meshes/s", "cores": threads, "kind": "port", "nproc": nproc,
             "cpu_model": cpu_model, "threads": threads, "torch": torch.__version__,
+            # tools/cpu_port_vs_reference.py (build container, B=8, 8 threads): the port needs 1.33x the time of the real
+            # reference code for the same step (identical loss): this baseline is that much slower than the reference
+            "port_over_reference_time": 1.328,
             "sample": f"{n} {what} at batch {B} after 1 warm-up, same synthetic "
                       f"{'MANO' if mano else 'SMPL'}-like mesh, inputs and losses; oracle port of the reference CPU "
                       f"path (same torch.sparse.mm -> cat -> permute -> Linear -> BatchNorm1d sequence), "
@@ -270,7 +273,7 @@ def main():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "rmsprop"])
     ap.add_argument("--no-edge-loss", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--cpu-seconds", type=float, default=45.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--stock-losses", action="store_true", help="use the stock-torch loss modules instead of p2m_mesh_loss")
     ap.add_argument("--infer-path", default="graph", choices=["graph", "eager", "general"],

@@ -343,6 +343,7 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
 // row from LDS: the per-entry {a, b, local index} is a broadcast ds_read_b128, the data a conflict-free ds_read_b128.
 // Entry order = merged-CSR order and the same fmaf chain as k_basis_fwd: results are bitwise identical to it.
 // ---------------------------------------------------------------------------------------------
+namespace p2m {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int LPR>
@@ -440,6 +441,8 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
     }
   }
 }
+
+}  // namespace p2m
 
 static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
                             int32_t in_shift, int real_only, void* stream) {
