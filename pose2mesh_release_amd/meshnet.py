@@ -182,8 +182,13 @@ class _MeshNetFn(torch.autograd.Function):
         training = net.training
         wc = net._weight_cache
         J, cin = net.num_joint, net.num_joint_input_chan
+        if net._prefetch_event is not None:       # operands built on the helper stream (prefetch_operands)
+            torch.cuda.current_stream().wait_event(net._prefetch_event)
+            net._prefetch_event = None
         if training:
-            ops.bump_weight_epoch()       # running statistics change behind torch's back: cached eval coefficients are stale
+            if not net._epoch_bumped:
+                ops.bump_weight_epoch()   # running statistics change behind torch's back: cached eval coefficients are stale
+            net._epoch_bumped = False
         elif not keep and net._infer_real_only:
             ctx.saved = None
             return _forward_inference(net, graphs, x, params)
@@ -602,6 +607,7 @@ class Pose2Mesh(nn.Module):
         self._layers = layers
         self._block_first = {L.block: i for i, L in enumerate(layers) if L.first_in_block}
         self._class_rep = {}
+        self._prefetch_event, self._epoch_bumped = None, False
         self._graph_cache = ops.GraphCache(graph_L, class_plan=self._class_plan)
         self._weight_cache = ops.WeightCache()
         self._direct_grad = False
@@ -704,6 +710,57 @@ class Pose2Mesh(nn.Module):
             t = torch.from_numpy(inv).to(device)
             self._out_index[device] = t
         return t
+
+    def prefetch_operands(self):
+        """Train mode only: build this step's derived weight operands (packed / transposed / pre-split / fake-vertex
+        effective copies: ~110 tiny launches that would otherwise sit one by one in front of the convs that use them) on
+        the helper stream, ordered after everything already issued, while the caller keeps the main stream busy with
+        something else (FlatPose2Mesh: PoseNet).  The next forward waits for them once.  Same builders and cache keys as
+        the forward / backward (tests/test_gpu_train.py asserts that nothing is left for them to build)."""
+        if not (self.training and torch.is_grad_enabled() and ops.PREFETCH_OPERANDS):
+            return
+        names, params = self._param_list()
+        dev = params[0].device
+        if dev.type != "cuda" or not ops.DW_SIDE_STREAM:
+            return
+        P, wc = self._param_index, self._weight_cache
+        with torch.cuda.device(dev):
+            graphs = self._graph_cache.on(dev)
+            main = torch.cuda.current_stream()
+            side = ops.side_stream(dev)
+            side.wait_stream(main)
+            ops.bump_weight_epoch()
+            self._epoch_bumped = True
+            with torch.cuda.stream(side):
+                fw = params[P["fc.weight"]]
+                wc.get("fc", fw, lambda: _fc_operands(fw))
+                wc.get("fc_bwd", fw, lambda: ops.weight_split(fw)
+                       if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
+                for L in self._layers:
+                    g = graphs[L.graph]
+                    W = params[P[f"cl.{L.ci}.weight"]]
+                    if _narrow(L):
+                        Wp, _ = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
+                        wc.get((L.ci, "narrow_bwd"), W, lambda: _transposed_operands(Wp))
+                        continue
+                    fwd_fused = ops.fused_supported(L.Fin, L.Fout)
+                    bwd_fused = ops.fused_supported(L.Fout, L.Fin)
+                    fform = _bwd_forward_form(L)
+                    want_w3 = bwd_fused or fform
+                    Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
+                                                                                   need_w3=want_w3))
+                    if g.split and fform and not fwd_fused:
+                        wc.get((L.ci, "split_fwd"), W,
+                               lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
+                    elif not fwd_fused and L.Fin % 32 == 0 and L.Fout % 32 == 0:
+                        wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
+                    if not bwd_fused and fform:
+                        if g.split:
+                            wc.get((L.ci, "split_bwd"), W,
+                                   lambda: ops.split_operands(W3, L.Fout, L.Fin, g.fake_a, g.fake_b))
+                        else:
+                            wc.get((L.ci, "w3x"), W, lambda: ops.weight_split(W3))
+                self._prefetch_event = side.record_event()
 
     def forward(self, x):
         _, params = self._param_list()

@@ -99,6 +99,10 @@ DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
 PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
+# derived weight operands of a train step built on the helper stream under PoseNet (Pose2Mesh.prefetch_operands).
+# OFF by default: measured neutral (5 677 / 5 690 with, 5 704 / 5 706 meshes/s without, same box) -- the ~110 tiny
+# launches cost the in-order main stream less than their stand-alone durations suggest
+PREFETCH_OPERANDS = _os.environ.get("P2M_PREFETCH", "0") == "1"
 # the BatchNorm-backward reduction of a layer in the epilogue of the contraction that produces its incoming gradient
 # (p2m_gemm_planes_rows_bnbwd).  OFF by default: measured 5 330 vs 5 660 meshes/s -- the epilogue's 4-byte reads of the
 # layer's raw input cost the contraction more (+4.5 ms) than the separate streaming pass they replace (3.3 ms)
@@ -329,6 +333,7 @@ def bump_weight_epoch():
 class WeightCache:
     def __init__(self):
         self._d = {}
+        self.builds = 0          # builder calls so far (tests: a prefetched step builds nothing in its forward / backward)
 
     def get(self, key, W, builder):
         """W: the source tensor, or a tuple of source tensors."""
@@ -339,6 +344,7 @@ class WeightCache:
         if hit is not None and hit[0] == tag:
             return hit[1]
         val = builder()
+        self.builds += 1
         self._d[key] = (tag, val)
         return val
 
