@@ -270,6 +270,25 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                           int32_t N, void* stream);
 
+/* ---- project-then-combine form of an un-pooled conv -----------------------------------------------------------
+ * A conv whose input was un-pooled x2 sees X_fine[r] = X[r >> 1] (meshnet.py:71-78,111), so
+ *     y = [X_fine | L X_fine | L2 X_fine] W = Z0[r >> 1] + sum_j a_j Z1[col_j >> 1] + b_j Z2[col_j >> 1],
+ *     Z = X [W0 | W1 | W2]:   [B * V/2, 3 N], ONE contraction over the coarse rows (p2m_gemm_planes[_rows], K = Fin),
+ * and the sparse stage gathers N-wide rows of Z1 | Z2 (LDS-staged, the level's in_shift = 1 tile plan) instead of
+ * writing two Fin-wide planes.  p2m_cheb_project_combine computes the real rows of Y [B*V, N] (N % 64 == 0), optionally
+ * with the fused eval-mode BatchNorm + ReLU, or with BatchNorm partials stats[B * ntiles(plan 1)][2][N] for
+ * p2m_bn_finalize_combine; _fake computes the fake rows (row set 2: y = Z0[p] + a Z1[p] + b Z2[p], p the parent),
+ * whose partials are p2m_gemm_planes_rows-style tiles (no classes) or p2m_stats_rows_w (classes).                    */
+int p2m_cheb_project_combine(p2m_graph_t g, const float* Z, const float* bias, const float* act_scale,
+                             const float* act_shift, int32_t act_relu, float* Y, float* stats, int32_t B, int32_t N,
+                             void* stream);
+int p2m_cheb_project_combine_fake(p2m_graph_t g, const float* Z, const float* bias, float* Y, int32_t B, int32_t N,
+                                  void* stream);
+int p2m_bn_finalize_combine(p2m_graph_t g, const float* stats_real, const float* stats_fake, int32_t B,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                            int32_t N, void* stream);
+
 /* ---- classes of identical fake rows ------------------------------------------------------------------------
  * Inside the coarse-to-fine stack every descendant of a fake vertex is fake, isolated and produced by the same per-row
  * arithmetic from the same un-pooled value (meshnet.py:71-78: both children copy the parent): in the tree order the

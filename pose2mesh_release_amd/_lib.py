@@ -51,6 +51,10 @@ HIP_SYMBOLS = {
                                         _vp, _vp, _vp, _i32, _vp]),
     "p2m_bn_finalize_split": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
                                          _vp]),
+    "p2m_cheb_project_combine": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "p2m_cheb_project_combine_fake": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "p2m_bn_finalize_combine": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
+                                           _vp]),
     "p2m_graph_fake_ids": (_c.c_int, [_vp, _vp]),
     "p2m_graph_set_classes": (_c.c_int, [_vp, _vp]),
     "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),

@@ -809,15 +809,15 @@ extern "C" int p2m_bn_finalize(const float* stats, int32_t ntiles, int64_t M, co
                          scale, shift, N, (hipStream_t)stream, "bn_finalize");
 }
 
-static int finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* stats_b,
-                         int32_t tps_b, int32_t rows_b, const float* tile_w_b, int32_t B,
+static int finalize_rows(const float* stats_a, int32_t tps_a, int32_t rows_a, const float* tile_w_a,
+                         const float* stats_b, int32_t tps_b, int32_t rows_b, const float* tile_w_b, int32_t B,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          float momentum, float eps, float* mean, float* invstd, float* scale,
                          float* shift, int32_t N, void* stream) {
   P2M_CHECK_ARG(stats_a && gamma && beta && mean && invstd && scale && shift && N > 0 && B > 0, "null pointer or empty shape");
   P2M_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats must both be given or both NULL");
   const int tile_rows = p2m_stats_tile_rows();
-  StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a, nullptr};
+  StatSeg a{stats_a, B * tps_a, tps_a, (long)rows_a, tile_w_a};
   StatSeg b{stats_b, stats_b ? B * tps_b : 0, tps_b > 0 ? tps_b : 1, (long)rows_b, stats_b ? tile_w_b : nullptr};
   const long M = (long)B * ((long)rows_a + (stats_b ? (long)rows_b : 0));
   return finalize_launch(a, b, M, tile_rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
@@ -828,7 +828,7 @@ extern "C" int p2m_bn_finalize_rows(const float* stats_a, int32_t tps_a, int32_t
                                     int32_t tps_b, int32_t rows_b, int32_t B, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                     float* invstd, float* scale, float* shift, int32_t N, void* stream) {
-  return finalize_rows(stats_a, tps_a, rows_a, stats_b, tps_b, rows_b, nullptr, B, gamma, beta, running_mean,
+  return finalize_rows(stats_a, tps_a, rows_a, nullptr, stats_b, tps_b, rows_b, nullptr, B, gamma, beta, running_mean,
                        running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
 }
 
@@ -841,7 +841,22 @@ extern "C" int p2m_bn_finalize_split(p2m_graph_t gh, const float* stats_real, co
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
   const int tile_rows = p2m_stats_tile_rows();
   const int rows_fake = g.w ? g.n_fake_all : g.n_fake;      // with classes: the statistics count every fake vertex
-  return finalize_rows(stats_real, cdiv(g.n_real, tile_rows), g.n_real, g.n_fake > 0 ? stats_fake : nullptr,
+  return finalize_rows(stats_real, cdiv(g.n_real, tile_rows), g.n_real, nullptr, g.n_fake > 0 ? stats_fake : nullptr,
+                       cdiv(g.n_fake, tile_rows), rows_fake, g.w ? g.fake_tile_w : nullptr, B, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
+}
+
+// the same when the real-vertex partials come from p2m_cheb_project_combine: one tile of the in_shift = 1 plan each
+extern "C" int p2m_bn_finalize_combine(p2m_graph_t gh, const float* stats_real, const float* stats_fake, int32_t B,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       float momentum, float eps, float* mean, float* invstd, float* scale,
+                                       float* shift, int32_t N, void* stream) {
+  P2M_CHECK_ARG(gh, "null graph");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  P2M_CHECK_ARG(g.plan[1].ntiles > 0, "this level has no in_shift = 1 tile plan");
+  const int tile_rows = p2m_stats_tile_rows();
+  const int rows_fake = g.w ? g.n_fake_all : g.n_fake;
+  return finalize_rows(stats_real, g.plan[1].ntiles, g.n_real, g.plan[1].tile_cnt, g.n_fake > 0 ? stats_fake : nullptr,
                        cdiv(g.n_fake, tile_rows), rows_fake, g.w ? g.fake_tile_w : nullptr, B, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
 }

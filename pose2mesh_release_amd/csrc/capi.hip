@@ -99,8 +99,11 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
     tile_u.push_back((int)ucol.size());
   }
   if (tile_row.size() < 2) return P2M_OK;
+  std::vector<float> tile_cnt(tile_row.size() - 1);
+  for (size_t q = 0; q + 1 < tile_row.size(); q++) tile_cnt[q] = (float)(tile_row[q + 1] - tile_row[q]);
   int rc;
-  if ((rc = upload(tile_row.data(), sizeof(int) * tile_row.size(), (void**)&pl.tile_row)) != P2M_OK ||
+  if ((rc = upload(tile_cnt.data(), sizeof(float) * tile_cnt.size(), (void**)&pl.tile_cnt)) != P2M_OK ||
+      (rc = upload(tile_row.data(), sizeof(int) * tile_row.size(), (void**)&pl.tile_row)) != P2M_OK ||
       (rc = upload(tile_u.data(), sizeof(int) * tile_u.size(), (void**)&pl.tile_u)) != P2M_OK ||
       (rc = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
       (rc = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
@@ -273,6 +276,7 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
     if (pl.ucol) (void)hipFree(pl.ucol);
     if (pl.erow) (void)hipFree(pl.erow);
     if (pl.ent) (void)hipFree(pl.ent);
+    if (pl.tile_cnt) (void)hipFree(pl.tile_cnt);
   }
   delete g;
   return P2M_OK;

@@ -23,6 +23,7 @@ struct TilePlan {
   int* ucol = nullptr;        // union source rows (vertex id >> shift), ascending within a tile
   int* erow = nullptr;        // [n_real+1]  entry range of each compact row
   float4* ent = nullptr;      // per entry {a, b, bits(local index into the tile's union), 0}, merged-CSR order
+  float* tile_cnt = nullptr;  // [ntiles]    rows of each tile (as float: the weight of a tile's BatchNorm partials)
 };
 #ifndef P2M_TILE_RMAX
 #define P2M_TILE_RMAX 32

@@ -82,6 +82,23 @@ def _transposed_operands(Wp):
     return Wpt, ops.weight_split(Wpt)
 
 
+def _wcat_operands(W3):
+    """[Fin, 3*Fout] operand of the project-then-combine form: columns k*Fout + fo = W[fo][fin*3 + k] (W3 transposed)."""
+    Wc = W3.t().contiguous()
+    return Wc, ops.weight_split(Wc)
+
+
+def _project_combine(net, L, g, graphs, x_shift, real_only):
+    """Un-pooled convs whose forward takes the project-then-combine form (include/p2m.h): split level with an in_shift = 1
+    tile plan, widths the combine kernel supports; in train mode the fake rows' statistics need the classes."""
+    if not (ops.PROJECT_COMBINE and x_shift and g.split and L.first_in_block and L.ci > 0 and _bwd_forward_form(L)):
+        return False
+    if g.plan_tiles[1] == 0 or L.Fout % 64 or ops.fused_supported(L.Fin, L.Fout):
+        return False
+    gc = graphs[net._layers[L.ci - 1].graph]
+    return gc.V * 2 == g.V and (real_only or g.classes)
+
+
 def _fc_operands(fw):
     fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
     return fwt, (ops.weight_split(fwt) if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
@@ -134,7 +151,14 @@ def _forward_inference(net, graphs, x, params):
         Wt, _, _ = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
                                                                     need_w3=want_w3))
         mfma = L.Fin % 32 == 0 and L.Fout % 32 == 0
-        if g.split and mfma:
+        if _project_combine(net, L, g, graphs, cur_shift, True):
+            gc = graphs[net._layers[L.ci - 1].graph]
+            _, _, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=False, need_w3=True))
+            Wcat, Wcatx = wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
+            Z = ops.conv_project(gc, B, cur, L.Fin, Wcat, Wcatx, K_CHEB * L.Fout, real_only=True)
+            y, _ = ops.cheb_project_combine(g, gc, Z, bvec, B, L.Fout, act=act)
+            T1 = T2 = Z = None
+        elif g.split and mfma:
             y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
             T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
             Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
@@ -231,7 +255,16 @@ class _MeshNetFn(torch.autograd.Function):
             Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
                                                                            need_w3=want_w3))
             split = g.split and bwd_fwdform and not fwd_fused
-            if split:
+            if split and _project_combine(net, L, g, graphs, cur_shift, False):
+                # un-pooled input: the contraction at the coarse resolution, then the sparse combine on Fout-wide rows
+                gc = graphs[net._layers[L.ci - 1].graph]
+                Wcat, Wcatx = wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
+                Z = ops.conv_project(gc, B, cur, L.Fin, Wcat, Wcatx, K_CHEB * L.Fout)
+                y, st = ops.cheb_project_combine(g, gc, Z, bvec, B, L.Fout, stats=need_stats)
+                st2 = ops.cheb_project_combine_fake(g, Z, bvec, y, B, L.Fout, stats=need_stats)
+                T1 = T2 = Z = None
+                tile_rows = "combine"
+            elif split:
                 # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
@@ -254,7 +287,11 @@ class _MeshNetFn(torch.autograd.Function):
             if L.has_bn:
                 bn = net.bn[L.ci]
                 gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
-                if training and tile_rows == "rows":
+                if training and tile_rows == "combine":
+                    co = ops.bn_finalize_combine(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
+                                                 bn_momentum(bn), bn.eps)
+                    bn.num_batches_tracked.add_(1)
+                elif training and tile_rows == "rows":
                     co = ops.bn_finalize_rows(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
                                               bn_momentum(bn), bn.eps)
                     bn.num_batches_tracked.add_(1)
@@ -749,7 +786,10 @@ class Pose2Mesh(nn.Module):
                     want_w3 = bwd_fused or fform
                     Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
                                                                                    need_w3=want_w3))
-                    if g.split and fform and not fwd_fused:
+                    x_shift = int(L.first_in_block and 2 <= L.block <= len(self.CL_F) - 2)
+                    if g.split and fform and not fwd_fused and _project_combine(self, L, g, graphs, x_shift, False):
+                        wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
+                    elif g.split and fform and not fwd_fused:
                         wc.get((L.ci, "split_fwd"), W,
                                lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
                     elif not fwd_fused and L.Fin % 32 == 0 and L.Fout % 32 == 0:

@@ -99,6 +99,11 @@ DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
 PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
+# forward of un-pooled convs in project-then-combine form (include/p2m.h): the contraction at the coarse resolution.
+# OFF by default: measured 5 510 vs 5 584 meshes/s (train) and 4.04 vs 4.13 ms (inference, B=64) on the same box -- the
+# contraction saves 0.8 ms, but the combine has to stage Z1 | Z2 rows twice as wide as the x rows the basis kernel
+# stages (+1.1 ms); as an opt-in it is covered by the A/B parity test
+PROJECT_COMBINE = _os.environ.get("P2M_PROJECT_COMBINE", "0") == "1"
 # derived weight operands of a train step built on the helper stream under PoseNet (Pose2Mesh.prefetch_operands).
 # OFF by default: measured neutral (5 677 / 5 690 with, 5 704 / 5 706 meshes/s without, same box) -- the ~110 tiny
 # launches cost the in-order main stream less than their stand-alone durations suggest
@@ -454,6 +459,59 @@ def bn_part_rows(g, sets, B, N, device):
     t = [B * int(lib.p2m_rows_tiles_per_sample(g.handle, rs)) if g.set_size(rs) > 0 else 0 for rs in sets]
     part = torch.empty((t[0] + t[1], 2, N), device=device, dtype=torch.float32)
     return part, part[:t[0]], part[t[0]:]
+
+
+def conv_project(gc, B, Xc, Ka, Wcat, Wcatx, N3, real_only=False):
+    """Z = Xc [W0 | W1 | W2] over the rows of the coarse level gc that the fine level reads (real vertices, plus the fake
+    ones / their representatives unless real_only): [B * gc.V, N3]."""
+    Mc = B * gc.V
+    if gc.split:
+        Z = torch.empty((Mc, N3), device=Xc.device, dtype=torch.float32)
+        for rs in ((1,) if real_only else (1, 2)):
+            gemm_planes_rows(gc, rs, B, [Xc], Ka, 0, False, Wcat, None, None, Z, N3, Bx=Wcatx)
+        return Z
+    (Z,), _ = gemm_planes([Xc], Ka, 0, Wcat, None, Mc, N3, 1, False, Bx=Wcatx)
+    return Z
+
+
+def cheb_project_combine(g, gc, Z, bias, B, N, stats=False, act=None):
+    """Real rows of the un-pooled conv from Z (conv_project): Y [B*V, N] (other rows untouched), BatchNorm partials per
+    (sample, tile of the in_shift = 1 plan) when stats, fused eval BatchNorm + ReLU when act = (scale, shift, relu)."""
+    Y = torch.empty((B * g.V, N), device=Z.device, dtype=torch.float32)
+    st = torch.empty((B * g.plan_tiles[1], 2, N), device=Z.device, dtype=torch.float32) if stats else None
+    moved = 4.0 * B * N * (g.n_real + 3.0 * gc.n_real)           # Y rows written, the Z rows of the real parents read
+    with _timed("cheb_basis_fwd", (moved, 12.0 * B * g.V * N)):
+        check(_lib.hip().p2m_cheb_project_combine(g.handle, _p(_req(Z, "Z")), _p(bias if bias is None else _req(bias, "bias")),
+                                                  _p(None if act is None else act[0]),
+                                                  _p(None if act is None else act[1]), int(bool(act and act[2])),
+                                                  _p(Y), _p(st), B, N, _stream()), "p2m_cheb_project_combine")
+    return Y, st
+
+
+def cheb_project_combine_fake(g, Z, bias, Y, B, N, stats=False):
+    """Fake rows (row set 2; with classes: the representatives) of the same conv; returns their weighted partials."""
+    if g.n_fake == 0:
+        return None
+    check(_lib.hip().p2m_cheb_project_combine_fake(g.handle, _p(_req(Z, "Z")), _p(bias if bias is None else _req(bias, "bias")),
+                                                   _p(Y), B, N, _stream()), "p2m_cheb_project_combine_fake")
+    if not stats:
+        return None
+    if not g.classes:
+        raise P2MError("BatchNorm partials of the fake rows of a project-then-combine conv need classes")
+    tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, 2))
+    st = torch.empty((B * tps, 2, N), device=Y.device, dtype=torch.float32)
+    check(_lib.hip().p2m_stats_rows_w(g.handle, _p(Y), B, N, _p(st), _stream()), "p2m_stats_rows_w")
+    return st
+
+
+def bn_finalize_combine(g, B, st_real, st_fake, gamma, beta, running_mean, running_var, momentum, eps):
+    N = gamma.shape[0]
+    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
+    check(_lib.hip().p2m_bn_finalize_combine(g.handle, _p(st_real), _p(st_fake), B, _p(_req(gamma, "bn.weight")),
+                                             _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
+                                             float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
+                                             _stream()), "p2m_bn_finalize_combine")
+    return co
 
 
 def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, bn=None):

@@ -198,10 +198,12 @@ def test_configs2_default_vs_independent_kernel_set(hip_libs, tmp_path):
 
 
 @pytest.mark.parametrize("env,fwd_bitwise", [({"P2M_CLASSES": "0"}, False), ({"P2M_PAIR_BWD": "0"}, True),
-                                             ({"P2M_BN_BWD_EPILOGUE": "1"}, True)])
+                                             ({"P2M_BN_BWD_EPILOGUE": "1"}, True),
+                                             ({"P2M_PROJECT_COMBINE": "1"}, False)])
 def test_algebraic_shortcuts_against_their_plain_forms(hip_libs, tmp_path, env, fwd_bitwise):
     """The default path's exact algebraic shortcuts -- classes of identical fake rows (only one representative of a run of
     identical padding rows is computed), the backward of un-pooled convs at the coarse resolution -- and the opt-in
+    project-then-combine forward of un-pooled convs and the opt-in
     epilogue form of the BatchNorm-backward reduction, each against the same network with the knob flipped (child
     process; human36, B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
     out = str(tmp_path / "plain.npz")
