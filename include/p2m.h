@@ -57,7 +57,9 @@ const char* p2m_version(void);
  * K=3 Chebyshev recurrence T1 = L x, T2 = 2 L T1 - x (lib/models/backbones/cheby_graph_conv.py:25,28)
  * becomes ONE gather pass  T1 = L x, T2 = L2 x.  It also bakes the lists of real / isolated (padding) vertices
  * and, for levels that have both, the tile plans of the LDS-staged basis kernel (consecutive real rows grouped
- * by the union of their neighbourhoods, one plan per un-pool shift).                                       */
+ * by the union of their neighbourhoods: one plan per un-pool shift, one for the paired operator S L | S L2).
+ * The handle is immutable afterwards, with one exception: p2m_graph_set_classes, to be called (once) before the
+ * handle is used.                                                                                          */
 int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val,
                      int32_t V, int32_t nnz, p2m_graph_t* out);
 int p2m_graph_destroy(p2m_graph_t g);
