@@ -183,8 +183,10 @@ int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32
  *   finalize: dgamma, dbeta (accumulate!=0 adds), coef[0][f]=dbeta/M, coef[1][f]=dgamma/M
  *   apply:    gy = gamma*invstd*(go - coef0 - yhat*coef1)   (training)   |   gamma*invstd*go (eval, coef NULL) */
 int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F);
-/* classes (optional graph handle with p2m_graph_set_classes; NULL = every row counts): holes are skipped by the
- * reduction, and the apply pass adds the constant term of a representative once per class member.                  */
+int32_t p2m_bn_bwd_blocks_classes(p2m_graph_t classes, int64_t M, int32_t F);   /* blocks when `classes` is passed */
+/* classes (optional graph handle with p2m_graph_set_classes; NULL = every row counts): the passes walk the live rows
+ * of the level only (holes are neither read nor written; part then has p2m_bn_bwd_blocks_classes blocks), and the apply
+ * pass adds the constant term of a representative once per class member.                                           */
 int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
                       const float* mean, const float* invstd, int32_t relu, float* part,
                       int64_t M, int32_t F, p2m_graph_t classes, void* stream);

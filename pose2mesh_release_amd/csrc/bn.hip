@@ -113,8 +113,30 @@ __global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const fl
   shift_o[n] = beta[n] - rm[n] * sc;
 }
 
-// vertex index of a row that advanced by a small step: the modulo only runs when the sample boundary is crossed
-__device__ __forceinline__ unsigned wrapv(unsigned x, unsigned V) { return x >= V ? x % V : x; }
+// Row map of the streaming passes on a level with classes (include/p2m.h): they walk the LIVE rows only -- logical row
+// j = b * n + i  ->  actual row b * V + ids[i] -- so every lane always has a row to move (predicating the holes away
+// instead left a third of the loads in flight empty: 4.3 instead of 5+ TB/s).  ids == nullptr: identity.
+struct RowMap {
+  const float* w;      // per-vertex weight (1 real vertex, class size for a representative); with ids only
+  const int* ids;      // [n] live vertices of the level, ascending
+  unsigned n, V;
+};
+struct RowPos { unsigned b, i; };
+__device__ __forceinline__ RowPos row_pos(long j, const RowMap& m) {
+  RowPos p;
+  p.b = (unsigned)(j / m.n);
+  p.i = (unsigned)(j - (long)p.b * m.n);
+  return p;
+}
+__device__ __forceinline__ RowPos row_adv(RowPos p, unsigned step, const RowMap& m) {   // the division only at a wrap
+  p.i += step;
+  if (p.i >= m.n) {
+    const unsigned q = p.i / m.n;
+    p.b += q;
+    p.i -= q * m.n;
+  }
+  return p;
+}
 
 // ---- forward activation ---------------------------------------------------------------------
 __device__ __forceinline__ float lerp_feat(const float* __restrict__ row, int Fres, int F, int j) {
@@ -133,29 +155,28 @@ constexpr int ACT_UNROLL = 4;
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
                                                      const float* __restrict__ resid, int Fres, int res_shift,
-                                                     float* __restrict__ x, long M, int F,
-                                                     const float* __restrict__ w, int V) {
+                                                     float* __restrict__ x, long M, int F, RowMap m) {
   const int F4 = F >> 2;
   const int rpb = 256 / F4;                                  // rows per block pass
   const int f = (threadIdx.x % F4) * 4;
-  const long rbase = (long)blockIdx.x * rpb * ACT_UNROLL + threadIdx.x / F4;
+  const long rbase = (long)blockIdx.x * rpb * ACT_UNROLL + threadIdx.x / F4;   // logical rows (M of them)
   float4 v[ACT_UNROLL], q[ACT_UNROLL];
-  bool live[ACT_UNROLL];
+  long row[ACT_UNROLL];
   const bool same = resid != nullptr && Fres == F;
-  const unsigned vb = w ? (unsigned)rbase % (unsigned)V : 0u;
+  const bool mapped = m.ids != nullptr;
+  RowPos p0 = {0u, 0u};
+  if (mapped && rbase < M) p0 = row_pos(rbase, m);
 #pragma unroll
   for (int u = 0; u < ACT_UNROLL; u++) {
-    long r = rbase + (long)u * rpb;
-    if (r >= M) r = M - 1;                                   // clamped: keeps the loads unconditional
-    // classes: holes (w == 0) hold no data and nobody reads them -- neither loaded nor stored (measured against
-    // redirecting their lanes to one cached row, which keeps the loads unconditional: the predicated form is ~10 % faster)
-    live[u] = w == nullptr || w[wrapv(vb + (unsigned)(u * rpb), (unsigned)V)] != 0.f;
-    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    q[u] = v[u];
-    if (live[u]) {
-      v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
-      if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
+    const long j = rbase + (long)u * rpb;
+    long r = j < M ? j : M - 1;                               // clamped: keeps the loads unconditional
+    if (mapped) {
+      const RowPos pu = j < M ? row_adv(p0, (unsigned)(u * rpb), m) : row_pos(M - 1, m);
+      r = (long)pu.b * m.V + m.ids[pu.i];
     }
+    row[u] = r;
+    v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+    if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
   }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (scale != nullptr) {
@@ -164,9 +185,8 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y,
   }
 #pragma unroll
   for (int u = 0; u < ACT_UNROLL; u++) {
-    const long r = rbase + (long)u * rpb;
-    if (r >= M) break;
-    if (!live[u]) continue;
+    if (rbase + (long)u * rpb >= M) break;
+    const long r = row[u];
     float4 o = v[u];
     if (scale != nullptr) {
       o.x = fmaf(o.x, sc.x, sh.x); o.y = fmaf(o.y, sc.y, sh.y);
@@ -372,8 +392,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ gx, const float* __restrict__ y,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int relu, float* __restrict__ part, long M,
-                                                        const float* __restrict__ w, int V) {
+                                                        int relu, float* __restrict__ part, long M, RowMap m) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   __shared__ float red[2][RP][F];
@@ -387,26 +406,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
   long r1 = r0 + BWD_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
-  unsigned vb = w ? (unsigned)(r0 + rloc) % (unsigned)V : 0u;
+  const bool mapped = m.ids != nullptr;                     // M, r0, r1 count LOGICAL rows (the live ones) then
+  RowPos pb = {0u, 0u};
+  if (mapped && r0 + rloc < r1) pb = row_pos(r0 + rloc, m);
   for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
     float4 gq[4], vq[4];
-    bool live[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      long r = rb + (long)u * RP;
-      if (r >= r1) r = r1 - 1;
-      // holes (w == 0) hold no data: they are skipped (their bits may be NaN); their lanes re-read one cached row, so
-      // the loads stay unconditional and back to back without HBM traffic
-      live[u] = w == nullptr || w[wrapv(vb + (unsigned)(u * RP), (unsigned)V)] != 0.f;
-      if (!live[u]) r = r0;
+      const long j = rb + (long)u * RP;
+      long r = j < r1 ? j : r1 - 1;
+      if (mapped) {
+        const RowPos pu = j < r1 ? row_adv(pb, (unsigned)(u * RP), m) : row_pos(r1 - 1, m);
+        r = (long)pu.b * m.V + m.ids[pu.i];
+      }
       gq[u] = *reinterpret_cast<const float4*>(gx + r * F + f);
       vq[u] = *reinterpret_cast<const float4*>(y + r * F + f);
     }
-    if (w) vb = wrapv(vb + 4u * RP, (unsigned)V);
+    if (mapped) pb = row_adv(pb, 4u * RP, m);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (rb + (long)u * RP >= r1) break;
-      if (!live[u]) continue;
       float4 g = gq[u];
       const float4 v = vq[u];
       if (relu) {
@@ -440,16 +459,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_generic(const float* __re
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
-                                                                float* __restrict__ part, long M, int F,
-                                                                const float* __restrict__ w, int V) {
+                                                                float* __restrict__ part, long M, int F, RowMap m) {
   const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
   long r1 = r0 + BWD_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
   for (int f = threadIdx.x; f < F; f += 256) {
     const float sc = scale[f], sh = shift[f], mu = mean[f], is = invstd[f];
     float s0 = 0.f, s1 = 0.f;
-    for (long r = r0; r < r1; r++) {
-      if (w != nullptr && w[r % V] == 0.f) continue;
+    for (long j = r0; j < r1; j++) {
+      long r = j;
+      if (m.ids != nullptr) {
+        const RowPos pj = row_pos(j, m);
+        r = (long)pj.b * m.V + m.ids[pj.i];
+      }
       const float v = y[r * F + f];
       float g = gx[r * F + f];
       if (relu && fmaf(v, sc, sh) <= 0.f) g = 0.f;
@@ -468,17 +490,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ coef, int relu,
-                                                               float* __restrict__ gy, long M, int F,
-                                                               const float* __restrict__ w, int V) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+                                                               float* __restrict__ gy, long M, int F, RowMap m) {
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * F) return;
   const int f = (int)(idx % F);
+  float wr = 1.f;
+  if (m.ids != nullptr) {
+    const RowPos pj = row_pos(idx / F, m);
+    const unsigned vtx = (unsigned)m.ids[pj.i];
+    wr = m.w[vtx];
+    idx = ((long)pj.b * m.V + vtx) * F + f;
+  }
   const float v = y[idx];
   float go = gx[idx];
   if (relu && fmaf(v, scale[f], shift[f]) <= 0.f) go = 0.f;
   const float k = gamma[f] * invstd[f];
   const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
-  const float wr = w ? w[(idx / F) % V] : 1.f;
   gy[idx] = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
 }
 
@@ -543,8 +570,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ coef,
-                                                       int relu, float* __restrict__ gy, long M,
-                                                       const float* __restrict__ w, int V) {
+                                                       int relu, float* __restrict__ gy, long M, RowMap m) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
@@ -567,36 +593,42 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   const long r0 = (long)blockIdx.x * APPLY_ROWS_PER_BLOCK;
   long r1 = r0 + APPLY_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
-  unsigned vb = w ? (unsigned)(r0 + rloc) % (unsigned)V : 0u;
+  const bool mapped = m.ids != nullptr;                     // M, r0, r1 count LOGICAL rows (the live ones) then
+  RowPos pb = {0u, 0u};
+  if (mapped && r0 + rloc < r1) pb = row_pos(r0 + rloc, m);
   for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
     float g[4][4], v[4][4], wq[4];
+    long row[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      long r = rb + (long)u * RP;
-      if (r >= r1) r = r1 - 1;
-      wq[u] = w ? w[wrapv(vb + (unsigned)(u * RP), (unsigned)V)] : 1.f;
-      if (wq[u] != 0.f) {                                   // holes: neither loaded nor stored
-        *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
-        *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
+      const long j = rb + (long)u * RP;
+      long r = j < r1 ? j : r1 - 1;
+      wq[u] = 1.f;
+      if (mapped) {
+        const RowPos pu = j < r1 ? row_adv(pb, (unsigned)(u * RP), m) : row_pos(r1 - 1, m);
+        const unsigned vtx = (unsigned)m.ids[pu.i];
+        wq[u] = m.w[vtx];
+        r = (long)pu.b * m.V + vtx;
       }
+      row[u] = r;
+      *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
+      *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
     }
-    if (w) vb = wrapv(vb + 4u * RP, (unsigned)V);
+    if (mapped) pb = row_adv(pb, 4u * RP, m);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const long r = rb + (long)u * RP;
-      if (r >= r1) break;
+      if (rb + (long)u * RP >= r1) break;
       // classes: the constant term enters once per class member (a representative carries the class sum)
       const float wr = wq[u];
-      if (wr == 0.f) continue;
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         float go = g[u][i];
         if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-        o[i] = w ? fmaf(k[i], go, wr * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
-                 : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+        o[i] = mapped ? fmaf(k[i], go, wr * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                      : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
       }
-      *reinterpret_cast<float4*>(gy + r * F + f) = *reinterpret_cast<float4*>(o);
+      *reinterpret_cast<float4*>(gy + row[u] * F + f) = *reinterpret_cast<float4*>(o);
     }
   }
 }
@@ -610,8 +642,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ coef,
                                                              int relu, float* __restrict__ gy, float* __restrict__ pair_gx,
-                                                             float* __restrict__ pair_gy, long Mp,
-                                                             const float* __restrict__ w, int V) {
+                                                             float* __restrict__ pair_gy, long Mp, RowMap m) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
@@ -632,29 +663,41 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
   const long p0 = (long)blockIdx.x * (APPLY_ROWS_PER_BLOCK / 2);
   long p1 = p0 + APPLY_ROWS_PER_BLOCK / 2;
   if (p1 > Mp) p1 = Mp;
-  unsigned vb = w ? (unsigned)(2 * (p0 + rloc)) % (unsigned)V : 0u;
+  // with classes, m maps LOGICAL pairs (Mp of them: the coarse vertices with a live child, m.ids over m.V = V/2) to
+  // actual pairs; m.w is the FINE level's weight table (children 2c, 2c+1): a hole child is neither loaded nor stored
+  const bool mapped = m.ids != nullptr;
+  RowPos pp = {0u, 0u};
+  if (mapped && p0 + rloc < p1) pp = row_pos(p0 + rloc, m);
   for (long pb = p0 + rloc; pb < p1; pb += 2 * RP) {        // 2 pairs = 4 rows per pass: 8 loads in flight per thread
     float g[4][4], v[4][4], wq[4];
+    long pair[2];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      long q = pb + (long)(u >> 1) * RP;
-      if (q >= p1) q = p1 - 1;
+      const long jq = pb + (long)(u >> 1) * RP;
+      long q = jq < p1 ? jq : p1 - 1;
+      wq[u] = 1.f;
+      if (mapped) {
+        const RowPos pu = jq < p1 ? row_adv(pp, (unsigned)((u >> 1) * RP), m) : row_pos(p1 - 1, m);
+        const unsigned c = (unsigned)m.ids[pu.i];
+        wq[u] = m.w[2 * c + (u & 1)];
+        q = (long)pu.b * m.V + c;
+      }
+      pair[u >> 1] = q;
       const long r = 2 * q + (u & 1);
-      wq[u] = w ? w[wrapv(vb + (unsigned)(2 * (u >> 1) * RP + (u & 1)), (unsigned)V)] : 1.f;
 #pragma unroll
       for (int i = 0; i < 4; i++) g[u][i] = v[u][i] = 0.f;
-      if (wq[u] != 0.f) {                                   // holes: neither loaded nor stored
+      if (wq[u] != 0.f) {
         *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
         *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
       }
     }
-    if (w) vb = wrapv(vb + 4u * RP, (unsigned)V);
+    if (mapped) pp = row_adv(pp, 2u * RP, m);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const long q = pb + (long)h * RP;
-      if (q >= p1) break;
+      if (pb + (long)h * RP >= p1) break;
+      const long q = pair[h];
       float o[2][4];
-      const float wr[2] = {wq[2 * h], wq[2 * h + 1]};    // V is even: 2q and 2q+1 are rows of the same sample
+      const float wr[2] = {wq[2 * h], wq[2 * h + 1]};
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const int u = 2 * h + c;
@@ -662,8 +705,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
         for (int i = 0; i < 4; i++) {
           float go = g[u][i];
           if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-          o[c][i] = w ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
-                      : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+          o[c][i] = mapped ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                           : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
           if (wr[c] == 0.f) o[c][i] = 0.f;                // a hole: no data (its g / v registers were zeroed above)
         }
         if (wr[c] != 0.f) *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
@@ -765,6 +808,23 @@ static bool class_table(p2m_graph_t gh, int64_t M, const float** w, int* V) {
   return true;
 }
 
+
+// row map of a streaming pass (RowMap above): with classes the LIVE rows (or, pairs: the coarse vertices with a live
+// child) of the level, else the identity; *Mlog = the logical rows the launch covers
+static bool row_map_of(p2m_graph_t gh, int64_t M, bool pairs, RowMap* m, long* Mlog) {
+  m->w = nullptr; m->ids = nullptr; m->n = 1u; m->V = 1u;
+  *Mlog = pairs ? M / 2 : M;
+  if (gh == nullptr) return true;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.w == nullptr) return true;
+  if (M % g.V != 0 || M >= (1LL << 32) || (pairs && (g.V & 1))) return false;
+  const long B = M / g.V;
+  m->w = g.w;
+  if (pairs) { m->ids = g.live_pairs; m->n = (unsigned)g.n_live_pairs; m->V = (unsigned)(g.V / 2); }
+  else { m->ids = g.live_ids; m->n = (unsigned)g.n_live; m->V = (unsigned)g.V; }
+  *Mlog = B * (long)m->n;
+  return m->n > 0;
+}
 
 // scratch of the two-stage finalize kernels: FIN_SPLITS x 2 x N doubles, one buffer per (device, stream) - the calls of
 // one stream are ordered, so stage 1 of the next call cannot overtake stage 2 of the previous one.  Internal to the
@@ -884,11 +944,11 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
     const int F4 = F / 4;
     if (F4 <= 256 && 256 % F4 == 0) {
       const long rows_per_block = (long)(256 / F4) * ACT_UNROLL;
-      const float* w;
-      int V;
-      P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
-      hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(M, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
-                         Fres, res_shift, x, (long)M, F, w, V);
+      RowMap m;
+      long Mlog;
+      P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
+      hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(Mlog, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
+                         Fres, res_shift, x, Mlog, F, m);
     } else {
       long tot = M * F4;
       hipLaunchKernelGGL(k_bn_act_fwd_v4, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
@@ -906,23 +966,30 @@ extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
   (void)F;
   return cdiv(M, BWD_ROWS_PER_BLOCK);
 }
+// the same when the reduction runs with `classes` (it walks the live rows only)
+extern "C" int32_t p2m_bn_bwd_blocks_classes(p2m_graph_t classes, int64_t M, int32_t F) {
+  RowMap m;
+  long Mlog;
+  if (!row_map_of(classes, M, false, &m, &Mlog)) return 0;
+  return p2m_bn_bwd_blocks(Mlog, F);
+}
 
 extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, int32_t relu, float* part, int64_t M,
                                  int32_t F, p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && M > 0 && F > 0, "null pointer or empty shape");
-  const float* w;
-  int V;
-  P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
+  RowMap m;
+  long Mlog;
+  P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
   hipStream_t s = (hipStream_t)stream;
-  const int grid = p2m_bn_bwd_blocks(M, F);
+  const int grid = p2m_bn_bwd_blocks(Mlog, F);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, w, V); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, (long)M, F, w, V);
+      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, F, m);
   }
   return check_launch("bn_bwd_reduce");
 }
@@ -948,32 +1015,32 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
                                 int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
                                 p2m_graph_t classes, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
-  const float* w;
-  int V;
-  P2M_CHECK_ARG(class_table(classes, M, &w, &V), "M is not a multiple of the level's vertex count (or too large)");
-  P2M_CHECK_ARG(w == nullptr || !(pair_gx || pair_gy) || V % 2 == 0, "pair-sums with classes need an even vertex count");
+  RowMap m;
+  long Mlog;
   hipStream_t s = (hipStream_t)stream;
   if (pair_gx || pair_gy) {
     P2M_CHECK_ARG(M % 2 == 0 && (F == 32 || F == 64 || F == 128 || F == 256),
                   "pair-sum by-products need an even row count and F in {32, 64, 128, 256}");
-    const long Mp = M / 2;
+    long Mp;
+    P2M_CHECK_ARG(row_map_of(classes, M, true, &m, &Mp), "M is not a multiple of the level's (even) vertex count");
     const int gridp = cdiv(Mp, APPLY_ROWS_PER_BLOCK / 2);
     switch (F) {
-      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
-      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
-      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
-      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, w, V); break;
+      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
+      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
+      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
+      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
     }
     return check_launch("bn_bwd_apply(pairs)");
   }
-  const int grid = cdiv(M, APPLY_ROWS_PER_BLOCK);
+  P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
+  const int grid = cdiv(Mlog, APPLY_ROWS_PER_BLOCK);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, w, V); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv((long)M * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, (long)M, F, w, V);
+      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv(Mlog * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, F, m);
   }
   return check_launch("bn_bwd_apply");
 }

@@ -267,6 +267,8 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
   if (g->pair_real_ids) (void)hipFree(g->pair_real_ids);
   if (g->pair_fake_ids) (void)hipFree(g->pair_fake_ids);
   if (g->w) (void)hipFree(g->w);
+  if (g->live_ids) (void)hipFree(g->live_ids);
+  if (g->live_pairs) (void)hipFree(g->live_pairs);
   if (g->rep_of) (void)hipFree(g->rep_of);
   if (g->fake_wts) (void)hipFree(g->fake_wts);
   if (g->fake_tile_w) (void)hipFree(g->fake_tile_w);
@@ -349,6 +351,14 @@ extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
     for (int c = 0; c < V / 2; c++)
       // 2c+1 is then either a hole of 2c's class or (on the coarsest level of the chain) a class of its own
       if (is_fake[2 * c] && is_fake[2 * c + 1] && rep_of[2 * c] == 2 * c) pfake.push_back(c);
+  std::vector<int> live, live_pairs;
+  for (int v = 0; v < V; v++)
+    if (w[v] != 0.f) live.push_back(v);
+  if (!(V & 1))
+    for (int c = 0; c < V / 2; c++)
+      if (w[2 * c] != 0.f || w[2 * c + 1] != 0.f) live_pairs.push_back(c);
+  g->n_live = (int)live.size();
+  g->n_live_pairs = (int)live_pairs.size();
   const int n_rep = (int)reps.size();
   std::vector<float> tile_w(cdiv(n_rep > 0 ? n_rep : 1, 128), 0.f);
   for (int i = 0; i < n_rep; i++) tile_w[i / 128] += wts[i];
@@ -365,6 +375,8 @@ extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
       (rc = upload(wts.data(), sizeof(float) * wts.size(), (void**)&g->fake_wts)) != P2M_OK ||
       (rc = upload(tile_w.data(), sizeof(float) * tile_w.size(), (void**)&g->fake_tile_w)) != P2M_OK ||
       (rc = upload(rep_v.data(), sizeof(int) * V, (void**)&g->rep_of)) != P2M_OK ||
+      (rc = upload(live.data(), sizeof(int) * live.size(), (void**)&g->live_ids)) != P2M_OK ||
+      (rc = upload(live_pairs.data(), sizeof(int) * live_pairs.size(), (void**)&g->live_pairs)) != P2M_OK ||
       (rc = upload(w.data(), sizeof(float) * V, (void**)&g->w)) != P2M_OK)
     return rc;
   (void)hipFree(g->fake_ids);

@@ -75,6 +75,10 @@ struct Graph {
   float* fake_wts = nullptr;
   float* fake_tile_w = nullptr;
   int n_fake_all = 0;             // fake vertices of the level (representatives + holes)
+  int* live_ids = nullptr;        // [n_live]  real vertices and representatives, ascending: what the streaming passes walk
+  int n_live = 0;
+  int* live_pairs = nullptr;      // [n_live_pairs]  coarse vertices c with a live child (2c or 2c+1), ascending
+  int n_live_pairs = 0;
 };
 
 // Row set of a kernel launch: logical row (b, i), i < n  ->  actual row b*V + ids[i]   (ids == nullptr: identity)

@@ -764,17 +764,17 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None,
     the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows)."""
     lib = _lib.hip()
     have_part = part is not None        # the reduction already ran in the epilogue of the contraction that produced gx
+    cls = classes.handle if (classes is not None and classes.classes) else None
     if have_part:
         nblk = part.shape[0]
     else:
-        nblk = int(lib.p2m_bn_bwd_blocks(M, F))
+        nblk = int(lib.p2m_bn_bwd_blocks(M, F) if cls is None else lib.p2m_bn_bwd_blocks_classes(cls, M, F))
         part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
     acc = 1 if dgamma is not None else 0
     if dgamma is None:
         dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
         dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
-    cls = classes.handle if (classes is not None and classes.classes) else None
     if not have_part:
         check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
                                     int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
