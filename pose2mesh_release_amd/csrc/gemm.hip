@@ -400,6 +400,8 @@ __device__ __forceinline__ unsigned hi_pair(float lo_elem, float hi_elem) {   //
   return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 __device__ __forceinline__ float low_part(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+// (Measured and rejected: the two remainders of a pair with one v_pk_add_f32 -- 36 instead of 44 VALU per 8 values, but
+// 120 instead of 129 TFLOP/s on 3x128 -> 128: the packed op costs the issue slots of more than the two it replaces.)
 __device__ __forceinline__ void split3_pack4(float x0, float x1, float x2, float x3, u32x2& ph, u32x2& pm, u32x2& pl) {
   const float r0 = low_part(x0), r1 = low_part(x1), r2 = low_part(x2), r3 = low_part(x3);
   const float s0 = low_part(r0), s1 = low_part(r1), s2 = low_part(r2), s3 = low_part(r3);
