@@ -386,13 +386,22 @@ __global__ __launch_bounds__(256) void k_class_reduce(const float* __restrict__ 
 }
 
 // ---- backward ---------------------------------------------------------------------------------
+// rows per block of the reduction: 512 for the big levels; fewer when that would leave the 256 CUs with a handful of
+// blocks each (F = 256 at V <= 2944: 580-1100 blocks of 512 rows ran at 2.4 TB/s)
 constexpr int BWD_ROWS_PER_BLOCK = 512;
+static inline int bwd_rows_per_block(long M) {
+  if (M >= (long)BWD_ROWS_PER_BLOCK * 4096) return BWD_ROWS_PER_BLOCK;
+  long r = (M + 4095) / 4096;
+  r = (r + 63) / 64 * 64;
+  return (int)(r < 64 ? 64 : r);
+}
 
 template <int LPR>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ gx, const float* __restrict__ y,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int relu, float* __restrict__ part, long M, RowMap m) {
+                                                        int relu, float* __restrict__ part, long M, RowMap m,
+                                                        int rows_per_block) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   __shared__ float red[2][RP][F];
@@ -403,8 +412,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   const float4 mu = *reinterpret_cast<const float4*>(mean + f);
   const float4 is = *reinterpret_cast<const float4*>(invstd + f);
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
-  long r1 = r0 + BWD_ROWS_PER_BLOCK;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   const bool mapped = m.ids != nullptr;                     // M, r0, r1 count LOGICAL rows (the live ones) then
   RowPos pb = {0u, 0u};
@@ -459,9 +468,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce_generic(const float* __re
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
-                                                                float* __restrict__ part, long M, int F, RowMap m) {
-  const long r0 = (long)blockIdx.x * BWD_ROWS_PER_BLOCK;
-  long r1 = r0 + BWD_ROWS_PER_BLOCK;
+                                                                float* __restrict__ part, long M, int F, RowMap m,
+                                                                int rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   for (int f = threadIdx.x; f < F; f += 256) {
     const float sc = scale[f], sh = shift[f], mu = mean[f], is = invstd[f];
@@ -964,7 +974,7 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
 
 extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {
   (void)F;
-  return cdiv(M, BWD_ROWS_PER_BLOCK);
+  return cdiv(M, bwd_rows_per_block(M));
 }
 // the same when the reduction runs with `classes` (it walks the live rows only)
 extern "C" int32_t p2m_bn_bwd_blocks_classes(p2m_graph_t classes, int64_t M, int32_t F) {
@@ -983,13 +993,14 @@ extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* s
   P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
   hipStream_t s = (hipStream_t)stream;
   const int grid = p2m_bn_bwd_blocks(Mlog, F);
+  const int rpb = bwd_rows_per_block(Mlog);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, F, m);
+      hipLaunchKernelGGL(k_bn_bwd_reduce_generic, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, F, m, rpb);
   }
   return check_launch("bn_bwd_reduce");
 }
