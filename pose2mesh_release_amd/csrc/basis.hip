@@ -452,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
 // Optional fused eval-mode BatchNorm + ReLU (the two roundings of the separate pass), optional BatchNorm partials per
 // (sample, tile): (sum y, sum (y - tile mean)^2), weight = the tile's row count (TilePlan::tile_cnt).
 // ---------------------------------------------------------------------------------------------
+#if P2M_TILE_RMAX <= 32          // (probe builds with larger tiles leave the opt-in combine kernel out)
 template <bool STATS>
 __global__ __launch_bounds__(512, 2) void k_combine_tile(TilePlan pl, const int* __restrict__ real_ids,
                                                           const float* __restrict__ Z, const float* __restrict__ bias,
@@ -593,6 +594,8 @@ __global__ __launch_bounds__(512, 2) void k_combine_tile(TilePlan pl, const int*
   }
 }
 
+#endif
+
 // the fake rows of the same conv: isolated, so y = Z0[p] + a Z1[p] + b Z2[p] (+ bias), p = the parent row
 __global__ __launch_bounds__(256) void k_combine_fake(const int* __restrict__ ids, int n, const float* __restrict__ Z,
                                                        const float* __restrict__ bias, float fa, float fb,
@@ -658,6 +661,10 @@ extern "C" int p2m_cheb_project_combine(p2m_graph_t gh, const float* Z, const fl
   const TilePlan& pl = g.plan[1];
   P2M_CHECK_ARG(pl.ntiles > 0 && !(g.V & 1), "this level has no in_shift = 1 tile plan (p2m_graph_plan_info)");
   if (B <= 0) return P2M_OK;
+#if P2M_TILE_RMAX > 32
+  set_error("p2m_cheb_project_combine: not built (tiles of more than 32 rows)");
+  return P2M_ERR_INVALID;
+#else
   hipStream_t s = (hipStream_t)stream;
   const int spb = 8;
   const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (N / 64), 8) * 8);
@@ -668,6 +675,7 @@ extern "C" int p2m_cheb_project_combine(p2m_graph_t gh, const float* Z, const fl
     hipLaunchKernelGGL(k_combine_tile<false>, grid, dim3(512), 0, s, pl, g.real_ids, Z, bias, act_scale, act_shift,
                        act_relu, Y, stats, B, N, g.V, spb);
   return check_launch("cheb_project_combine");
+#endif
 }
 
 extern "C" int p2m_cheb_project_combine_fake(p2m_graph_t gh, const float* Z, const float* bias, float* Y, int32_t B,
