@@ -346,8 +346,11 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
 namespace p2m {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef P2M_TILE_MINBLK
+#define P2M_TILE_MINBLK 2      // resident blocks per CU the register budget is sized for (probe builds: 3 with small tiles)
+#endif
 template <int LPR>
-__global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
+__global__ __launch_bounds__(512, P2M_TILE_MINBLK) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
                                                         float* __restrict__ T1, float* __restrict__ T2, int B, int F,
                                                         long x_rows, int nset, int spb) {
   constexpr int NT = 512;
