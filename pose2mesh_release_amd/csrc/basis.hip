@@ -26,6 +26,16 @@ namespace p2m {
 constexpr int ROWS_PER_BLOCK = P2M_BASIS_ROWS;
 
 // P2M_BASIS_TILED=0 falls back to the row-per-wave gather kernel for the real rows of split levels
+// samples a tile block walks (amortises the tile tables; P2M_BASIS_SPB for probe runs, read once)
+static int basis_spb() {
+  static const int v = [] {
+    const char* e = getenv("P2M_BASIS_SPB");
+    const int n = e ? atoi(e) : 8;
+    return n >= 1 && n <= 256 ? n : 8;
+  }();
+  return v;
+}
+
 static bool basis_tiled() {
   static int v = [] { const char* e = getenv("P2M_BASIS_TILED"); return e ? atoi(e) : 1; }();
   return v != 0;
@@ -632,7 +642,7 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
   if (nset == 0) return P2M_OK;
   if (real_only && basis_tiled() && g.plan[in_shift].ntiles > 0 && (F == 32 || F == 64 || F % 128 == 0)) {
     const TilePlan& pl = g.plan[in_shift];
-    const int spb = 8;                                        // samples per block (amortises the tile tables)
+    const int spb = basis_spb();
     const long x_rows = g.V >> in_shift;
     const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (F >= 128 ? F / 128 : 1), 8) * 8);
     if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
@@ -702,7 +712,7 @@ extern "C" int p2m_cheb_basis_pair(p2m_graph_t gh, const float* G, float* P1c, f
   P2M_CHECK_ARG(F == 32 || F == 64 || F % 128 == 0, "feature width must be 32, 64 or a multiple of 128");
   if (B <= 0) return P2M_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int spb = 8;
+  const int spb = basis_spb();
   const long x_rows = g.V;
   const int nset = g.n_pair_real;
   const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (F >= 128 ? F / 128 : 1), 8) * 8);

@@ -550,7 +550,7 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 
 # blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,
 # 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce)
-TN_TARGET_BLOCKS = 768
+TN_TARGET_BLOCKS = int(_os.environ.get("P2M_TN_TARGET_BLOCKS", "768"))
 
 
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
