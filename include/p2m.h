@@ -46,7 +46,7 @@ typedef struct p2m_graph* p2m_graph_t;
 
 /* Thread-local description of the last error returned on this thread. */
 const char* p2m_last_error_string(void);
-/* Library version / build info (e.g. "p2m-hip 0.2 (gfx950; ...)"). */
+/* Library version / build info (e.g. "p2m-hip 0.3 (gfx950; ...)"). */
 const char* p2m_version(void);
 
 /* ---- graph handle: one per coarsening level ------------------------------------------------

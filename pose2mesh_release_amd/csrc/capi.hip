@@ -118,7 +118,7 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
 using namespace p2m;
 
 extern "C" const char* p2m_last_error_string(void) { return g_err; }
-extern "C" const char* p2m_version(void) { return "p2m-hip 0.2 (gfx950; fp32 contractions on the BF16 MFMA pipe as 3 exact slices, or on the f32 MFMA)"; }
+extern "C" const char* p2m_version(void) { return "p2m-hip 0.3 (gfx950; fp32 contractions on the BF16 MFMA pipe as 3 exact slices, or on the f32 MFMA; paired operator, fake-row classes)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).
 extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val, int32_t V, int32_t nnz,
