@@ -219,7 +219,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_combine_small(Graph g, const float* __restrict__ P, int ldp,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int B,
                                                         const int* __restrict__ ids, int nset,
-                                                        const int* __restrict__ out_index, int out_rows, float scale) {
+                                                        const int* __restrict__ out_index, int out_rows, float scale,
+                                                        int skip_real) {
   // ids != nullptr: only the listed (real) vertices are computed; out_index != nullptr: vertex v is stored at row
   // out_index[v] of a [B, out_rows, NC] tensor (mesh-model vertex order), scaled -- the Tester's / demo's
   // pred_mesh[:, graph_perm_reverse[:nv], :] * scale (lib/core/base.py:201-202) folded into the last conv's store
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(256) void k_combine_small(Graph g, const float* __r
   const int b = (int)(idx / n);
   const int i = (int)(idx - (long)b * n);
   const int row = ids ? ids[i] : i;
+  // skip_real: the rows with neighbours were done by k_combine_small_tile; this launch covers the single-entry rows
+  if (skip_real && g.rowptr[row + 1] - g.rowptr[row] > 1) return;
   const long base = (long)b * g.V * ldp;             // sample offset in P
   // classes (Graph::rep_of): a hole is never computed upstream; its output is its representative's, recomputed here
   const int src = g.rep_of ? g.rep_of[row] : row;
@@ -257,10 +260,11 @@ __global__ __launch_bounds__(256) void k_combine_small(Graph g, const float* __r
 // E[r] = [ G[r] | (L G)[r] | (L2 G)[r] | 0 ... ]   (row width lde >= 3*NC): the basis of a narrow gradient
 template <int NC>
 __global__ __launch_bounds__(256) void k_expand_small(Graph g, const float* __restrict__ G, float* __restrict__ E,
-                                                       int lde, int B) {
+                                                       int lde, int B, int skip_real) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * g.V) return;
   const int row = (int)(idx % g.V);
+  if (skip_real && g.rowptr[row + 1] - g.rowptr[row] > 1) return;     // done by k_expand_small_tile
   const long base = (idx - row) * NC;
   float t1[NC], t2[NC];
 #pragma unroll
@@ -284,6 +288,114 @@ __global__ __launch_bounds__(256) void k_expand_small(Graph g, const float* __re
   for (int c = 3 * NC; c < lde; c++) e[c] = 0.f;
 }
 
+// LDS-staged forms of the two kernels above for the rows that HAVE neighbours, on levels with a tile plan (TilePlan,
+// p2m_common.h): one block = one tile (<= 32 real rows) x 8 samples.  The 2 NC (combine) / NC (expand) floats each union
+// row contributes are staged once per (tile, sample) instead of being fetched once per referencing row (~21x through
+// L1/L2, a 128-byte line each): 537 -> ~170 us per launch at the finest level.  Entry order and fmaf chains are
+// those of the row kernels: bitwise the same results.
+#if P2M_TILE_RMAX == 32
+constexpr int SMALL_SPB = 8;
+template <int NC>
+__global__ __launch_bounds__(256) void k_combine_small_tile(TilePlan pl, const int* __restrict__ real_ids, int V,
+                                                             const float* __restrict__ P, int ldp,
+                                                             const float* __restrict__ bias, float* __restrict__ Y, int B,
+                                                             const int* __restrict__ out_index, int out_rows,
+                                                             float scale) {
+  __shared__ float4 ents[TILE_ECAP];
+  __shared__ int rowoff[TILE_RMAX + 1];
+  __shared__ float xs[SMALL_SPB][TILE_UCAP][2 * NC];
+  const int tile = blockIdx.x % pl.ntiles, sg = blockIdx.x / pl.ntiles;
+  const int t = threadIdx.x;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  const int e0 = pl.erow[r0], nE = pl.erow[r0 + R] - e0;
+  for (int i = t; i < nE; i += 256) ents[i] = pl.ent[e0 + i];
+  if (t <= R) rowoff[t] = pl.erow[r0 + t] - e0;
+  const int b0 = sg * SMALL_SPB;
+  for (int q = t; q < U * SMALL_SPB; q += 256) {
+    const int u = q % U, sl = q / U, b = b0 + sl;
+    if (b < B) {
+      const float* src = P + ((long)b * V + pl.ucol[u0 + u]) * ldp + NC;
+#pragma unroll
+      for (int c = 0; c < 2 * NC; c++) xs[sl][u][c] = src[c];
+    }
+  }
+  __syncthreads();
+  const int i = t % TILE_RMAX, sl = t / TILE_RMAX, b = b0 + sl;
+  if (i >= R || b >= B) return;
+  const int row = real_ids[r0 + i];
+  const float* p0 = P + ((long)b * V + row) * ldp;
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) acc[c] = p0[c] + (bias ? bias[c] : 0.f);
+  for (int j = rowoff[i]; j < rowoff[i + 1]; j++) {
+    const float4 en = ents[j];
+    const float* q = xs[sl][__float_as_int(en.z)];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = fmaf(en.y, q[NC + c], fmaf(en.x, q[c], acc[c]));
+  }
+  long orow = row;
+  int rows_out = V;
+  if (out_index) {
+    orow = out_index[row];
+    rows_out = out_rows;
+    if (orow < 0) return;
+  }
+  float* y = Y + ((long)b * rows_out + orow) * NC;
+#pragma unroll
+  for (int c = 0; c < NC; c++) y[c] = out_index ? acc[c] * scale : acc[c];
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_expand_small_tile(TilePlan pl, const int* __restrict__ real_ids, int V,
+                                                            const float* __restrict__ G, float* __restrict__ E, int lde,
+                                                            int B) {
+  __shared__ float4 ents[TILE_ECAP];
+  __shared__ int rowoff[TILE_RMAX + 1];
+  __shared__ float xs[SMALL_SPB][TILE_UCAP][NC];
+  const int tile = blockIdx.x % pl.ntiles, sg = blockIdx.x / pl.ntiles;
+  const int t = threadIdx.x;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  const int e0 = pl.erow[r0], nE = pl.erow[r0 + R] - e0;
+  for (int i = t; i < nE; i += 256) ents[i] = pl.ent[e0 + i];
+  if (t <= R) rowoff[t] = pl.erow[r0 + t] - e0;
+  const int b0 = sg * SMALL_SPB;
+  for (int q = t; q < U * SMALL_SPB; q += 256) {
+    const int u = q % U, sl = q / U, b = b0 + sl;
+    if (b < B) {
+      const float* src = G + ((long)b * V + pl.ucol[u0 + u]) * NC;
+#pragma unroll
+      for (int c = 0; c < NC; c++) xs[sl][u][c] = src[c];
+    }
+  }
+  __syncthreads();
+  const int i = t % TILE_RMAX, sl = t / TILE_RMAX, b = b0 + sl;
+  if (i >= R || b >= B) return;
+  const long ridx = (long)b * V + real_ids[r0 + i];
+  float t1[NC], t2[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) t1[c] = t2[c] = 0.f;
+  for (int j = rowoff[i]; j < rowoff[i + 1]; j++) {
+    const float4 en = ents[j];
+    const float* q = xs[sl][__float_as_int(en.z)];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      t1[c] = fmaf(en.x, q[c], t1[c]);
+      t2[c] = fmaf(en.y, q[c], t2[c]);
+    }
+  }
+  float* e = E + ridx * lde;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    e[c] = G[ridx * NC + c];
+    e[NC + c] = t1[c];
+    e[2 * NC + c] = t2[c];
+  }
+  for (int c = 3 * NC; c < lde; c++) e[c] = 0.f;
+}
+#endif
+
 }  // namespace p2m
 
 using namespace p2m;
@@ -297,8 +409,19 @@ static int combine_small_launch(p2m_graph_t gh, const float* P, int32_t ldp, int
   const long tot = (long)B * nset;
   if (tot == 0) return P2M_OK;
   hipStream_t s = (hipStream_t)stream;
+  int skip_real = 0;
+#if P2M_TILE_RMAX == 32
+  // rows with neighbours through the tile plan (when the level has one); the row kernel then covers the rest
+  const TilePlan& pl = g.plan[0];
+  if (pl.ntiles > 0 && basis_tiled() && nc == 3) {
+    hipLaunchKernelGGL(k_combine_small_tile<3>, dim3(pl.ntiles * cdiv(B, SMALL_SPB)), dim3(256), 0, s, pl, g.real_ids, g.V,
+                       P, ldp, bias, Y, B, out_index, out_rows, scale);
+    if (real_only) return check_launch("cheb_combine_small(tiled)");
+    skip_real = 1;
+  }
+#endif
 #define P2M_COMBINE(NCv) hipLaunchKernelGGL(k_combine_small<NCv>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, \
-                                            Y, B, ids, nset, out_index, out_rows, scale)
+                                            Y, B, ids, nset, out_index, out_rows, scale, skip_real)
   switch (nc) {
     case 1: P2M_COMBINE(1); break;
     case 2: P2M_COMBINE(2); break;
@@ -333,11 +456,20 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
   const long tot = (long)B * g.V;
   hipStream_t s = (hipStream_t)stream;
+  int skip_real = 0;
+#if P2M_TILE_RMAX == 32
+  const TilePlan& pl = g.plan[0];
+  if (pl.ntiles > 0 && basis_tiled() && nc == 3) {
+    hipLaunchKernelGGL(k_expand_small_tile<3>, dim3(pl.ntiles * cdiv(B, SMALL_SPB)), dim3(256), 0, s, pl, g.real_ids, g.V,
+                       G, E, lde, B);
+    skip_real = 1;
+  }
+#endif
   switch (nc) {
-    case 1: hipLaunchKernelGGL(k_expand_small<1>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B); break;
-    case 2: hipLaunchKernelGGL(k_expand_small<2>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B); break;
-    case 3: hipLaunchKernelGGL(k_expand_small<3>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B); break;
-    case 4: hipLaunchKernelGGL(k_expand_small<4>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B); break;
+    case 1: hipLaunchKernelGGL(k_expand_small<1>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
+    case 2: hipLaunchKernelGGL(k_expand_small<2>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
+    case 3: hipLaunchKernelGGL(k_expand_small<3>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
+    case 4: hipLaunchKernelGGL(k_expand_small<4>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
     default: set_error("p2m_cheb_expand_small: nc must be 1..4 (got %d)", nc); return P2M_ERR_INVALID;
   }
   return check_launch("cheb_expand_small");

@@ -428,6 +428,39 @@ def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, V, Fin, Fo
     assert (db - db_ref).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("V,B,graph", [(1472, 11, "band"), (736, 3, "band"), (184, 5, "rand")])
+def test_narrow_conv_combine_and_expand(ops, V, B, graph):
+    """The final conv's sparse halves (project-then-combine by linearity): Y = P0 + L P1 + L2 P2 + bias and its
+    transpose-side E = [G | L G | L2 G | 0], tile-plan kernels + row kernel on split levels, row kernel alone below,
+    against float64 sparse algebra; the real-only form with an output order (inference) against the same."""
+    L = _band_graph(V, 5 + V) if graph == "band" else _rand_graph(V, V + 2)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert (g.plan_tiles[0] > 0) == (graph == "band")
+    Ld = torch.as_tensor(L.toarray(), dtype=torch.float64)
+    L2d = 2 * Ld @ Ld - torch.eye(V, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(V)
+    P = torch.randn(B, V, 32, generator=gen)
+    bias = torch.randn(3, generator=gen)
+    Pd = P.double()
+    ref = Pd[..., 0:3] + Ld @ Pd[..., 3:6] + L2d @ Pd[..., 6:9] + bias.double()
+    Y = ops.cheb_combine_small(g, P.cuda().view(B * V, 32), 3, bias.cuda(), B)
+    assert (Y.view(B, V, 3).cpu().double() - ref).abs().max() < 2e-5
+    G = torch.randn(B, V, 3, generator=gen)
+    E = ops.cheb_expand_small(g, G.cuda().view(B * V, 3), 3, 32, B).view(B, V, 32).cpu().double()
+    Gd = G.double()
+    assert (E[..., 0:3] - Gd).abs().max() == 0 and (E[..., 9:] != 0).sum() == 0
+    assert (E[..., 3:6] - Ld @ Gd).abs().max() < 1e-5 and (E[..., 6:9] - L2d @ Gd).abs().max() < 1e-5
+    if g.split:
+        real = _real_ids(L)
+        nv = real.size - 7
+        order = np.random.default_rng(3).permutation(real)[:nv]            # vertex stored at output row k
+        inv = np.full(V, -1, dtype=np.int32)
+        inv[order] = np.arange(nv, dtype=np.int32)
+        Yo = ops.cheb_combine_small_real(g, P.cuda().view(B * V, 32), 3, bias.cuda(), B,
+                                         torch.from_numpy(inv).cuda(), nv, 1000.0)
+        assert (Yo.cpu().double() - 1000.0 * ref[:, order]).abs().max() < 2e-2
+
+
 def test_classes_of_identical_fake_rows(ops):
     """include/p2m.h "classes": with runs of identical fake rows declared, the kernels that see them give what the full
     computation gives -- weighted statistics, class-sum gradients, holes neither read (they are NaN here) nor needed."""
