@@ -328,7 +328,10 @@ extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
   P2M_CHECK_ARG(g->w == nullptr, "classes already set on this handle");
   const int V = g->V;
   std::vector<int> fake(g->n_fake);
-  if (g->n_fake) (void)hipMemcpy(fake.data(), g->fake_ids, sizeof(int) * g->n_fake, hipMemcpyDeviceToHost);
+  if (g->n_fake) {
+    const hipError_t e = hipMemcpy(fake.data(), g->fake_ids, sizeof(int) * g->n_fake, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); return P2M_ERR_HIP; }
+  }
   std::vector<char> is_fake(V, 0);
   for (int v : fake) is_fake[v] = 1;
   std::vector<float> w(V, 1.f);
@@ -377,8 +380,12 @@ extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
       (rc = upload(rep_v.data(), sizeof(int) * V, (void**)&g->rep_of)) != P2M_OK ||
       (rc = upload(live.data(), sizeof(int) * live.size(), (void**)&g->live_ids)) != P2M_OK ||
       (rc = upload(live_pairs.data(), sizeof(int) * live_pairs.size(), (void**)&g->live_pairs)) != P2M_OK ||
-      (rc = upload(w.data(), sizeof(float) * V, (void**)&g->w)) != P2M_OK)
+      (rc = upload(w.data(), sizeof(float) * V, (void**)&g->w)) != P2M_OK) {
+    if (d_reps) (void)hipFree(d_reps);      // the handle's own fields are released by p2m_graph_destroy
+    if (d_pf) (void)hipFree(d_pf);
+    if (g->w) { (void)hipFree(g->w); g->w = nullptr; }   // "no classes": the handle stays usable as it was
     return rc;
+  }
   (void)hipFree(g->fake_ids);
   g->fake_ids = d_reps;
   g->n_fake = n_rep;
