@@ -1,9 +1,12 @@
-"""How long does the host take to enqueue one train step (no sync)?  If < GPU step time the run is GPU-bound."""
+"""How long does the host take to enqueue one train step (no sync)?  If < GPU step time the run is GPU-bound.
+   python tools/probes/cpu_overhead.py [joint_set] [batch]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R]
 import torch, bench
-step = bench.TrainStep(torch.device("cuda", 0), 256, "coco", 1)
+JS = sys.argv[1] if len(sys.argv) > 1 else "coco"
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+step = bench.TrainStep(torch.device("cuda", 0), BATCH, JS, 1)
 for _ in range(3): step()
 torch.cuda.synchronize()
 ts = []
