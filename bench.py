@@ -91,6 +91,13 @@ class TrainStep:
         self.dense_gflop_fwd = _dense_gflop_fwd(self.model.pose2mesh)
         self.dense_gflop_fwd_bwd = 3.0 * self.dense_gflop_fwd
 
+    def loss_fn(self):
+        """Forward + the five reference losses (fused form) -> the total loss: what train.GraphedTrainStep captures
+        between zero_grad and the optimizer step."""
+        pred_mesh, lift_pose = self.model(self.pose2d)
+        mesh_total, _ = self.mesh_loss(pred_mesh, self.gt_mesh, self.gt_reg, self.one, self.one)
+        return mesh_total + 1e-3 * self.losses[4](lift_pose, self.gt_lift, self.one)
+
     def __call__(self):
         m = self.model
         self.opt.zero_grad()
@@ -276,6 +283,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=45.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--stock-losses", action="store_true", help="use the stock-torch loss modules instead of p2m_mesh_loss")
+    ap.add_argument("--train-graph", action="store_true",
+                    help="train mode, 1 GPU: the whole step as one captured hipGraph (train.GraphedTrainStep)")
     ap.add_argument("--infer-path", default="graph", choices=["graph", "eager", "general"],
                     help="--mode infer: captured hipGraph of the real-only path (default), the same launch by launch, "
                          "or the general drop-in module + epilogue kernel")
@@ -308,6 +317,13 @@ def main():
         torch.cuda.synchronize()
 
     graphed = infer and args.infer_path == "graph"
+    eager_step = step
+    train_graph = args.train_graph and not infer and world == 1 and not args.stock_losses
+    if train_graph:
+        from pose2mesh_release_amd import train as p2m_train
+        step = p2m_train.GraphedTrainStep(eager_step.model, eager_step.opt, eager_step.loss_fn, warmup=2)
+        args.warmup = max(args.warmup, 4)              # 2 eager steps, the capture, one replay before the clock starts
+        graphed = True
     for _ in range(args.warmup):
         step()
     if not args.no_kernel_timing and not graphed:
@@ -322,15 +338,21 @@ def main():
         # HIP events cannot bracket the nodes of a replayed graph: the per-kernel roofline of the graphed path is taken
         # from the SAME launches issued one by one right after the timed region (stated in the JSON)
         ops.TIMER = ops.KernelTimer()
-        with torch.no_grad():
+        if train_graph:
             for _ in range(args.steps):
-                step.step._eager()
+                eager_step()
+        else:
+            with torch.no_grad():
+                for _ in range(args.steps):
+                    step.step._eager()
         torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     timer, ops.TIMER = ops.TIMER, None
+    if train_graph:
+        step = eager_step                    # the attributes the report reads live on the TrainStep
 
     if rank == 0:
         total = args.batch * world * args.steps
@@ -361,7 +383,9 @@ def main():
                        "gemm_arith": ("fp32 contraction as 3 exact bf16 slices x 6 products on the BF16 MFMA pipe, "
                                       "fp32 accumulate (error vs float64 <= native f32 MFMA)"
                                       if ops.GEMM_ARITH == "bf16x3" else "native f32 MFMA"),
-                       "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if (world > 1 and not infer) else 0},
+                       "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if (world > 1 and not infer) else 0,
+                       **({"train_step": "one captured hipGraph (train.GraphedTrainStep); kernel timings from the same "
+                                         "launches issued one by one after the timed region"} if train_graph else {})},
         }
         # "MFMA util = meshes/s * FLOPs / 157.3e12" over the WHOLE step (all kernels, not only GEMM time)
         gf = step.dense_gflop_fwd if infer else step.dense_gflop_fwd_bwd

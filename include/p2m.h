@@ -380,6 +380,13 @@ int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   v = alpha v + (1-alpha) g^2;  p -= lr g / (sqrt(v) + eps),  g = grad * grad_scale.                              */
 int p2m_rmsprop_step(float* param, const float* grad, float* square_avg, int64_t n, float lr, float alpha,
                      float eps, float grad_scale, void* stream);
+/* The same two steps with the step-dependent scalars in DEVICE memory, hp = {lr, 1 - beta1^t, sqrt(1 - beta2^t),
+ * grad_scale} (RMSprop reads hp[0] and hp[3]): the launches are then identical from step to step and can be part of a
+ * captured hipGraph (train.GraphedTrainStep); the host refreshes hp before each replay.                            */
+int p2m_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hp,
+                      float beta1, float beta2, float eps, void* stream);
+int p2m_rmsprop_step_dev(float* param, const float* grad, float* square_avg, int64_t n, const float* hp, float alpha,
+                         float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,14 @@ namespace p2m {
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, long n4, long n, float lr, float b1, float b2,
-                                               float eps, float bc1, float bc2_sqrt, float grad_scale) {
+                                               float eps, float bc1, float bc2_sqrt, float grad_scale,
+                                               const float* __restrict__ hp) {
+  if (hp != nullptr) {          // step-dependent scalars from device memory: the launch can sit in a captured hipGraph
+    lr = hp[0];
+    bc1 = hp[1];
+    bc2_sqrt = hp[2];
+    grad_scale = hp[3];
+  }
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
     float4 P = reinterpret_cast<float4*>(p)[i];
@@ -45,7 +52,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 //   v = alpha v + (1 - alpha) g^2 ;  p -= lr * g / (sqrt(v) + eps)
 __global__ __launch_bounds__(256) void k_rmsprop(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ v, long n4, long n, float lr, float alpha,
-                                                  float eps, float grad_scale) {
+                                                  float eps, float grad_scale, const float* __restrict__ hp) {
+  if (hp != nullptr) {
+    lr = hp[0];
+    grad_scale = hp[3];
+  }
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
     float4 P = reinterpret_cast<float4*>(p)[i];
@@ -81,8 +92,32 @@ extern "C" int p2m_rmsprop_step(float* param, const float* grad, float* square_a
   P2M_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)square_avg) % 16 == 0, "buffers must be 16-byte aligned");
   const long n4 = n / 4;
   hipLaunchKernelGGL(k_rmsprop, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, square_avg,
-                     n4, (long)n, lr, alpha, eps, grad_scale);
+                     n4, (long)n, lr, alpha, eps, grad_scale, (const float*)nullptr);
   return check_launch("rmsprop_step");
+}
+
+// The same steps with the step-dependent scalars read from DEVICE memory, hp = {lr, 1 - beta1^t, sqrt(1 - beta2^t),
+// grad_scale} (RMSprop uses hp[0] and hp[3]): the launch itself is then the same every step and can be part of a
+// captured hipGraph; the host refreshes the four floats before each replay.
+extern "C" int p2m_rmsprop_step_dev(float* param, const float* grad, float* square_avg, int64_t n, const float* hp,
+                                    float alpha, float eps, void* stream) {
+  P2M_CHECK_ARG(param && grad && square_avg && hp && n > 0, "null pointer or empty buffer");
+  P2M_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)square_avg) % 16 == 0, "buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_rmsprop, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, square_avg,
+                     n4, (long)n, 0.f, alpha, eps, 1.f, hp);
+  return check_launch("rmsprop_step_dev");
+}
+
+extern "C" int p2m_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* hp, float beta1, float beta2, float eps, void* stream) {
+  P2M_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hp && n > 0, "null pointer or empty buffer");
+  P2M_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+                "buffers must be 16-byte aligned");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_adam, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n4, (long)n, 0.f, beta1, beta2, eps, 1.f, 1.f, 1.f, hp);
+  return check_launch("adam_step_dev");
 }
 
 extern "C" int p2m_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
@@ -95,6 +130,7 @@ extern "C" int p2m_adam_step(float* param, const float* grad, float* exp_avg, fl
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const long n4 = n / 4;
   hipLaunchKernelGGL(k_adam, dim3(cdiv(n4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n4, (long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     exp_avg_sq, n4, (long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale,
+                     (const float*)nullptr);
   return check_launch("adam_step");
 }

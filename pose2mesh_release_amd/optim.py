@@ -51,6 +51,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.step_count = 0
+        self._hp_host = self._hp_dev = None
 
     @property
     def lr(self):
@@ -83,6 +84,35 @@ class _FlatOptimizer(torch.optim.Optimizer):
             self._launch(float(grad_scale))
         ops.bump_weight_epoch()       # the parameters changed behind torch's back: derived weight operands are stale
         return loss
+
+    # ---- capturable form (train.GraphedTrainStep): the step-dependent scalars live in device memory --------------------
+    def _hp_values(self, grad_scale):
+        """{lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale} for the step that is about to run."""
+        return [float(self.param_groups[0]["lr"]), 1.0, 1.0, float(grad_scale)]
+
+    def prepare_step(self, grad_scale=1.0):
+        """Host half of a captured step: counts the step and refreshes the four device-resident scalars (one small async
+        copy from pinned memory on the current stream).  Call it right before replaying the graph that holds
+        step_captured()."""
+        self.step_count += 1
+        if self._hp_dev is None:
+            self._hp_host = torch.empty(4, dtype=torch.float32).pin_memory()
+            self._hp_dev = torch.empty(4, dtype=torch.float32, device=self.flat_param.device)
+        self._hp_host.copy_(torch.tensor(self._hp_values(grad_scale), dtype=torch.float32))
+        self._hp_dev.copy_(self._hp_host, non_blocking=True)
+
+    def _launch_captured(self):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def step_captured(self):
+        """Device half of a captured step: the update launch, reading lr / bias corrections / grad_scale from device
+        memory (prepare_step) -- identical from step to step, hence capturable."""
+        if self._hp_dev is None:
+            raise RuntimeError("prepare_step() must run once before the capture")
+        with torch.cuda.device(self.flat_param.device):
+            self._launch_captured()
+        ops.bump_weight_epoch()
 
     # torch-shaped state dict so reference checkpoints (main/train.py:51-58) round-trip
     def state_dict(self):
@@ -126,6 +156,21 @@ class FlatAdam(_FlatOptimizer):
     def exp_avg_sq(self):
         return self._bufs["exp_avg_sq"]
 
+    def _hp_values(self, grad_scale):
+        # exactly what p2m_adam_step derives on the host: the betas as C floats, pow / sqrt in double, one rounding to float
+        import ctypes
+        import math
+        g, t = self.param_groups[0], self.step_count
+        b1, b2 = ctypes.c_float(g["betas"][0]).value, ctypes.c_float(g["betas"][1]).value
+        return [float(g["lr"]), 1.0 - math.pow(b1, t), math.sqrt(1.0 - math.pow(b2, t)), float(grad_scale)]
+
+    def _launch_captured(self):
+        g = self.param_groups[0]
+        check(_lib.hip().p2m_adam_step_dev(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
+                                           _vp(self.exp_avg.data_ptr()), _vp(self.exp_avg_sq.data_ptr()), self.numel,
+                                           _vp(self._hp_dev.data_ptr()), g["betas"][0], g["betas"][1], g["eps"],
+                                           _vp(torch.cuda.current_stream().cuda_stream)), "p2m_adam_step_dev")
+
     def _launch(self, grad_scale):
         g = self.param_groups[0]
         check(_lib.hip().p2m_adam_step(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
@@ -144,6 +189,13 @@ class FlatRMSprop(_FlatOptimizer):
     @property
     def square_avg(self):
         return self._bufs["square_avg"]
+
+    def _launch_captured(self):
+        g = self.param_groups[0]
+        check(_lib.hip().p2m_rmsprop_step_dev(_vp(self.flat_param.data_ptr()), _vp(self.flat_grad.data_ptr()),
+                                              _vp(self.square_avg.data_ptr()), self.numel, _vp(self._hp_dev.data_ptr()),
+                                              g["alpha"], g["eps"], _vp(torch.cuda.current_stream().cuda_stream)),
+              "p2m_rmsprop_step_dev")
 
     def _launch(self, grad_scale):
         g = self.param_groups[0]

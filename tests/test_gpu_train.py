@@ -168,3 +168,101 @@ def test_prefetched_operands_leave_nothing_to_build_and_change_nothing(hip_libs,
         outs.append([y.detach()] + [p.grad for p in net.parameters()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "rmsprop"])
+def test_graphed_train_step_is_bitwise_the_eager_loop(hip_libs, opt_name):
+    """train.GraphedTrainStep: 3 eager warm-up steps, capture, 3 replays (with an lr change in between, as MultiStepLR
+    makes) == 6 eager steps, bit for bit.  MeshNet alone (every kernel of the step is this package's, all
+    deterministic; with PoseNet in the step hipBLASLt may pick another algorithm under capture, which moves the last
+    bit of its output)."""
+    import helpers
+    from pose2mesh_release_amd import meshnet, optim, train
+    gL, _, _ = helpers.golden_graphs("mano")
+    B, J = 6, int(gL[-1].shape[0])
+    x = helpers.meshnet_input(B, J, seed=4).cuda()
+    w = torch.randn(B, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(1)).cuda()
+    results = []
+    for graphed in (False, True):
+        net = meshnet.get_model(5, 3, gL, mano=True)
+        net.load_state_dict(helpers.numpy_state(net.state_dict(), 3))
+        net = net.cuda().train()
+        opt = (optim.FlatAdam if opt_name == "adam" else optim.FlatRMSprop)(net.parameters(), lr=1e-3)
+        net.accumulate_grads_in_place(True)
+
+        def loss_fn():
+            return (net(x) * w).sum() * 1e-3
+
+        losses = []
+        if graphed:
+            step = train.GraphedTrainStep(net, opt, loss_fn, warmup=3)
+            for i in range(6):
+                if i == 4:
+                    opt.param_groups[0]["lr"] = 1e-4
+                losses.append(float(step()))
+            assert step.graph is not None
+        else:
+            for i in range(6):
+                if i == 4:
+                    opt.param_groups[0]["lr"] = 1e-4
+                opt.zero_grad()
+                loss = loss_fn()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        results.append((losses, opt.flat_param.clone(), [b.clone() for b in opt._bufs.values()],
+                        {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "tracked" in k}))
+    (la, pa, ba, sa), (lb, pb, bb, sb) = results
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)
+    for u, v in zip(ba, bb):
+        assert torch.equal(u, v)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_graphed_flat_model_step_tracks_the_eager_loop(hip_libs):
+    """The full FlatPose2Mesh step (PoseNet on hipBLASLt + MeshNet + fused losses) captured: the loss curve follows the
+    eager one (not bitwise: see above)."""
+    from pose2mesh_release_amd import loss as p2m_loss, optim, pose2mesh_net, synth, train
+    faces, gL, perm_rev, J = synth.make_graphs("mano")
+    nv = int(faces.max()) + 1
+    B = 6
+    gen = torch.Generator().manual_seed(3)
+    pose2d = synth.pose2d_batch(B, J, 11).cuda()
+    gt_mesh = (torch.randn(B, nv, 3, generator=gen) * 0.3).cuda()
+    gt_pose = (torch.randn(B, J, 3, generator=gen) * 300).cuda()
+    one = torch.ones(B, 1, 1).cuda()
+    curves = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        model = pose2mesh_net.get_model(J, gL).cuda().train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = optim.FlatRMSprop(model.parameters(), lr=1e-4)
+        model.pose2mesh.accumulate_grads_in_place(True)
+        mesh_loss = p2m_loss.FusedMeshLoss(faces, perm_rev, synth.synthetic_regressor(J, nv))
+        lift_loss = p2m_loss.get_loss(faces)[4]
+
+        def loss_fn():
+            mesh, lift = model(pose2d)
+            total, _ = mesh_loss(mesh, gt_mesh, gt_pose, one, one)
+            return total + 1e-3 * lift_loss(lift, gt_pose, one)
+
+        if graphed:
+            step = train.GraphedTrainStep(model, opt, loss_fn, warmup=2)
+            curves.append([float(step()) for _ in range(6)])
+        else:
+            c = []
+            for _ in range(6):
+                opt.zero_grad()
+                loss = loss_fn()
+                loss.backward()
+                opt.step()
+                c.append(float(loss.detach()))
+            curves.append(c)
+    a, b = curves
+    assert all(abs(u - v) <= 2e-3 * abs(u) for u, v in zip(a, b)), (a, b)
+    assert a[-1] < a[0] and b[-1] < b[0]
