@@ -242,16 +242,27 @@ def cpu_baseline(joint_set, budget_s, edge_loss=True, batch=32, mode="train"):
     what = "train steps (fwd + 5 losses + bwd + Adam)" if mode == "train" else "eval forwards + Tester epilogue"
     return {"value": round(B * n / dt, 3), "unit": "meshes/s", "cores": threads, "kind": "port", "nproc": nproc,
             "cpu_model": cpu_model, "threads": threads, "torch": torch.__version__,
-            # tools/cpu_port_vs_reference.py (build container, B=8, 8 threads): the port needs 1.33x the time of the real
-            # reference code for the same step (identical loss): this baseline is that much slower than the reference
-            "port_over_reference_time": 1.328,
+            # how much slower this port is than the real reference code for the same step (identical loss)
+            **_port_ratio(),
             "sample": f"{n} {what} at batch {B} after 1 warm-up, same synthetic "
                       f"{'MANO' if mano else 'SMPL'}-like mesh, inputs and losses; oracle port of the reference CPU "
                       f"path (same torch.sparse.mm -> cat -> permute -> Linear -> BatchNorm1d sequence), "
                       f"{threads} of {nproc} host threads"}
 
 
-def _traffic_for(kernel_prefix):
+def _port_ratio():
+    """Time of the oracle port / time of the real reference code for the same train step, measured by
+    tools/cpu_port_vs_reference.py where /root/reference exists and committed as profiles/cpu_port_vs_reference.json."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")))
+        return {"port_over_reference_time": r["port_over_reference_time"],
+                "port_over_reference_measured_at": f"batch {r['batch']}, {r['threads']} threads, {r['joint_set']}, "
+                                                   f"{r['where']}"}
+    except (OSError, ValueError, KeyError):
+        return {"port_over_reference_time": None}
+
+
+def _traffic_for(*kernel_prefixes):
     """HBM bytes per launch of a kernel family (all template instantiations whose name contains the prefix) from the
     committed PMC passes of this command (tools/rocprof_traffic.sh -> profiles/traffic_latest.json)."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -261,7 +272,7 @@ def _traffic_for(kernel_prefix):
         return None, None
     tot, n = 0.0, 0
     for name, rec in t.get("kernels", {}).items():
-        if kernel_prefix in name:
+        if any(p in name for p in kernel_prefixes):
             tot += rec["total_hbm_bytes"]
             n += rec["launches"]
     if n == 0:
@@ -326,25 +337,27 @@ def main():
         graphed = True
     for _ in range(args.warmup):
         step()
-    if not args.no_kernel_timing and not graphed:
-        ops.TIMER = ops.KernelTimer()
+    # the timed region is CLEAN: no per-launch HIP events in it (round 2 had the timer on inside; it cost ~1 %)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if graphed and not args.no_kernel_timing:
-        # HIP events cannot bracket the nodes of a replayed graph: the per-kernel roofline of the graphed path is taken
-        # from the SAME launches issued one by one right after the timed region (stated in the JSON)
+    if not args.no_kernel_timing:
+        # per-kernel rooflines: the SAME steps once more, launch by launch, every launch bracketed by HIP events on its
+        # stream (a replayed graph cannot be bracketed node by node, so the graphed paths re-issue their launches eagerly)
         ops.TIMER = ops.KernelTimer()
         if train_graph:
             for _ in range(args.steps):
                 eager_step()
-        else:
+        elif graphed:
             with torch.no_grad():
                 for _ in range(args.steps):
                     step.step._eager()
+        else:
+            for _ in range(args.steps):
+                step()
         torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -391,10 +404,12 @@ def main():
         gf = step.dense_gflop_fwd if infer else step.dense_gflop_fwd_bwd
         line["step_dense"] = {("gflop_per_mesh_fwd" if infer else "gflop_per_mesh_fwd_bwd"): round(gf, 2),
                               "tflops": round(line["value"] * gf / 1e3 / world, 2),
-                              "frac_of_f32_mfma_peak": round(line["value"] * gf / 1e3 / world
-                                                             / PEAK_FP32_MFMA_TFLOPS, 4),
-                              "note": "per GPU; algorithmic dense FLOPs of the reference network (fake vertices "
-                                      "included) x meshes/s, against the f32 MFMA peak the reference arithmetic maps to"}
+                              "speedup_equivalent_frac_of_f32_mfma_peak": round(line["value"] * gf / 1e3 / world
+                                                                                / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "note": "per GPU; algorithmic dense FLOPs of the REFERENCE network (every padding vertex "
+                                      "counted, although their contractions are never executed at full width here) x "
+                                      "meshes/s, against the f32 MFMA peak the reference arithmetic maps to: a "
+                                      "speed-up-equivalent, NOT a utilisation -- `roofline` counts executed FLOPs"}
         if timer is not None:
             summ = timer.summary()
 
@@ -444,13 +459,16 @@ def main():
                 # rows the fake-vertex split never touches: kept as speedup_equivalent, not as a roofline fraction.
                 mov = sp["work"] / (sp["ms"] * 1e-3) / 1e9
                 alg = sp["work_alg"] / (sp["ms"] * 1e-3) / 1e9
-                tr, tr_src = _traffic_for("k_basis_tile")
+                # traffic over the SAME launch set as `algorithmic_bytes_per_launch`: every basis kernel of the step
+                tr, tr_src = _traffic_for("k_basis_tile", "k_basis_fwd<")
                 line["roofline_sparse"] = {"bound": "hbm", "kernel": "k_basis_tile (split levels) + k_basis_fwd",
                                            "achieved": round(mov, 1),
                                            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(mov / PEAK_HBM_GBPS, 4),
                                            "frac_of_copy_ceiling_6300": round(mov / 6300.0, 4),
                                            "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
                                            "algorithmic_bytes_per_launch": round(sp["work"] / sp["launches"]),
+                                           "traffic_over_algorithmic": None if tr is None else round(
+                                               tr["hbm_bytes_per_launch"] / (sp["work"] / sp["launches"]), 3),
                                            "launches": sp["launches"],
                                            "avg_launch_ms": round(sp["ms"] / sp["launches"], 4),
                                            "speedup_equivalent": {

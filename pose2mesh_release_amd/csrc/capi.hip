@@ -360,32 +360,41 @@ extern "C" int p2m_graph_set_classes(p2m_graph_t gh, const int32_t* rep_of) {
   if (!(V & 1))
     for (int c = 0; c < V / 2; c++)
       if (w[2 * c] != 0.f || w[2 * c + 1] != 0.f) live_pairs.push_back(c);
-  g->n_live = (int)live.size();
-  g->n_live_pairs = (int)live_pairs.size();
   const int n_rep = (int)reps.size();
   std::vector<float> tile_w(cdiv(n_rep > 0 ? n_rep : 1, 128), 0.f);
   for (int i = 0; i < n_rep; i++) tile_w[i / 128] += wts[i];
-  g->n_fake_all = g->n_fake;
   const int n_pf = (int)pfake.size();
   reps.resize(reps.size() + 64, 0);
   wts.resize(wts.size() + 64, 0.f);
   pfake.resize(pfake.size() + 64, 0);
   std::vector<int> rep_v(rep_of, rep_of + V);
-  int *d_reps = nullptr, *d_pf = nullptr;
+  // upload everything into locals and commit to the handle only when all of it succeeded: on failure the handle is
+  // exactly what it was ("no classes"), and a retry neither leaks nor sees half-set fields
+  int *d_reps = nullptr, *d_pf = nullptr, *d_rep_of = nullptr, *d_live = nullptr, *d_live_pairs = nullptr;
+  float *d_wts = nullptr, *d_tile_w = nullptr, *d_w = nullptr;
   int rc;
   if ((rc = upload(reps.data(), sizeof(int) * reps.size(), (void**)&d_reps)) != P2M_OK ||
       (rc = upload(pfake.data(), sizeof(int) * pfake.size(), (void**)&d_pf)) != P2M_OK ||
-      (rc = upload(wts.data(), sizeof(float) * wts.size(), (void**)&g->fake_wts)) != P2M_OK ||
-      (rc = upload(tile_w.data(), sizeof(float) * tile_w.size(), (void**)&g->fake_tile_w)) != P2M_OK ||
-      (rc = upload(rep_v.data(), sizeof(int) * V, (void**)&g->rep_of)) != P2M_OK ||
-      (rc = upload(live.data(), sizeof(int) * live.size(), (void**)&g->live_ids)) != P2M_OK ||
-      (rc = upload(live_pairs.data(), sizeof(int) * live_pairs.size(), (void**)&g->live_pairs)) != P2M_OK ||
-      (rc = upload(w.data(), sizeof(float) * V, (void**)&g->w)) != P2M_OK) {
-    if (d_reps) (void)hipFree(d_reps);      // the handle's own fields are released by p2m_graph_destroy
-    if (d_pf) (void)hipFree(d_pf);
-    if (g->w) { (void)hipFree(g->w); g->w = nullptr; }   // "no classes": the handle stays usable as it was
+      (rc = upload(wts.data(), sizeof(float) * wts.size(), (void**)&d_wts)) != P2M_OK ||
+      (rc = upload(tile_w.data(), sizeof(float) * tile_w.size(), (void**)&d_tile_w)) != P2M_OK ||
+      (rc = upload(rep_v.data(), sizeof(int) * V, (void**)&d_rep_of)) != P2M_OK ||
+      (rc = upload(live.data(), sizeof(int) * live.size(), (void**)&d_live)) != P2M_OK ||
+      (rc = upload(live_pairs.data(), sizeof(int) * live_pairs.size(), (void**)&d_live_pairs)) != P2M_OK ||
+      (rc = upload(w.data(), sizeof(float) * V, (void**)&d_w)) != P2M_OK) {
+    for (void* q : {(void*)d_reps, (void*)d_pf, (void*)d_wts, (void*)d_tile_w, (void*)d_rep_of, (void*)d_live,
+                    (void*)d_live_pairs, (void*)d_w})
+      if (q) (void)hipFree(q);
     return rc;
   }
+  g->n_live = (int)live.size();
+  g->n_live_pairs = (int)live_pairs.size();
+  g->n_fake_all = g->n_fake;
+  g->fake_wts = d_wts;
+  g->fake_tile_w = d_tile_w;
+  g->rep_of = d_rep_of;
+  g->live_ids = d_live;
+  g->live_pairs = d_live_pairs;
+  g->w = d_w;
   (void)hipFree(g->fake_ids);
   g->fake_ids = d_reps;
   g->n_fake = n_rep;

@@ -691,7 +691,15 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
 #ifdef P2M_PRODUCER_PRIO
     __builtin_amdgcn_s_setprio(P2M_PRODUCER_PRIO);
 #endif
-    const int a_row = pt / (KB / 4), a_k4 = (pt % (KB / 4)) * 4;
+    // LDS stores without bank conflicts.  A row of a slice image is LDX = 24 bf16 = 12 dwords; a ds_write_b64 is serviced
+    // in groups of 16 consecutive lanes (4 rows x 4 k-quads, an 8-dword window per row) over 32 banks, and rows r, r+3
+    // overlap (12 * 3 = 36 = 4 mod 32): 2-way conflicts on every store, 33 % of all LDS cycles of the round-2 kernel
+    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Rows {0,2,4,6} (and {1,3,5,7}) of an 8-row group start at dwords
+    // 0,24,16,8 (12,4,28,20) mod 32 and tile the 32 banks exactly, so each 16-lane group takes the even or the odd rows of
+    // its 8-row group.  The global loads only permute rows inside a wave's 16 rows: same 64-byte segments, same coalescing.
+    const int a_rl = (pt >> 2) & 7;
+    const int a_row = ((pt >> 5) << 3) | ((a_rl & 3) << 1) | (a_rl >> 2), a_k4 = (pt % (KB / 4)) * 4;
+    static_assert(KB == 16, "the conflict-free row permutation assumes 4 k-quads per row");
     // Addresses = wave-uniform 64-bit base (plane + first row of this block's sample / tile, + k0 per chunk: SALU) +
     // per-thread 32-BIT byte offset inside that sample / tile (fixed for the whole kernel): the loads take the
     // `global_load v, v_off, s[base]` form and the chunk loop carries no 64-bit vector address arithmetic - the
@@ -722,7 +730,9 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       voff0[ps] = (unsigned)(((lf >> g.a0_shift) * g.Ka + a_k4) * 4);
       voff12[ps] = (unsigned)((lc * g.Ka + a_k4) * 4);
     }
-    const int b_n = (pt % (BN * 2)) >> 1, b_half = (pt & 1) * 8;
+    // same for the B image: a ds_write_b128 is serviced in groups of 8 consecutive lanes (4 columns x 2 halves)
+    const int b_nl = (pt >> 1) & 7;
+    const int b_n = ((((pt % (BN * 2)) >> 1) >> 3) << 3) | ((b_nl & 3) << 1) | (b_nl >> 2), b_half = (pt & 1) * 8;
     const unsigned bx_voff = (unsigned)((((n0 + b_n) * 16) + b_half) * 2);       // bytes inside one slice of one chunk
     const long bx_slice = (long)g.Npad * 16;
 

@@ -12,12 +12,19 @@ import torch
 
 from . import _lib
 from . import loss as _loss
+from . import ops as _ops
 
 
 class GraphedInference:
     """step = GraphedInference(model, perm_reverse, nv, joint_regressor, batch, scale=1000.0)
     mesh, joints, pose3d = step(pose2d)        # [B, nv, 3] (mesh order, x scale), [B, J, 3], [B, J, 3]
-    The returned tensors are the graph's static outputs: they are overwritten by the next call."""
+    The returned tensors are the graph's static outputs: they are overwritten by the next call.
+
+    The model is put in eval() and switched to the mesh-order inference output (Pose2Mesh.set_inference) for good: other
+    users of the same module object see that layout too.  The captured graph holds raw pointers to the derived weight
+    operands (packed / split weights, eval BatchNorm coefficients) that existed at capture time; the instance keeps
+    those tensors alive, and when the weights change afterwards (optimizer steps, load_state_dict, a train-mode forward:
+    ops.WEIGHT_EPOCH or a parameter's version moves) the next call re-captures instead of replaying stale operands."""
 
     def __init__(self, model, perm_reverse, nv, joint_regressor, batch, scale=1000.0, use_graph=True, warmup=3):
         p = next(model.parameters())
@@ -32,20 +39,35 @@ class GraphedInference:
         self._ident = torch.arange(self.nv, dtype=torch.int32, device=self.device)
         num_joint = model.num_joint
         self.pose2d = torch.zeros((batch, num_joint, 2), device=self.device, dtype=torch.float32)
-        self.graph = None
+        self.graph, self.use_graph, self.warmup = None, bool(use_graph), max(1, int(warmup))
+        self.captures = 0
+        self._capture()
+
+    def _weights_tag(self):
+        return (_ops.WEIGHT_EPOCH,) + tuple((t.data_ptr(), t._version)
+                                           for t in list(self.model.parameters()) + list(self.model.buffers()))
+
+    def _capture(self):
         with torch.cuda.device(self.device), torch.no_grad():
+            self.graph = None
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # warm-up: graph handles, weight packs, allocator pools
-                for _ in range(max(1, warmup)):
+                for _ in range(self.warmup):
                     out = self._eager()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if use_graph:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+            # the operands the captured kernels will read: referenced here so that a later rebuild of the cache entries
+            # cannot hand their memory to someone else while the graph still points at it
+            self._held = [m._weight_cache._d.copy() for m in self.model.modules() if hasattr(m, "_weight_cache")]
+            if self.use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
                     out = self._eager()
+                self.graph = g
             self.mesh, self.joints, self.pose3d = out
+            self._tag = self._weights_tag()
+            self.captures += 1
 
     def _eager(self):
         mesh, pose3d = self.model(self.pose2d)                       # mesh: [B, nv, 3] mesh order x scale
@@ -64,6 +86,8 @@ class GraphedInference:
     @torch.no_grad()
     def __call__(self, pose2d):
         self.pose2d.copy_(pose2d.reshape(self.pose2d.shape), non_blocking=True)
+        if self.graph is not None and self._weights_tag() != self._tag:
+            self._capture()                            # the weights moved since the capture: its operands are stale
         if self.graph is not None:
             self.graph.replay()
             return self.mesh, self.joints, self.pose3d

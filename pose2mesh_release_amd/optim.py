@@ -20,6 +20,7 @@ from . import _lib, ops
 from ._lib import check
 
 _vp = ctypes.c_void_p
+_HP_SLOTS = 16          # pinned staging slots of prepare_step (how far the host may run ahead of the GPU without waiting)
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
@@ -52,6 +53,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self.step_count = 0
         self._hp_host = self._hp_dev = None
+        self._hp_events, self._hp_slot = [], 0
 
     @property
     def lr(self):
@@ -95,11 +97,23 @@ class _FlatOptimizer(torch.optim.Optimizer):
         copy from pinned memory on the current stream).  Call it right before replaying the graph that holds
         step_captured()."""
         self.step_count += 1
-        if self._hp_dev is None:
-            self._hp_host = torch.empty(4, dtype=torch.float32).pin_memory()
-            self._hp_dev = torch.empty(4, dtype=torch.float32, device=self.flat_param.device)
-        self._hp_host.copy_(torch.tensor(self._hp_values(grad_scale), dtype=torch.float32))
-        self._hp_dev.copy_(self._hp_host, non_blocking=True)
+        with torch.cuda.device(self.flat_param.device):
+            if self._hp_dev is None:
+                # a RING of pinned staging slots: with graph replay the host runs many steps ahead of the GPU, and an
+                # async H2D copy reads its pinned source when the GPU gets there -- one slot would be overwritten by
+                # step t+k's values before step t's copy has run (wrong bias corrections / lr, nondeterministically)
+                self._hp_host = torch.empty((_HP_SLOTS, 4), dtype=torch.float32).pin_memory()
+                self._hp_dev = torch.empty(4, dtype=torch.float32, device=self.flat_param.device)
+                self._hp_events = [None] * _HP_SLOTS
+            k = self._hp_slot
+            self._hp_slot = (k + 1) % _HP_SLOTS
+            if self._hp_events[k] is not None:
+                self._hp_events[k].synchronize()      # the copy that last read this slot has completed
+            self._hp_host[k].copy_(torch.tensor(self._hp_values(grad_scale), dtype=torch.float32))
+            self._hp_dev.copy_(self._hp_host[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hp_events[k] = ev
 
     def _launch_captured(self):
         raise NotImplementedError

@@ -18,6 +18,7 @@ momentum=None (its update reads a host counter), anything in loss_fn that synchr
 """
 import torch
 
+from . import ops as _ops
 from . import optim as _optim
 
 
@@ -26,7 +27,9 @@ class GraphedTrainStep:
         if not isinstance(optimizer, _optim._FlatOptimizer):
             raise TypeError("GraphedTrainStep needs optim.FlatAdam / optim.FlatRMSprop (device-resident optimizer state)")
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
-        self.warmup, self.grad_scale = int(warmup), float(grad_scale)
+        # at least one eager step on the capture stream: graph handles, per-stream scratch buffers and the optimizer's
+        # device scalars must exist before the capture (hipMalloc / synchronous copies are illegal inside one)
+        self.warmup, self.grad_scale = max(1, int(warmup)), float(grad_scale)
         self.device = optimizer.flat_param.device
         self.stream = torch.cuda.Stream(device=self.device)
         self.graph, self.loss, self.calls = None, None, 0
@@ -39,6 +42,10 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self):
+        with torch.cuda.device(self.device):
+            return self._call()
+
+    def _call(self):
         cur = torch.cuda.current_stream(self.device)
         self.calls += 1
         if self.graph is None and self.calls <= self.warmup:
@@ -65,4 +72,8 @@ class GraphedTrainStep:
             self.graph = g
         self.opt.prepare_step(self.grad_scale)                  # host: step counter, lr, bias corrections -> device
         self.graph.replay()
+        # the replay updated parameters and BatchNorm running statistics by raw pointer: derived operands cached by
+        # ops.WeightCache (packed / split weights, eval-mode BatchNorm coefficients) are stale for any EAGER forward that
+        # follows (the reference's train-epoch / validation-epoch loop); the captured kernels rebuild their own copies
+        _ops.bump_weight_epoch()
         return self.loss

@@ -98,3 +98,28 @@ def test_graphed_inference_vs_general_path_and_oracle(hip_libs):
     assert helpers.max_vertex_l2(mesh.cpu() / 1000.0, om / 1000.0) <= 1e-4
     assert (joints.cpu() - oj).abs().max() <= 1e-1                      # millimetres (1e-4 m)
     net.set_inference(real_only=False)
+
+
+def test_graphed_inference_recaptures_when_the_weights_change(hip_libs):
+    """the captured graph reads derived weight operands by raw pointer.  After the weights change
+    (here: load_state_dict of other values) the next call must not replay the old operands: it re-captures, and the
+    result is the general path's result for the NEW weights."""
+    from pose2mesh_release_amd import infer, loss as L, synth
+    net, sd, gL, rev, J = _flat("mano")
+    nv, B = 778, 3
+    jreg = synth.synthetic_regressor(J, nv)
+    x = synth.pose2d_batch(B, J, seed=5).cuda()
+    step = infer.GraphedInference(net, rev, nv, jreg, B, scale=1000.0)
+    m0 = step(x)[0].clone()
+    assert step.captures == 1
+    step(x)
+    assert step.captures == 1                                   # unchanged weights: plain replay
+    net.load_state_dict(helpers.numpy_state(net.state_dict(), 11))
+    m1 = step(x)[0].clone()
+    assert step.captures == 2
+    assert not torch.equal(m0, m1)
+    net.set_inference(real_only=False)
+    with torch.no_grad():
+        cam, _ = net(x)
+    ref = L.MeshEpilogue(rev, nv, jreg, scale=1000.0)(cam)[0]
+    assert torch.equal(m1, ref)

@@ -35,19 +35,17 @@ def test_meshnet_vs_reference_golden(hip_libs, joint_set, mode):
     assert err <= VERTEX_TOL, f"max per-vertex L2 {err:.3e}"
     w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).cuda()
     (y * w).sum().backward()
-    # gradients: ReLU kinks make single elements flip between fp32 evaluation orders, so compare in norm
-    assert helpers.rel_l2(x.grad.cpu(), z[f"{mode}_gin"]) < 2e-2
+    # Gradients are NOT compared in norm here any more (round 1's 2e-2 bound hid real errors and flagged nothing): every
+    # gradient tensor is checked element-wise against the float64 oracle with the ReLU kinks accounted for in
+    # tests/test_gpu_parity_full.py.  What the reference fixture pins exactly: a conv bias in front of a train-mode
+    # BatchNorm has a true gradient of exactly 0, and everything is finite.
     P = dict(net.named_parameters())
-    for k, n in zip(z[f"{mode}_grad_names"], z[f"{mode}_grad_norms"]):
+    assert torch.isfinite(x.grad).all()
+    for k in z[f"{mode}_grad_names"]:
         k = str(k)
+        assert torch.isfinite(P[k].grad).all(), k
         if mode == "train" and k.startswith("cl.") and k.endswith("bias") and f"bn.{k.split('.')[1]}.weight" in P:
-            # conv bias in front of a train-mode BatchNorm: the true gradient is exactly 0
             assert float(P[k].grad.norm()) < 1e-3 * max(1.0, float(P[k.replace("bias", "weight")].grad.norm()))
-            continue
-        assert abs(float(P[k].grad.double().norm()) - n) <= 2e-2 * n + 1e-6, k
-        full = f"{mode}_grad::{k}"
-        if full in z:
-            assert helpers.rel_l2(P[k].grad.cpu(), z[full]) < 2e-2, k
     if mode == "train":
         for k, v in net.state_dict().items():
             if "running" in k:

@@ -266,3 +266,93 @@ def test_graphed_flat_model_step_tracks_the_eager_loop(hip_libs):
     a, b = curves
     assert all(abs(u - v) <= 2e-3 * abs(u) for u, v in zip(a, b)), (a, b)
     assert a[-1] < a[0] and b[-1] < b[0]
+
+
+def test_eval_between_graph_replays_sees_the_current_weights(hip_libs):
+    """the reference's loop alternates train epochs and validation epochs.  A replayed step updates
+    parameters and BatchNorm running statistics by raw pointer, so the derived operands cached for eval-mode forwards
+    (packed / split weights, eval BatchNorm coefficients) must be invalidated by every replay: replay, eval, replay, eval
+    must give the eval outputs of the eager loop, bit for bit."""
+    import helpers
+    from pose2mesh_release_amd import meshnet, optim, train
+    gL, _, _ = helpers.golden_graphs("mano")
+    B, J = 4, int(gL[-1].shape[0])
+    x = helpers.meshnet_input(B, J, seed=4).cuda()
+    xe = helpers.meshnet_input(3, J, seed=9).cuda()
+    w = torch.randn(B, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for graphed in (False, True):
+        net = meshnet.get_model(5, 3, gL, mano=True)
+        net.load_state_dict(helpers.numpy_state(net.state_dict(), 3))
+        net = net.cuda().train()
+        opt = optim.FlatAdam(net.parameters(), lr=1e-3)
+        net.accumulate_grads_in_place(True)
+
+        def loss_fn():
+            return (net(x) * w).sum() * 1e-3
+
+        def eager():
+            opt.zero_grad()
+            loss_fn().backward()
+            opt.step()
+        step = train.GraphedTrainStep(net, opt, loss_fn, warmup=1) if graphed else eager
+        evals = []
+        for i in range(6):                       # graphed: 1 eager, capture + replay, then replays
+            step()
+            if i >= 2:
+                net.eval()
+                with torch.no_grad():
+                    evals.append(net(xe).clone())
+                net.train()
+        if graphed:
+            assert step.graph is not None
+        outs.append(evals)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[1][0], outs[1][-1])          # the weights did move between the evals
+
+
+def test_graph_replays_without_host_sync_keep_their_own_step_scalars(hip_libs):
+    """with replay the host runs many steps ahead of the GPU; every step's {lr, bias corrections,
+    grad_scale} must reach the device intact (a single pinned staging slot would be overwritten before its async copy
+    ran).  40 replays issued back to back behind a long-running kernel, lr changed half way == the eager loop, bitwise."""
+    import helpers
+    from pose2mesh_release_amd import meshnet, optim, train
+    gL, _, _ = helpers.golden_graphs("mano")
+    B, J = 2, int(gL[-1].shape[0])
+    x = helpers.meshnet_input(B, J, seed=4).cuda()
+    w = torch.randn(B, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(1)).cuda()
+    N = 40
+    finals = []
+    for graphed in (False, True):
+        net = meshnet.get_model(5, 3, gL, mano=True)
+        net.load_state_dict(helpers.numpy_state(net.state_dict(), 3))
+        net = net.cuda().train()
+        opt = optim.FlatAdam(net.parameters(), lr=1e-3)
+        net.accumulate_grads_in_place(True)
+
+        def loss_fn():
+            return (net(x) * w).sum() * 1e-3
+        if graphed:
+            step = train.GraphedTrainStep(net, opt, loss_fn, warmup=1)
+            step()
+            step()                                            # capture + first replay
+            torch.cuda.synchronize()
+            big = torch.randn(8192, 8192, device="cuda")
+            for _ in range(6):                                # ~tens of ms of queued GPU work: the host gets far ahead
+                big = big @ big * 1e-4
+            for i in range(2, N):
+                if i == N // 2:
+                    opt.param_groups[0]["lr"] = 1e-4
+                step()                                        # no host sync in this loop
+        else:
+            for i in range(N):
+                if i == N // 2:
+                    opt.param_groups[0]["lr"] = 1e-4
+                opt.zero_grad()
+                loss_fn().backward()
+                opt.step()
+        torch.cuda.synchronize()
+        finals.append((opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)

@@ -2,7 +2,10 @@
 """Times the oracle PORT (oracle/meshnet_oracle.py + oracle/loss_oracle.py, what bench.py's cpu_baseline leg runs on the
 GPU box) against the REAL reference (/root/reference through oracle/ref_loader.py) on the same host, same inputs:
 forward+backward+Adam train step, SMPL-like mesh.  Only runs where /root/reference exists (this container).
-usage: python tools/cpu_port_vs_reference.py [B] [threads]"""
+The measured ratio is written to profiles/cpu_port_vs_reference.json (tracked); bench.py's cpu_baseline object reads it as
+`port_over_reference_time` instead of carrying a literal.
+usage: python tools/cpu_port_vs_reference.py [B] [threads] [joint_set]"""
+import json
 import os
 import sys
 import time
@@ -20,9 +23,10 @@ from pose2mesh_release_amd import synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
 torch.set_num_threads(threads)
-faces, graph_L, perm_rev, J = synth.make_graphs("human36")
+joint_set = sys.argv[3] if len(sys.argv) > 3 else "coco"      # bench.py's default train workload (configs[2])
+faces, graph_L, perm_rev, J = synth.make_graphs(joint_set)
 nv = 6890
-ns = ref_loader.load("human36")
+ns = ref_loader.load(joint_set)
 L = ref_loader.load_loss()
 torch.manual_seed(123)
 net = ns.pose2mesh_net.get_model(J, [g.copy() for g in graph_L])
@@ -82,6 +86,13 @@ def bench(fn, n=3):
 
 tr, lr = bench(ref_step)
 tp, lp = bench(port_step)
+out = {"port_over_reference_time": round(tp / tr, 4), "batch": B, "threads": threads, "nproc": os.cpu_count(),
+       "joint_set": joint_set, "reference_s_per_step": round(tr, 3), "port_s_per_step": round(tp, 3),
+       "first_step_loss_reference": lr, "first_step_loss_port": lp, "torch": torch.__version__,
+       "where": "build container (the only place /root/reference exists)",
+       "command": "python tools/cpu_port_vs_reference.py " + " ".join(sys.argv[1:])}
+with open(os.path.join(R, "profiles", "cpu_port_vs_reference.json"), "w") as f:
+    json.dump(out, f, indent=1)
 print(f"B={B} threads={threads} nproc={os.cpu_count()}: real reference {tr:.3f} s/step ({B / tr:.2f} meshes/s), "
       f"oracle port {tp:.3f} s/step ({B / tp:.2f} meshes/s), port/reference time ratio {tp / tr:.3f}; "
       f"first-step loss reference {lr:.6f} port {lp:.6f}")
