@@ -274,6 +274,30 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                           int32_t N, void* stream);
 
+/* ---- Chebyshev basis inside the contraction (default on levels with a tile plan) ---------------------------------
+ * The real rows of one graph convolution (lib/models/backbones/cheby_graph_conv.py:16-37) in ONE kernel - the planes
+ * T1 = L X, T2 = (2 L L - I) X are formed per tile in LDS, cut into bf16 slices and contracted without touching HBM:
+ *     C[b, v, :] = [ A0[b, v >> a0_shift] | (L X)[b, v] | (L2 X)[b, v] ] W (+ bias) (+ addend[b, v, :])
+ * over the rows of the level's tile plan `plan` (p2m_graph_plan_info):
+ *     0  real vertices v of the level;        X [B, V, Ka],   A0 [B, V, Ka]   (usually A0 = X),   C [B, V, N]
+ *     1  the same with an un-pooled input:     X [B, V/2, Ka], A0 [B, V/2, Ka] read at v >> 1,     C [B, V, N]
+ *     2  the paired operator (row set 3):      X [B, V, Ka],   A0 [B, V/2, Ka] = S X (pair-sums),  C [B, V/2, N],
+ *        planes S L X, S L2 X - the backward of an un-pooled conv at the coarse resolution
+ * Bx = p2m_weight_split of the [3 Ka, N] operand (rows k * Ka + fin).  N in {64, 128, 256}, Ka % 32 == 0
+ * (p2m_cheb_tile_gemm_supported).  Rows of C outside the row set are not touched (fake vertices: p2m_gemm_planes_rows,
+ * row set 2 / 4, with p2m_weight_eff).  Optional: stats[B * ntiles(plan)][2][N] BatchNorm partials per (sample, tile)
+ * for p2m_bn_finalize_tiles; E1 / E2 [B * nset, Ka]: the two gathered planes, compact (bitwise those of
+ * p2m_cheb_basis_fwd_real / p2m_cheb_basis_pair), for the weight gradient p2m_gemm_tn_rows; act_*: fused eval-mode
+ * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  Arithmetic: P2M_ARITH_BF16X3.                              */
+int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
+int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
+                       const float* bias, const float* addend, float* C, int32_t N, float* stats, float* E1, float* E2,
+                       const float* act_scale, const float* act_shift, int32_t act_relu, int32_t B, void* stream);
+int p2m_bn_finalize_tiles(p2m_graph_t g, int32_t plan, const float* stats_real, const float* stats_fake, int32_t B,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                          int32_t N, void* stream);
+
 /* ---- project-then-combine form of an un-pooled conv -----------------------------------------------------------
  * A conv whose input was un-pooled x2 sees X_fine[r] = X[r >> 1] (meshnet.py:71-78,111), so
  *     y = [X_fine | L X_fine | L2 X_fine] W = Z0[r >> 1] + sum_j a_j Z1[col_j >> 1] + b_j Z2[col_j >> 1],

@@ -55,6 +55,11 @@ HIP_SYMBOLS = {
     "p2m_cheb_project_combine_fake": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "p2m_bn_finalize_combine": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
                                            _vp]),
+    "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
+    "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32,
+                                      _i32, _vp]),
+    "p2m_bn_finalize_tiles": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
+                                         _i32, _vp]),
     "p2m_graph_fake_ids": (_c.c_int, [_vp, _vp]),
     "p2m_graph_set_classes": (_c.c_int, [_vp, _vp]),
     "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),

@@ -1,0 +1,497 @@
+// Chebyshev basis INSIDE the contraction: the real rows of one graph convolution in ONE kernel, no T1 / T2 planes in HBM.
+//
+//     C[b, v, :] = [ A0[b, v] | (L X)[b, v] | (L2 X)[b, v] ] * W  (+ bias) (+ addend)        v = a real vertex of the level
+//
+// Reference arithmetic: lib/models/backbones/cheby_graph_conv.py:16-37 (x1 = L x0, x2 = 2 L x1 - x0, cat, nn.Linear) and,
+// because L is symmetric (lib/coarsening.py:23), its autograd backward dX = [g | L g | L2 g] W3.  Round 2 ran this as
+// k_basis_tile (writes T1, T2) + k_gemm_planes_ws (reads X, T1, T2): 4 of the ~7.5 row-widths a forward conv moves
+// per real row were the two planes going out and coming back.  Here a block owns one tile of the level's TilePlan
+// (<= 32 consecutive real rows, the sorted union of their source rows, per entry {a, b, local index}) and S = 4 samples
+// = a 128-row M tile, and walks the features in chunks of 32 (one 128-byte line of every union row):
+//
+//   waves 4..7  PRODUCERS   per chunk: the union-row slices of the 4 samples (prefetched into registers a chunk ahead,
+//               whole 128-byte lines) go to LDS xs[u][s][32]; every lane owns (row, sample, 4 features) and accumulates
+//               T1 = sum a x, T2 = sum b x from LDS in the merged-CSR entry order (the fmaf chain of k_basis_fwd /
+//               k_basis_tile: bitwise their planes), takes plane 0 from global, cuts the three planes into the exact
+//               bf16 slices (p2m_split.h) IN REGISTERS, and - once the MFMA waves are done with the previous chunk - stores
+//               them into the A operand image As[slice][s*32 + i][96 k] (k = plane*32 + feature);
+//   waves 0..3  CONSUMERS   per chunk 6 k-steps of 16: A fragments from LDS (ds_read_b128, conflict-free: 208-byte rows),
+//               B fragments (the pre-split weight, p2m_weight_split layout) straight from L2 into registers one step
+//               ahead, 6 slice products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//   Two LDS-only block barriers per chunk; the producers' gather / split of chunk c+1 runs under the MFMAs of chunk c.
+//   A block walks `gpb` sample groups of its tile (tables loaded once; the epilogue of group g overlaps the gather of
+//   group g+1's first chunk).
+//
+// HBM traffic per real row: the union rows once per tile (re-use across neighbouring tiles through L2, as in
+// k_basis_tile), plane 0 once (L2-warm: the row is in its own union), C once; optionally the two gathered planes
+// (backward: the weight gradient X^T [g | Lg | L2g] reads them).
+// LDS: 80 640 (A image) + 61 440 (union rows) + 15 872 (entries, rows padded to 4) + tables = 158.5 KB -> one block per CU:
+// 4 MFMA waves + 8 producer waves (two per SIMD: the gather is a chain of dependent LDS reads, a second wave fills its
+// latencies) for N <= 128, 4 + 4 for N = 256 (the 128-register accumulator needs the 256-register budget).
+#include <cstdlib>
+
+#include "p2m_split.h"
+
+namespace p2m {
+
+constexpr int CT_S = 4;                       // samples per group (M tile = 4 x 32 rows)
+constexpr int CT_CF = 32;                     // features per chunk
+constexpr int CT_KC = 3 * CT_CF;              // k per chunk
+constexpr int CT_LDA = CT_KC + 8;             // bf16 per row of the A image: 208 bytes = 52 dwords (13 x 16 B, 13 odd ->
+                                              // the 16-lane groups of ds_read_b128 tile the 64 banks exactly)
+constexpr int CT_SPAD = 32;                   // + 64 bytes per sample: the two samples of a 16-lane ds_write_b64 group
+                                              // land on disjoint bank halves
+constexpr int CT_SLICE = CT_S * 32 * CT_LDA + CT_S * CT_SPAD;     // bf16 per slice image
+constexpr int CT_ECAP = TILE_ECAP + 3 * TILE_RMAX;                // entries of a tile, every row padded to a multiple of 4
+constexpr int CT_AS_BYTES = 3 * CT_SLICE * 2;
+constexpr int CT_XS_BYTES = TILE_UCAP * CT_S * CT_CF * 4;
+constexpr int CT_ENT_BYTES = CT_ECAP * 16;
+constexpr int CT_TAB_BYTES = 1024;            // rowoff[40], rowvid[32], rowlen[32], rawoff[40]
+constexpr int CT_LDS_BYTES = CT_AS_BYTES + CT_XS_BYTES + CT_ENT_BYTES + CT_TAB_BYTES;
+static_assert(TILE_RMAX == 32, "one MFMA tile per (tile, sample)");
+static_assert(CT_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+
+struct TileGemmArgs {
+  TilePlan pl;
+  const int* row_ids;          // [nset] compact row -> vertex id of the OUTPUT level
+  const float* X;              // gather source [B][x_rows][Ka]
+  const float* A0;             // plane 0       [B][a0_rows][Ka], row = row_ids[i] >> a0_shift
+  const unsigned short* Bx;    // pre-split weight Bx[k / 16][slice][n][k % 16], k = plane * Ka + feature (p2m_weight_split)
+  const float* bias;           // [N] or null
+  const float* addend;         // [B][c_rows][N] or null
+  const float* act_scale;      // optional fused eval-mode BatchNorm (+ ReLU), the two roundings of p2m_bn_act_fwd
+  const float* act_shift;
+  float* C;                    // [B][c_rows][N]
+  float* stats;                // [B][ntiles][2][N] (sum, M2 about the tile mean) or null
+  float* E1;                   // [B * nset][Ka] compact planes out, or null
+  float* E2;
+  long x_rows, a0_rows, c_rows;
+  int act_relu, a0_shift, B, Ka, N, Npad, nset, gpb;
+  int debug;                   // probe runs only (P2M_TILE_GEMM_DEBUG): 1 no gather, 2 no MFMAs, 4 no split, 8 no C stores,
+                               // 16 no B loads, 32 no image stores, 64 no xs stores, 128 no union loads
+};
+
+// TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
+// the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
+template <int TM, int TN, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gemm(TileGemmArgs g) {
+  constexpr int NT = 256 + 64 * NPW;          // 4 consumer waves + NPW producer waves
+  constexpr int WM = CT_S / TM;               // consumer waves along the samples
+  constexpr int WN = 4 / WM;                  // ... along the columns
+  constexpr int RPP = 2 * NPW;                // tile rows the producers gather per pass (2 per wave)
+  constexpr int NRP = 32 / RPP;               // gather passes = rows per producer lane
+  constexpr int NPU = (TILE_UCAP + RPP - 1) / RPP;      // union-row loads per producer lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(ct_smem);
+  unsigned char* xs = ct_smem + CT_AS_BYTES;
+  f32x4* ents = reinterpret_cast<f32x4*>(ct_smem + CT_AS_BYTES + CT_XS_BYTES);
+  int* rowoff = reinterpret_cast<int*>(ct_smem + CT_AS_BYTES + CT_XS_BYTES + CT_ENT_BYTES);
+  int* rowvid = rowoff + 40;
+
+  const TilePlan& pl = g.pl;
+  const int ngroups = (g.B + CT_S - 1) / CT_S;
+  const int nbg = (ngroups + g.gpb - 1) / g.gpb;
+  const int lid = xcd_contiguous(blockIdx.x, gridDim.x);
+  if (lid >= pl.ntiles * nbg) return;
+  const int tile = lid % pl.ntiles;           // tile fastest: the blocks of one XCD work on adjacent tiles of the same
+  const int bg = lid / pl.ntiles;             // samples, whose unions overlap (served by that XCD's L2)
+  const int grp0 = bg * g.gpb;
+  int grp1 = grp0 + g.gpb;
+  if (grp1 > ngroups) grp1 = ngroups;
+  const int nchunks = g.Ka / CT_CF;
+  const int nunits = (grp1 - grp0) * nchunks;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  // Entry table of the tile in LDS, every row PADDED to a multiple of 4 entries with {0, 0, row 0}: the gather loop then
+  // runs whole blocks of 4 with no tail and no masks (0 * x is exact for finite x).  local index -> byte offset in xs.
+  int* rowlen = rowvid + 32;                  // [32] entries per row, [33] unpadded offsets
+  int* rawoff = rowlen + 32;
+  if (t < 32) {
+    rowlen[t] = t < R ? pl.erow[r0 + t + 1] - pl.erow[r0 + t] : 0;
+    rowvid[t] = t < R ? g.row_ids[r0 + t] : -1;
+  }
+  __syncthreads();
+  if (t <= 32) {
+    int po = 0, ro = 0;
+    for (int r = 0; r < t; r++) {
+      po += (rowlen[r] + 3) & ~3;
+      ro += rowlen[r];
+    }
+    rowoff[t] = po;                           // rows >= R: empty
+    rawoff[t] = ro;
+  }
+  __syncthreads();
+  {
+    const int e0 = pl.erow[r0];
+    for (int r = t >> 6; r < R; r += NT / 64) {
+      const int eb = e0 + rawoff[r], len = rowlen[r], o = rowoff[r];
+      for (int k = lane; k < ((len + 3) & ~3); k += 64) {
+        f32x4 en = {0.f, 0.f, 0.f, 0.f};
+        if (k < len) {
+          en = *reinterpret_cast<const f32x4*>(&pl.ent[eb + k]);
+          en[2] = __int_as_float(__float_as_int(en[2]) * (CT_S * CT_CF * 4));
+        }
+        ents[o + k] = en;
+      }
+    }
+  }
+  __syncthreads();
+
+  const bool producer = t >= 256;             // wave-uniform
+
+  if (producer) {
+    // ------------------------------------------------------------------------------------------------------------
+    const int pt = t - 256;
+    const int pw = pt >> 6;                             // producer wave
+    const int q = pt & 7, s = (pt >> 3) & 3;            // this lane's 4 features (16 bytes) of sample s of the group
+    const int lu = pt >> 5;                             // union-row loads: rows lu, lu + RPP, ...
+    const int rlo = lane >> 5;                          // gather: rows ps * RPP + pw * 2 + rlo
+    const unsigned lane_off = (unsigned)((pt & 31) * 16);                     // (s, q) inside a 512-byte xs row
+    unsigned uoff[NPU];                                 // byte offset of this lane's union rows inside one sample of X
+#pragma unroll
+    for (int ps = 0; ps < NPU; ps++) {
+      const int u = lu + ps * RPP;
+      uoff[ps] = (unsigned)pl.ucol[u0 + (u < U ? u : U - 1)] * (unsigned)(g.Ka * 4);      // clamped: loads stay unconditional
+    }
+    int ri[NRP];
+    unsigned a0off[NRP];
+#pragma unroll
+    for (int ps = 0; ps < NRP; ps++) {
+      ri[ps] = ps * RPP + pw * 2 + rlo;
+      const int vid = rowvid[ri[ps]];
+      a0off[ps] = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
+    }
+    f32x4 pf[NPU];                                      // union-row slices in flight (unit w + 1 while unit w is gathered)
+    f32x4 p0[NRP];                                      // plane-0 values of the unit being gathered
+    // unit w = (sample group grp0 + w / nchunks, feature chunk w % nchunks); the loaders are called with consecutive
+    // units, so each keeps its own (group, chunk) counters instead of dividing
+    auto sample_of = [&](int grp) {                     // clamped: a group's missing samples recompute the last one
+      const int b = grp * CT_S + s;
+      return b < g.B ? b : g.B - 1;
+    };
+    int ug = grp0, ufc = 0;                             // next unit of load_union
+    auto load_union = [&]() {
+      const char* base = reinterpret_cast<const char*>(g.X + ((long)sample_of(ug) * g.x_rows) * g.Ka + ufc * CT_CF + q * 4);
+#pragma unroll
+      for (int ps = 0; ps < NPU; ps++) pf[ps] = *reinterpret_cast<const f32x4*>(base + uoff[ps]);
+      if (++ufc == nchunks) { ufc = 0; ug++; }
+    };
+    int pg = grp0, pfc = 0;                             // next unit of load_p0
+    auto load_p0 = [&]() {
+      const char* base = reinterpret_cast<const char*>(g.A0 + ((long)sample_of(pg) * g.a0_rows) * g.Ka + pfc * CT_CF + q * 4);
+#pragma unroll
+      for (int ps = 0; ps < NRP; ps++) p0[ps] = *reinterpret_cast<const f32x4*>(base + a0off[ps]);
+      if (++pfc == nchunks) { pfc = 0; pg++; }
+    };
+    auto store_xs = [&]() {
+#pragma unroll
+      for (int ps = 0; ps < NPU; ps++) {
+        const int u = lu + ps * RPP;
+        if (u < U) *reinterpret_cast<f32x4*>(xs + u * (CT_S * CT_CF * 4) + lane_off) = pf[ps];
+      }
+    };
+    load_union();
+    load_p0();
+    store_xs();
+    if (nunits > 1) load_union();
+    lds_block_barrier();                                // B1(-1): xs(0) visible
+    int grp = grp0, fc = 0;
+    for (int w = 0; w < nunits; w++) {
+      u32x2 sp[NRP][3][3];                              // [row][plane][slice]: the A operand of this unit, held until the
+                                                        // MFMA waves release the image
+#pragma unroll
+      for (int ps = 0; ps < NRP; ps++) {
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+        const int i = ri[ps];
+        const int e = rowoff[i + 1];
+        for (int j = (g.debug & 1) ? e : rowoff[i]; j < e; j += 4) {
+          f32x4 en[4], x[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) en[k] = ents[j + k];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            x[k] = *reinterpret_cast<const f32x4*>(xs + (unsigned)__float_as_int(en[k][2]) + lane_off);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              t1[c] = fmaf(en[k][0], x[k][c], t1[c]);
+              t2[c] = fmaf(en[k][1], x[k][c], t2[c]);
+            }
+          }
+        }
+        if (g.E1 != nullptr && i < R) {
+          const int b = grp * CT_S + s;
+          if (b < g.B) {
+            const long o = ((long)b * g.nset + r0 + i) * g.Ka + fc * CT_CF + q * 4;
+            __builtin_nontemporal_store(t1, reinterpret_cast<f32x4*>(g.E1 + o));
+            __builtin_nontemporal_store(t2, reinterpret_cast<f32x4*>(g.E2 + o));
+          }
+        }
+        if (g.debug & 4) {
+#pragma unroll
+          for (int sl = 0; sl < 3; sl++) {
+            sp[ps][0][sl] = u32x2{__float_as_uint(p0[ps][0]), __float_as_uint(p0[ps][sl])};
+            sp[ps][1][sl] = u32x2{__float_as_uint(t1[0]), __float_as_uint(t1[sl])};
+            sp[ps][2][sl] = u32x2{__float_as_uint(t2[0]), __float_as_uint(t2[sl])};
+          }
+        } else {
+          split3_pack4(p0[ps][0], p0[ps][1], p0[ps][2], p0[ps][3], sp[ps][0][0], sp[ps][0][1], sp[ps][0][2]);
+          split3_pack4(t1[0], t1[1], t1[2], t1[3], sp[ps][1][0], sp[ps][1][1], sp[ps][1][2]);
+          split3_pack4(t2[0], t2[1], t2[2], t2[3], sp[ps][2][0], sp[ps][2][1], sp[ps][2][2]);
+        }
+      }
+      lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
+                                                        //        every producer is done reading xs(w)
+#pragma unroll
+      for (int ps = 0; ps < NRP; ps++) {
+        if (g.debug & 32) break;
+        unsigned short* d = As + (s * 32 + ri[ps]) * CT_LDA + s * CT_SPAD + q * 4;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+          for (int sl = 0; sl < 3; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[ps][p][sl];
+      }
+      lds_block_barrier();                              // B1(w): image of unit w visible - the MFMA waves go; everything
+                                                        //        below runs under their MFMAs, not in front of them
+      if (w + 1 < nunits) {
+        if (!(g.debug & 64)) store_xs();                // xs(w + 1) from the registers loaded a unit ago
+        load_p0();
+        if (w + 2 < nunits && !(g.debug & 128)) load_union();
+      }
+      if (++fc == nchunks) { fc = 0; grp++; }
+      lds_block_barrier();                              // B3(w): xs(w + 1) visible to every producer (the MFMA waves pass
+                                                        //        it between two of their k-steps)
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------------------
+    const int wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // B fragments: byte address = Bx + ((plane * Ka/16 + fc * 2 + half) * 3 + slice) * Npad * 32 + (n * 16 + lhi * 8) * 2
+    const long bx_slice = (long)g.Npad * 32;            // bytes per slice of one 16-wide k chunk
+    const long bx_plane = (long)(g.Ka / 16) * 3 * bx_slice;
+    const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
+    constexpr int NB = TN == 1 ? 3 : 2;                 // ring of B fragment sets: the fragments of step st + NB - 1 are loaded
+    bf16x8 fb[NB][3][TN];                               // during step st (N = 256: no registers for a third set)
+    auto load_b = [&](int fc, int st, bf16x8 (&b)[3][TN]) {   // step st of chunk fc: plane st / 2, half st & 1
+      const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * 3 * bx_slice;
+#pragma unroll
+      for (int sl = 0; sl < 3; sl++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          b[sl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + sl * bx_slice + j * (32 * 16 * 2)));
+    };
+    const unsigned short* a_lane = As + ((wm * TM) * 32 + l31) * CT_LDA + (wm * TM) * CT_SPAD + lhi * 8;
+    auto read_a = [&](int sl, int st, bf16x8 (&a)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+        a[i] = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const u32x4*>(a_lane + sl * CT_SLICE + i * (32 * CT_LDA + CT_SPAD) + st * 16));
+    };
+    load_b(0, 0, fb[0]);
+    if (NB == 3) load_b(0, 1, fb[1]);
+    lds_block_barrier();                                // B1(-1)
+    int grp = grp0, fc = 0;
+    for (int w = 0; w < nunits; w++) {
+      const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
+      lds_block_barrier();                              // B2(w)
+      lds_block_barrier();                              // B1(w): image of unit w is in LDS
+      bf16x8 fl[TM];                                    // the low-slice A fragments: what the first MFMAs of a step read
+      read_a(2, 0, fl);
+#pragma unroll
+      for (int st = 0; st < 6; st++) {
+        // B fragments NB - 1 steps ahead (they do not depend on the producers; the last steps fetch the next unit's first).
+        // sched_barrier: the loads must be ISSUED here - left alone, the scheduler sinks them to just above the first
+        // MFMA that reads them and the L2 latency (longer than one step's MFMAs under load) is exposed at every step
+        if (!(g.debug & 16)) {
+          constexpr int AH = NB - 1;                    // steps of lead; 6 % NB == 0: the ring position of a step is st % NB
+          if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
+          else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 fh[TM], fm[TM];
+        read_a(0, st, fh);
+        read_a(1, st, fm);
+#define P2M_PAIR(FA, SB)                                                                       \
+  if (!(g.debug & 2)) _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], fb[st % NB][SB][j], acc[i][j], 0, 0, 0);
+        P2M_PAIR(fl, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st < 5) read_a(2, st + 1, fl);              // the next step's first operands, under this step's other 5/6
+        P2M_PAIR(fh, 2)
+        P2M_PAIR(fm, 1)
+        P2M_PAIR(fm, 0)
+        P2M_PAIR(fh, 1)
+        P2M_PAIR(fh, 0)
+#undef P2M_PAIR
+        __builtin_amdgcn_sched_barrier(0);
+        if (st == 1) lds_block_barrier();               // B3(w): the producers' xs stores for unit w + 1 (not ours to wait
+                                                        //        for, but s_barrier is block-wide)
+      }
+      if (fc == nchunks - 1) {
+        // ---- epilogue of this sample group: bias, activation, addend, store, BatchNorm partials; then a fresh accumulator
+        float bias_v[TN], sc_v[TN], sh_v[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int n = wn * TN * 32 + j * 32 + l31;
+          bias_v[j] = g.bias != nullptr ? g.bias[n] : 0.f;
+          sc_v[j] = g.act_scale != nullptr ? g.act_scale[n] : 1.f;
+          sh_v[j] = g.act_scale != nullptr ? g.act_shift[n] : 0.f;
+        }
+        int voff[16];                                   // element offset of this lane's 16 accumulator rows inside one
+#pragma unroll                                          // sample of C (-1: no such row); < 2^31: V * N <= 3 M elements
+        for (int r = 0; r < 16; r++) {
+          const int vid = rowvid[(r & 3) + 8 * (r >> 2) + 4 * lhi];
+          voff[r] = vid < 0 ? -1 : vid * g.N;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const int b = grp * CT_S + wm * TM + i;
+          const bool bok = b < g.B;
+          const long sbase = (long)(bok ? b : 0) * g.c_rows * g.N;
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            const int n = wn * TN * 32 + j * 32 + l31;
+            float* Cb = g.C + sbase + n;
+            const float* Ab = g.addend != nullptr ? g.addend + sbase + n : nullptr;
+            float csum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const bool ok = bok && voff[r] >= 0;
+              float v = acc[i][j][r] + bias_v[j];
+              if (g.act_scale != nullptr) v = fmaf(v, sc_v[j], sh_v[j]);
+              if (g.act_relu) v = fmaxf(v, 0.f);
+              if (ok) {
+                if (Ab != nullptr) v += Ab[voff[r]];
+                if (!(g.debug & 8)) Cb[voff[r]] = v;
+                csum += v;
+              }
+              acc[i][j][r] = ok ? v : 0.f;
+            }
+            if (g.stats != nullptr) {
+              // column sums over the tile's rows of this sample: the other 16 rows sit in lane ^ 32
+              csum += __shfl_xor(csum, 32);
+              const float mean = csum / (float)R;
+              float m2 = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; r++) {
+                const float d = acc[i][j][r] - mean;
+                if (voff[r] >= 0) m2 += d * d;
+              }
+              m2 += __shfl_xor(m2, 32);
+              if (lhi == 0 && bok) {
+                float* st = g.stats + ((long)b * pl.ntiles + tile) * 2 * g.N;
+                st[n] = csum;
+                st[g.N + n] = m2;
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+          }
+        }
+        grp++;
+      }
+      fc = fcn;
+    }
+  }
+}
+
+}  // namespace p2m
+
+using namespace p2m;
+
+// gpb: sample groups a block walks.  Enough blocks for a few waves of the 256 CUs, as few table loads as possible.
+static int pick_gpb(int ntiles, int ngroups) {
+  int gpb = 8;
+  while (gpb > 1 && (long)ntiles * cdiv(ngroups, gpb) < 4 * 256) gpb >>= 1;
+  return gpb;
+}
+
+template <int TM, int TN, int NPW>
+static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;     // once per process and instantiation (never inside a stream capture: the first call
+                                    // of every shape happens in the eager warm-up steps)
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", CT_LDS_BYTES, hipGetErrorString(e));
+      return P2M_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int ngroups = cdiv(a.B, CT_S);
+  const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
+  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW>), dim3(nblocks), dim3(256 + 64 * NPW), CT_LDS_BYTES, s, a);
+  return check_launch("cheb_tile_gemm");
+}
+
+extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, int32_t Ka, int32_t N) {
+  if (!gh || plan < 0 || plan > 2) return 0;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.plan[plan].ntiles <= 0) return 0;
+  if (Ka < 32 || Ka % 32 != 0) return 0;
+  return (N == 64 || N == 128 || N == 256) ? 1 : 0;
+}
+
+extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, const float* A0, int32_t Ka,
+                                  const void* Bx, const float* bias, const float* addend, float* C, int32_t N,
+                                  float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,
+                                  int32_t act_relu, int32_t B, void* stream) {
+  P2M_CHECK_ARG(gh && X && A0 && Bx && C, "null pointer");
+  P2M_CHECK_ARG(plan >= 0 && plan <= 2, "plan must be 0 (level), 1 (un-pooled input) or 2 (paired operator)");
+  P2M_CHECK_ARG((E1 == nullptr) == (E2 == nullptr), "E1 / E2 must both be given or both NULL");
+  P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
+  P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (!p2m_cheb_tile_gemm_supported(gh, plan, Ka, N)) {
+    set_error("p2m_cheb_tile_gemm: plan %d of this level / Ka = %d / N = %d is not supported (p2m_cheb_tile_gemm_supported)",
+              plan, Ka, N);
+    return P2M_ERR_INVALID;
+  }
+  if (B <= 0) return P2M_OK;
+  TileGemmArgs a;
+  a.pl = g.plan[plan];
+  const bool paired = plan == 2;
+  a.row_ids = paired ? g.pair_real_ids : g.real_ids;
+  a.nset = paired ? g.n_pair_real : g.n_real;
+  a.X = X;
+  a.A0 = A0;
+  a.Bx = reinterpret_cast<const unsigned short*>(Bx);
+  a.bias = bias;
+  a.addend = addend;
+  a.act_scale = act_scale;
+  a.act_shift = act_shift;
+  a.act_relu = act_relu;
+  a.C = C;
+  a.stats = stats;
+  a.E1 = E1;
+  a.E2 = E2;
+  a.x_rows = plan == 1 ? g.V / 2 : g.V;
+  a.a0_rows = plan == 0 ? g.V : g.V / 2;
+  a.c_rows = paired ? g.V / 2 : g.V;
+  a.a0_shift = plan == 1 ? 1 : 0;
+  a.B = B;
+  a.Ka = Ka;
+  a.N = N;
+  a.Npad = cdiv(N, 128) * 128;          // the layout p2m_weight_split writes
+  a.gpb = pick_gpb(a.pl.ntiles, cdiv(B, CT_S));
+  hipStream_t s = (hipStream_t)stream;
+  static const int dbg = [] { const char* e = getenv("P2M_TILE_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+  a.debug = dbg;
+  static const int npw = [] { const char* e = getenv("P2M_TILE_GEMM_NPW"); return e ? atoi(e) : 8; }();   // probe knob
+  if (N == 256) return launch_tile_gemm<4, 2, 4>(a, s);
+  if (npw == 4) return N == 128 ? launch_tile_gemm<4, 1, 4>(a, s) : launch_tile_gemm<2, 1, 4>(a, s);
+  return N == 128 ? launch_tile_gemm<4, 1, 8>(a, s) : launch_tile_gemm<2, 1, 8>(a, s);
+}

@@ -160,10 +160,14 @@ def _forward_inference(net, graphs, x, params):
             T1 = T2 = Z = None
         elif g.split and mfma:
             y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
-            T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
             Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
-            ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout, Bx=Wtx,
-                                 act=act)
+            T1 = T2 = None
+            if ops.tile_gemm_ok(g, cur_shift, L.Fin, L.Fout):
+                ops.cheb_tile_gemm(g, cur_shift, cur, cur, L.Fin, Wtx, bvec, None, y, L.Fout, B, act=act)
+            else:
+                T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
+                ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout, Bx=Wtx,
+                                     act=act)
         else:
             T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
             Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) if mfma else None
@@ -270,9 +274,9 @@ class _MeshNetFn(torch.autograd.Function):
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
                 opf = wc.get((L.ci, "split_fwd"), W,
                              lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
-                T1, T2, st, st2 = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
-                                                 g.fake_b, need_stats, operands=opf)
-                tile_rows = "rows"
+                T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
+                                                        g.fake_b, need_stats, operands=opf, want_planes=False)
+                tile_rows = ("tiles", cur_shift) if tiled else "rows"
             elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
                 T1 = T2 = None
                 y, st, _ = ops.cheb_gemm_fused(g, cur, L.Fin, cur_shift, Wt, bvec, None, L.Fout, B, stats=need_stats)
@@ -290,6 +294,10 @@ class _MeshNetFn(torch.autograd.Function):
                 if training and tile_rows == "combine":
                     co = ops.bn_finalize_combine(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
                                                  bn_momentum(bn), bn.eps)
+                    bn.num_batches_tracked.add_(1)
+                elif training and isinstance(tile_rows, tuple):
+                    co = ops.bn_finalize_tiles(g, tile_rows[1], B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
+                                               bn_momentum(bn), bn.eps)
                     bn.num_batches_tracked.add_(1)
                 elif training and tile_rows == "rows":
                     co = ops.bn_finalize_rows(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
@@ -527,8 +535,8 @@ class _MeshNetFn(torch.autograd.Function):
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                E1, E2, bn_part, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
-                                                    gph.fake_b, operands=opb, bn=bn_next)
+                E1, E2, bn_part, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
+                                                       gph.fake_b, operands=opb, bn=bn_next)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers

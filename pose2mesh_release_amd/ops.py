@@ -117,6 +117,15 @@ BN_BWD_IN_EPILOGUE = _os.environ.get("P2M_BN_BWD_EPILOGUE", "0") == "1"
 CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 
 
+# Chebyshev basis inside the contraction (p2m_cheb_tile_gemm, include/p2m.h): the real rows of a conv on a level with a
+# tile plan in ONE kernel, no T1 / T2 planes in HBM.  OPT-IN: correct (op and network parity tests) and it removes the
+# plane traffic, but measured slower than basis kernel + plane contraction on MI355X -- 51.2 vs 43.5 ms per train step,
+# 19.1 vs 16.6 ms over the 16 real-row shapes of the step stand-alone (DESIGN.md section 6 "basis inside the
+# contraction": 157 KB of LDS per block leave one block per CU, so nothing covers the MFMA waves' epilogue and the
+# image hand-over, which two resident blocks of the plain contraction cover for each other).
+TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "0") == "1"
+
+
 class DeviceGraph:
     """One coarsening level baked on one GPU: merged CSR of L and 2LL-I (p2m_graph_create).
     Replaces the torch sparse COO tensor + per-forward .cuda() of lib/models/meshnet.py:61-62,81."""
@@ -514,14 +523,54 @@ def bn_finalize_combine(g, B, st_real, st_fake, gamma, beta, running_mean, runni
     return co
 
 
+def tile_gemm_ok(g, plan, Ka, N):
+    """True when the real rows of this conv can take the basis-inside-the-contraction kernel."""
+    return bool(TILE_GEMM and GEMM_ARITH == "bf16x3" and _lib.hip().p2m_cheb_tile_gemm_supported(g.handle, plan, Ka, N))
+
+
+def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None):
+    """C[rows of the plan] = [A0 | L X | L2 X] W (+bias)(+addend) in one kernel (include/p2m.h).  Returns
+    (stats [B*ntiles, 2, N] or None, (E1, E2) compact planes or None)."""
+    nset = g.n_pair_real if plan == 2 else g.n_real
+    st = torch.empty((B * g.plan_tiles[plan], 2, N), device=C.device, dtype=torch.float32) if stats else None
+    E1 = torch.empty((B * nset, Ka), device=C.device, dtype=torch.float32) if want_planes else None
+    E2 = torch.empty((B * nset, Ka), device=C.device, dtype=torch.float32) if want_planes else None
+    fl = 2.0 * B * nset * 3 * Ka * N
+    # algorithmic HBM bytes (SURVEY 8(d), fused rule): the input rows once, the output once (+ the planes when asked for)
+    nbytes = 4.0 * B * nset * (Ka + N + (2 * Ka if want_planes else 0) + (N if addend is not None else 0))
+    with _timed("cheb_tile_gemm", (fl, fl, nbytes)):
+        check(_lib.hip().p2m_cheb_tile_gemm(g.handle, plan, _p(_req(X, "X")), _p(_req(A0, "A0")), Ka, _p(Bx),
+                                            _p(bias if bias is None else _req(bias, "bias")),
+                                            _p(addend if addend is None else _req(addend, "addend")), _p(C), N, _p(st),
+                                            _p(E1), _p(E2), _p(None if act is None else act[0]),
+                                            _p(None if act is None else act[1]), int(bool(act and act[2])), B,
+                                            _stream()), "p2m_cheb_tile_gemm")
+    return st, ((E1, E2) if want_planes else None)
+
+
+def bn_finalize_tiles(g, plan, B, st_real, st_fake, gamma, beta, running_mean, running_var, momentum, eps):
+    N = gamma.shape[0]
+    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
+    check(_lib.hip().p2m_bn_finalize_tiles(g.handle, plan, _p(st_real), _p(st_fake), B, _p(_req(gamma, "bn.weight")),
+                                           _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
+                                           float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
+                                           _stream()), "p2m_bn_finalize_tiles")
+    return co
+
+
 def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, bn=None):
     """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
     C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
     P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
     if P0 is None:
         P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
-    P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
     Bx, We, Wex = operands
+    if bn is None and tile_gemm_ok(g, 2, Ka, N):
+        # planes S L g, S L2 g formed inside the contraction; written out (compact) only for the weight gradient
+        _, (P1c, P2c) = cheb_tile_gemm(g, 2, Gy, P0, Ka, Bx, None, addend, C, N, B, want_planes=True)
+        gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
+        return P0, P1c, P2c, None
+    P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
     part, pa, pb = bn_part_rows(g, (3, 4), B, N, C.device) if bn is not None else (None, None, None)
     gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx,
                      bn=None if bn is None else (bn[0], bn[1], pa))
@@ -530,22 +579,32 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, bn=None):
     return P0, P1c, P2c, part
 
 
-def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, bn=None):
-    """One split contraction: basis planes of the real vertices, the real-vertex GEMM (K = 3*Ka), then the fake-vertex
-    GEMM (K = Ka, W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's
-    basis on a side stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake)."""
-    T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, bn=None,
+               want_planes=True):
+    """One split contraction: the real-vertex rows [X | L X | L2 X] Bm (K = 3*Ka), then the fake-vertex GEMM (K = Ka,
+    W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's basis on a side
+    stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
+    planes of the real vertices (None unless want_planes), the BatchNorm partials of the two launches, and whether
+    st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
+    (p2m_bn_finalize_split)."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
+    if bn is None and tile_gemm_ok(g, a0_shift, Ka, N):
+        st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
+                                     want_planes=want_planes)
+        st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
+        T1c, T2c = planes if planes is not None else (None, None)
+        return T1c, T2c, st1, st2, True
+    T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
     if bn is not None:          # backward use: bn = (y, co) of the layer C flows into; returns the reduction partials
         part, pa, pb = bn_part_rows(g, (1, 2), B, N, C.device)
         gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, False, Bx=Bx,
                          bn=(bn[0], bn[1], pa))
         gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, False, Bx=Wex,
                          bn=(bn[0], bn[1], pb))
-        return T1c, T2c, part, None
+        return T1c, T2c, part, None, False
     st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx)
     st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
-    return T1c, T2c, st1, st2
+    return T1c, T2c, st1, st2, False
 
 
 # blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,

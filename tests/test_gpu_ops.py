@@ -563,3 +563,62 @@ def test_non_default_kernel_variants_in_a_subprocess(env, hip_libs):
                        env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("V,Fin,Fout,shift,B", [(736, 128, 128, 0, 5), (736, 128, 128, 1, 3), (1472, 256, 128, 0, 4),
+                                                (1472, 128, 256, 1, 9), (2944, 128, 64, 0, 2), (736, 64, 128, 0, 7),
+                                                (736, 256, 256, 1, 6)])
+def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkeypatch, V, Fin, Fout, shift, B):
+    """p2m_cheb_tile_gemm (the Chebyshev planes formed per tile in LDS and contracted without touching HBM) against the
+    two-kernel form it replaces, p2m_cheb_basis_fwd_real + p2m_gemm_planes_rows: same real rows of C (fp32 round-off:
+    the k order of the accumulation differs), untouched fake rows, the optional planes BITWISE those of the basis kernel
+    (same entry order, same fmaf chain), BatchNorm statistics through their own finalize, addend, fused activation.
+    B is deliberately not a multiple of the 4 samples a block tile holds."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
+    L = _band_graph(V, 7 + V + shift)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert g.plan_tiles[shift] > 0 and ops.tile_gemm_ok(g, shift, Fin, Fout)
+    gen = torch.Generator().manual_seed(V + Fin + Fout)
+    M = B * V
+    X = torch.randn(B * (V >> shift), Fin, generator=gen).cuda()
+    Wt = (torch.randn(3 * Fin, Fout, generator=gen) / (3 * Fin) ** 0.5).cuda()
+    bias = torch.randn(Fout, generator=gen).cuda()
+    add = torch.randn(M, Fout, generator=gen).cuda()
+    Bx = ops.weight_split(Wt)
+    T1c, T2c = ops.cheb_basis_fwd_real(g, X, B, Fin, shift)
+    real = torch.as_tensor(_real_ids(L), device="cuda")
+    fake = torch.ones(V, dtype=torch.bool, device="cuda")
+    fake[real] = False
+    for addend, act, stats in ((None, None, True), (add, None, False),
+                               (None, (torch.rand(Fout).cuda() + 0.5, torch.randn(Fout).cuda(), True), False)):
+        yref = torch.full((M, Fout), 7.0, device="cuda")
+        st_ref = ops.gemm_planes_rows(g, 1, B, [X, T1c, T2c], Fin, shift, True, Wt, bias, addend, yref, Fout, stats,
+                                      Bx=Bx, act=act)
+        y = torch.full((M, Fout), 7.0, device="cuda")
+        st, planes = ops.cheb_tile_gemm(g, shift, X, X, Fin, Bx, bias, addend, y, Fout, B, stats=stats,
+                                        want_planes=stats, act=act)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        assert torch.equal(y.view(B, V, Fout)[:, fake], yref.view(B, V, Fout)[:, fake])        # fake rows untouched
+        err = (y - yref).abs().max().item()
+        assert err < 2e-5 * max(1.0, yref.abs().max().item()), err
+        if stats:
+            assert torch.equal(planes[0], T1c) and torch.equal(planes[1], T2c)
+            gamma, beta = (torch.rand(Fout) + 0.5).cuda(), torch.randn(Fout).cuda()
+            We = ops.weight_eff(Wt, Fin, Fout, g.fake_a, g.fake_b)
+            st2 = ops.gemm_planes_rows(g, 2, B, [X], Fin, shift, False, We, bias, None, yref, Fout, True)
+            co_ref = ops.bn_finalize_rows(g, B, st_ref, st2, gamma, beta, None, None, 0.1, 1e-5)
+            co = ops.bn_finalize_tiles(g, shift, B, st, st2, gamma, beta, None, None, 0.1, 1e-5)
+            assert (co - co_ref).abs().max() < 2e-5 * max(1.0, co_ref.abs().max().item())
+    # float64 anchor for the real rows (the two HIP forms above could share an error)
+    Xd = X.double().view(B, V >> shift, Fin)
+    if shift:
+        Xd = Xd.repeat_interleave(2, dim=1)
+    Ld = torch.from_numpy(sp.csr_matrix(L).toarray()).double().cuda()
+    T1d = torch.einsum("uv,bvf->buf", Ld, Xd)
+    T2d = 2 * torch.einsum("uv,bvf->buf", Ld, T1d) - Xd
+    yd = torch.cat((Xd, T1d, T2d), dim=2) @ Wt.double() + bias.double()
+    y = torch.zeros((M, Fout), device="cuda")
+    ops.cheb_tile_gemm(g, shift, X, X, Fin, Bx, bias, None, y, Fout, B)
+    err = (y.view(B, V, Fout)[:, real].double() - yd[:, real]).abs().max().item()
+    assert err < 2e-5 * max(1.0, yd.abs().max().item()), err
