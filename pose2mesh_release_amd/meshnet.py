@@ -379,6 +379,10 @@ class _MeshNetFn(torch.autograd.Function):
                     return None
                 out.append(gbuf)
             return out
+        def ready(*names):
+            """the kernels writing these parameters' gradients in place are enqueued on the CURRENT stream"""
+            if net._grad_sink is not None and net._direct_grad:
+                net._grad_sink([params[P[n]] for n in names])
         G = grad_out.contiguous().float().view(-1, net.num_mesh_output_chan)   # grad wrt current block output
         g_out = graphs[net._layers[-1].graph]
         if g_out.classes:      # class-sum form: a representative carries the gradient of its whole class, holes nothing
@@ -420,6 +424,7 @@ class _MeshNetFn(torch.autograd.Function):
                     tg = tgt("fc.weight", "fc.bias")
                     if tg is not None:
                         ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1, dW=tg[0], db=tg[1])
+                        ready("fc.weight", "fc.bias")
                     else:
                         grads[P["fc.weight"]], grads[P["fc.bias"]] = \
                             ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
@@ -488,6 +493,8 @@ class _MeshNetFn(torch.autograd.Function):
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
+                else:
+                    ready(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 if want_Gs:
                     Gs_block = res[3]
                 if want_P0:
@@ -525,6 +532,8 @@ class _MeshNetFn(torch.autograd.Function):
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
                                                      L.Fin, *(tg or ()))
                     keep.extend((Pw, Pb, Pw2, Pb2))
+                    if tg is not None:
+                        ready(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                 if tg is None:
                     grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, Pw2, Pb2, P0, E1, E2, add
@@ -547,6 +556,8 @@ class _MeshNetFn(torch.autograd.Function):
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
                                                      L.Fin, *(tg or ()))
                     keep.extend((Pw, Pb, Pw2, Pb2))
+                    if tg is not None:
+                        ready(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                 if tg is None:
                     grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, Pw2, Pb2, E1, E2, dXf
@@ -564,6 +575,7 @@ class _MeshNetFn(torch.autograd.Function):
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     if tg is not None:
                         ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, dW=tg[0], db=tg[1], layout=1)
+                        ready(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     else:
                         dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
                     keep.extend((Pw, Pb))
@@ -656,6 +668,7 @@ class Pose2Mesh(nn.Module):
         self._graph_cache = ops.GraphCache(graph_L, class_plan=self._class_plan)
         self._weight_cache = ops.WeightCache()
         self._direct_grad = False
+        self._grad_sink = None
         self._infer_real_only = False
         self._out_perm, self._out_nv, self._out_scale, self._out_index = None, 0, 1.0, {}
         self._tap = None        # tests set this to a list to receive (conv index, y_raw, bn scale, bn shift) per layer
@@ -724,6 +737,14 @@ class Pose2Mesh(nn.Module):
         with one small kernel each.  Same values; `loss.backward()` only -- torch.autograd.grad() on these parameters
         would see no gradient, which is why this is not the default."""
         self._direct_grad = bool(enable)
+        return self
+
+    def set_grad_sink(self, sink):
+        """sink(list of parameters): called from the backward, on the stream that just received the kernels writing those
+        parameters' gradients, when the gradients are accumulated in place (accumulate_grads_in_place) - autograd never
+        sees them, so hooks cannot report them.  dist.BucketedAllReduce.notify is the intended sink: the gradient
+        all-reduce of a finished bucket then starts under the backward of the coarser levels."""
+        self._grad_sink = sink
         return self
 
     def set_inference(self, real_only=True, perm_reverse=None, nv=None, scale=1.0):

@@ -145,10 +145,25 @@ def save_chebconv(gL_mano):
     np.savez_compressed(os.path.join(HERE, "chebconv.npz"), **out)
 
 
+def real_regressor():
+    """data/Human36M/J_regressor_h36m_correct.npy: the one regressor the reference ships ((17, 6890) float64, 107 nnz)."""
+    R = np.load(os.path.join(ref_loader.REF_ROOT, "data", "Human36M", "J_regressor_h36m_correct.npy"))
+    assert R.shape == (17, 6890)
+    return R.astype(np.float32)
+
+
+def regressor_triplets(R):
+    r, c = np.nonzero(R)
+    return {"jreg_rows": r.astype(np.int32), "jreg_cols": c.astype(np.int32), "jreg_vals": R[r, c].astype(np.float32),
+            "jreg_shape": np.asarray(R.shape, np.int64)}
+
+
 def save_loss(joint_set):
-    """The reference's loss classes, called in the order and with the weights of lib/core/base.py:130-143."""
+    """The reference's loss classes, called in the order and with the weights of lib/core/base.py:130-143.
+    human36: with the reference's REAL joint regressor (embedded in the fixture), the others with a synthetic one."""
     L = ref_loader.load_loss()
-    c = helpers.loss_case(joint_set)
+    jreg = real_regressor() if joint_set == "human36" else None
+    c = helpers.loss_case(joint_set, jreg=jreg)
     losses = L.get_loss(c["faces"])                                        # base.py:60 / loss.py:117-120
     out = {}
     for tag, with_edge in (("edge", True), ("noedge", False)):
@@ -172,6 +187,8 @@ def save_loss(joint_set):
         out[f"{tag}_grad_cam"] = cam.grad.numpy()
         out[f"{tag}_grad_lift"] = lift.grad.numpy()
     out["cam_sha"] = np.frombuffer(__import__("hashlib").sha256(c["cam_mesh"].numpy().tobytes()).digest(), np.uint8)
+    if jreg is not None:
+        out.update(regressor_triplets(jreg))
     np.savez_compressed(os.path.join(HERE, f"loss_{joint_set}.npz"), **out)
 
 
@@ -217,16 +234,21 @@ def save_demo(gL, rev):
     with torch.no_grad(), ref_loader.cpu_cuda_shim():
         pred_mesh, pose3d = net(x)                                                                # run.py:167
         mesh = pred_mesh[:, rev[:nv], :]                                                          # run.py:170
-        jreg = torch.from_numpy(synth.synthetic_regressor(J, nv))
-        joints = torch.matmul(jreg, mesh)                                                         # run.py:171
+        R = real_regressor()                          # demo/run.py:127 loads exactly this file (mesh_model.joint_regressor_h36m)
+        joints = torch.matmul(torch.from_numpy(R), mesh)                                          # run.py:171
     np.savez_compressed(os.path.join(HERE, "demo_h36m.npz"), joint_input=joint_input, bbox=bbox, bbox2=bbox2,
                         trans=trans, model_input=x.numpy(), cam_mesh=pred_mesh.numpy(), pose3d=pose3d.numpy(),
-                        mesh=mesh.numpy(), joints=joints.numpy())
+                        mesh=mesh.numpy(), joints=joints.numpy(), **regressor_triplets(R))
 
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference tree missing"
     torch.set_num_threads(os.cpu_count() or 1)
+    if sys.argv[1:] == ["regressor-fixtures"]:         # only the two fixtures that carry the reference's real regressor
+        save_loss("human36")
+        _, gLh, _, revh, _, _ = ref_graphs("human36")
+        save_demo(gLh, revh)
+        sys.exit(0)
     graphs = {}
     for js in ("mano", "human36", "coco"):
         graphs[js] = save_graphs(js)
@@ -237,7 +259,7 @@ if __name__ == "__main__":
     save_flat("mano", *graphs["mano"])
     save_flat("coco", *graphs["coco"])
     save_chebconv(graphs["mano"][0])
-    for js in ("mano", "coco"):
+    for js in ("mano", "coco", "human36"):
         save_loss(js)
         print("loss", js)
     for js in ("mano", "human36", "coco"):

@@ -101,7 +101,16 @@ def max_vertex_l2(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).norm(dim=-1).max())
 
 
-def loss_case(joint_set, B=None, seed=17):
+def golden_regressor(name="loss_human36.npz"):
+    """The reference's own joint regressor data/Human36M/J_regressor_h36m_correct.npy ((17, 6890), 107 nnz), as embedded
+    (CSR triplets, fp32) in the fixtures that tests/golden/make_golden.py generated from it."""
+    z = golden(name)
+    R = np.zeros(tuple(int(v) for v in z["jreg_shape"]), dtype=np.float32)
+    R[z["jreg_rows"], z["jreg_cols"]] = z["jreg_vals"]
+    return R
+
+
+def loss_case(joint_set, B=None, seed=17, jreg=None):
     """Deterministic inputs of the train-step epilogue + losses (lib/core/base.py:122-143) for one joint set:
     numpy PCG64 draws, mask shapes as the reference dataloaders emit them ([B, nv, 1] / [B, J, 1], constant per
     sample: data/Human36M/dataset.py:392-394).  Used by make_golden.py (real reference) and by the tests."""
@@ -118,7 +127,7 @@ def loss_case(joint_set, B=None, seed=17):
     def t(shape, scale):
         return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
     c = {"faces": faces, "perm_reverse": np.asarray(rev), "nv": nv, "V0": V0, "J": J, "B": B,
-         "J_regressor": torch.from_numpy(synth.synthetic_regressor(J, nv)),
+         "J_regressor": torch.from_numpy(synth.synthetic_regressor(J, nv) if jreg is None else np.asarray(jreg, np.float32)),
          "cam_mesh": t((B, V0, 3), 0.3), "lift_pose": t((B, J, 3), 300.0), "gt_mesh": t((B, nv, 3), 0.3),
          "gt_reg3dpose": t((B, J, 3), 300.0), "gt_lift3dpose": t((B, J, 3), 300.0)}
     vm = (rng.random(B) > 0.3).astype(np.float32)

@@ -47,7 +47,8 @@ class _FProxy:
         lid = self._n
         self._n += 1
         own = x.detach() > 0
-        m = own if self._masks is None else self._masks[lid].reshape(x.shape)
+        # masks may arrive bit-unpacked from a child process (padded to a multiple of 8 elements)
+        m = own if self._masks is None else self._masks[lid].flatten()[:x.numel()].reshape(x.shape)
         diff = m != own
         n = int(diff.sum())
         self._stats["n_relu_elements"] += x.numel()

@@ -37,7 +37,11 @@ for m in net.modules():
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.0
 opt = optim.FlatAdam(net.parameters(), lr=1e-3)
-red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=32 << 20)
+# the bench's configuration: MeshNet gradients accumulate in place and are reported to the reducer per layer from inside
+# the backward (no autograd hooks fire for them); small buckets so that several of them lie inside the MeshNet slice
+net.pose2mesh.accumulate_grads_in_place(True)
+red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=4 << 20)
+net.pose2mesh.set_grad_sink(red.notify)
 fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy())
 stock = L.get_loss(c["faces"])
 sl = slice(rank * 4, rank * 4 + 4)
@@ -49,6 +53,12 @@ total, _ = fused(mesh, c["gt_mesh"][sl].to(dev), c["gt_reg3dpose"][sl].to(dev), 
 lift_l = 1e-3 * stock[4](lift, c["gt_lift3dpose"][sl].to(dev), c["val_lift3dpose"][sl].to(dev))
 lift_l.backward()
 total.backward()
+# overlap by construction: a bucket made of MeshNet parameters only was launched while gradients were still arriving
+mesh_ids = {{id(p) for p in net.pose2mesh.parameters()}}
+mesh_only = [b for b, (_, _, idx) in enumerate(red.buckets) if all(id(opt.params[i]) in mesh_ids for i in idx)]
+log, seen_total = list(red.launch_log), red._seen
+early = [seen for b, seen in log if b in mesh_only]
+assert len(mesh_only) >= 2 and early and min(early) <= seen_total - 10, (mesh_only, log, seen_total)
 scale = red.finish()
 assert abs(scale - 0.5) < 1e-12 and len(red.buckets) >= 2
 grads = {{k: (p.grad * scale).cpu().numpy() for k, p in net.named_parameters()}}
@@ -146,3 +156,71 @@ def test_bench_two_ranks_on_one_gpu(hip_libs):
     assert j["config"]["global_batch"] == 32 and j["config"]["parallelism"] == "dp2"
     assert 300 < j["config"]["grad_allreduce_MB"] < 310          # 76.0 M parameters x 4 B
     assert j["value"] > 0 and "cpu_baseline" not in j
+
+
+ONE_RANK_RCCL = r'''
+import os, sys
+sys.path[:0] = [{root!r}, {root!r} + "/oracle", {root!r} + "/tests"]
+import torch, torch.distributed as dist
+import helpers
+from pose2mesh_release_amd import dist as pd, loss as L, optim, pose2mesh_net, synth
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm: loads librccl, one communicator
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+gL, _, rev = helpers.golden_graphs("mano")
+c = helpers.loss_case("mano", B=8, seed=23)
+pose2d = synth.pose2d_batch(8, 21, seed=31).to(dev)
+finals = []
+for use_rccl in (False, True):
+    net = pose2mesh_net.get_model(21, gL, mano=True)
+    net.load_state_dict(helpers.numpy_state(net.state_dict(), 4))
+    net = net.to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    opt = optim.FlatAdam(net.parameters(), lr=1e-3)
+    net.pose2mesh.accumulate_grads_in_place(True)
+    red = None
+    if use_rccl:
+        red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=4 << 20, always=True)
+        net.pose2mesh.set_grad_sink(red.notify)
+        assert red.active and red.world == 1
+    fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy())
+    stock = L.get_loss(c["faces"])
+    for step in range(3):                 # no host synchronisation between the steps: the ordering is the streams' job
+        opt.zero_grad()
+        mesh, lift = net(pose2d)
+        total, _ = fused(mesh, c["gt_mesh"].to(dev), c["gt_reg3dpose"].to(dev), c["val_mesh"].to(dev),
+                         c["val_reg3dpose"].to(dev))
+        lift_l = 1e-3 * stock[4](lift, c["gt_lift3dpose"].to(dev), c["val_lift3dpose"].to(dev))
+        lift_l.backward()
+        total.backward()
+        scale = 1.0
+        if red is not None:
+            n_launched_in_backward = len(red.launch_log)
+            scale = red.finish()
+            assert scale == 1.0 and n_launched_in_backward >= 3
+            red.launch_log.clear()
+        opt.step(scale)
+    torch.cuda.synchronize()
+    finals.append((opt.flat_param.clone(), opt.exp_avg.clone()))
+# a sum over ONE rank is the identity: with the collectives (async Work objects, waited on by the stream, issued from the
+# communication stream) in the step, three updates are bit for bit those of the plain loop
+assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+dist.destroy_process_group()
+print("ONE_RANK_RCCL_OK")
+'''
+
+
+def test_one_rank_rccl_group_runs_the_bucketed_all_reduce(hip_libs, tmp_path):
+    """VERDICT r2 "next round" 7(a): what one GPU can prove about the RCCL path.  A 1-rank `nccl` process group (librccl
+    loaded, a real communicator), the real FlatPose2Mesh train step with the bucketed all-reduce forced on: the nccl
+    backend's asynchronous Work.wait() (the stream waits, not the host - unlike gloo's blocking wait) must order the
+    optimizer step after the collectives; three steps without host synchronisation == the loop without collectives."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(ONE_RANK_RCCL.format(root=ROOT, port=str(_free_port())))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "ONE_RANK_RCCL_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

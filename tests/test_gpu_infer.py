@@ -123,3 +123,25 @@ def test_graphed_inference_recaptures_when_the_weights_change(hip_libs):
         cam, _ = net(x)
     ref = L.MeshEpilogue(rev, nv, jreg, scale=1000.0)(cam)[0]
     assert torch.equal(m1, ref)
+
+
+def test_graphed_inference_at_configs1_size_vs_oracle(hip_libs):
+    """BASELINE configs[1] on the bench's own path: batch 64, J=17, the captured hipGraph of the real-vertices-only
+    forward + Tester epilogue; 4 samples of that batch against the oracle (eval-mode samples are independent)."""
+    from pose2mesh_release_amd import infer, synth
+    net, sd, gL, rev, J = _flat("human36")
+    nv, B = 6890, 64
+    jreg = synth.synthetic_regressor(J, nv)
+    x = synth.pose2d_batch(B, J, seed=31).cuda()
+    step = infer.GraphedInference(net, rev, nv, jreg, B, scale=1000.0)
+    assert step.graph is not None
+    mesh, joints, _ = step(x)
+    torch.cuda.synchronize()
+    idx = [0, 21, 42, 63]
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        cam_o, _ = mo.flat_forward(sd, helpers.oracle_graphs(gL), x[idx].cpu(), False, False)
+    om, oj = lo.test_epilogue(cam_o, rev, nv, torch.from_numpy(jreg))
+    assert helpers.max_vertex_l2(mesh[idx].cpu() / 1000.0, om / 1000.0) <= 1e-4
+    assert (joints[idx].cpu() - oj).abs().max() <= 1e-1                      # millimetres (1e-4 m)
+    net.set_inference(real_only=False)

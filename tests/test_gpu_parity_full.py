@@ -117,6 +117,50 @@ def _kink_resolved_check(tag, joint_set, B, wseed, xseed, gseed, dtype=torch.flo
     return hip, st
 
 
+INDEPENDENT_SET = dict(P2M_GEMM_ARITH="f32", P2M_SPLIT_FAKE="0", P2M_BASIS_TILED="0", P2M_GEMM_WS="0", P2M_TN_WS="0")
+
+
+def _child_run(tmp_path, env, joint_set, B, mode, wseed, xseed, gseed):
+    out = str(tmp_path / "child.npz")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, joint_set, str(B), mode,
+                        str(wseed), str(xseed), str(gseed)], env=dict(os.environ, P2M_TEST_TAP="1", **env),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return np.load(out)
+
+
+def _kink_resolved_check_child(tag, tmp_path, env, joint_set, B, wseed, xseed, gseed):
+    """The same float64 comparison for a NON-DEFAULT kernel set: the network runs in a child process under `env`, its
+    ReLU masks come back bit-packed, the float64 oracle runs with those masks."""
+    import kinks
+    res = _child_run(tmp_path, env, joint_set, B, "train", wseed, xseed, gseed)
+    keys = sorted((k for k in res.files if k.startswith("mask::")), key=lambda k: int(k[6:]))
+    masks = [torch.from_numpy(np.unpackbits(res[k]).astype(bool)) for k in keys]
+    sd, glt, x, mano, w = _oracle_inputs(joint_set, B, wseed, xseed, gseed)
+    out64, g64, st = kinks.masked_oracle_gradients(sd, glt, x, mano, w, masks)
+    err = helpers.max_vertex_l2(res["out"], out64)
+    _record(f"{tag}_vertex_l2", err)
+    assert err <= VERTEX_TOL
+    assert st["max_abs_preact_at_flip"] <= KINK_WINDOW, st
+    assert st["n_flips"] <= max(20, 4e-6 * st["n_relu_elements"]), st
+    _compare_grads({k[6:]: res[k] for k in res.files if k.startswith("grad::")}, g64, ALIGNED_GRAD_TOL,
+                   f"{tag}_grads_masks_aligned", True)
+
+
+def test_independent_kernel_set_vs_oracle_train(hip_libs, tmp_path):
+    """The INDEPENDENT kernel set of test (c) -- native f32 MFMA, unsplit rows (every fake row computed, backward at the
+    fine resolution), row-per-wave basis kernel, 4-wave contractions -- pinned to the float64 oracle at NETWORK level
+    (human36, B=3, train, every gradient tensor, kinks accounted for), so that the B=256 / B=512 default-vs-independent
+    comparisons stand on a leg that is itself tied to the reference arithmetic."""
+    _kink_resolved_check_child("a_independent_human36_B3", tmp_path, INDEPENDENT_SET, "human36", 3, 21, 99, 5)
+
+
+def test_basis_inside_the_contraction_network_vs_oracle_train(hip_libs, tmp_path):
+    """The opt-in P2M_TILE_GEMM=1 path (p2m_cheb_tile_gemm on every split level: forward, plain and paired backward)
+    inside the whole network against the float64 oracle, kinks accounted for."""
+    _kink_resolved_check_child("a_tile_gemm_human36_B3", tmp_path, {"P2M_TILE_GEMM": "1"}, "human36", 3, 21, 99, 5)
+
+
 @pytest.mark.parametrize("joint_set,B", [("mano", 5), ("human36", 3), ("coco", 2)])
 def test_full_gradients_vs_oracle_train(hip_libs, joint_set, B):
     """(a) every parameter gradient and the input gradient, FULL tensors, train mode, fresh inputs, against float64
@@ -136,44 +180,43 @@ def test_full_gradients_vs_oracle_eval(hip_libs):
     _compare_grads({k[6:]: v for k, v in hip.items() if k.startswith("grad::")}, ref_g, 1e-3, "a_mano_eval_grads", False)
 
 
-@pytest.mark.parametrize("joint_set,B", [("mano", 256), ("human36", 32)])
+@pytest.mark.parametrize("joint_set,B", [("mano", 256), ("human36", 32), ("coco", 32)])
 def test_bench_scale_vs_oracle_train(hip_libs, joint_set, B):
     """(b) MANO B=256 (the MANO config's row-set tiling, 256 x tiles-per-sample) and SMPL-like B=32 (BASELINE.md
-    section 2: 8.8 GB on the CPU in fp32) forward + backward against the float64 oracle, kinks accounted for."""
+    section 2: 8.8 GB on the CPU in fp32) forward + backward against the float64 oracle, kinks accounted for; coco
+    (J=19) is the bench's own graph (BASELINE configs[2])."""
     _kink_resolved_check(f"b_{joint_set}_B{B}", joint_set, B, 31, 77, 8)
 
 
-def test_configs2_default_vs_independent_kernel_set(hip_libs, tmp_path):
-    """(c) BASELINE configs[2]: SMPL-like coco graph, B=256, train.  No CPU oracle can run this size (float64 needs
-    ~140 GB), so the default kernel set (bf16x3 contraction on the BF16 pipe, fake-vertex split, LDS-tiled basis,
-    wave-specialised GEMM) is compared with an INDEPENDENT one (native f32 MFMA, unsplit rows, row-per-wave gather,
-    4-wave GEMM) that the small-size tests pin to the oracle separately.  Forward: per-vertex L2.  Backward: the two
-    runs' ReLU masks are compared bit by bit -- the handful of differing elements (fp32 kinks) is counted, and the
-    gradient tolerance is the one that count explains; plus 4 eval samples of the SAME batch against the oracle."""
-    out = str(tmp_path / "indep.npz")
-    env = dict(os.environ, P2M_GEMM_ARITH="f32", P2M_SPLIT_FAKE="0", P2M_BASIS_TILED="0", P2M_GEMM_WS="0",
-               P2M_TN_WS="0", P2M_TEST_TAP="1")
-    r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, "coco", "256", "train",
-                        "41", "55", "9"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    ind = np.load(out)
-    hip = _hip_run("coco", 256, "train", 41, 55, 9, tap=True)
+@pytest.mark.parametrize("joint_set,B,seeds", [("coco", 256, (41, 55, 9)), ("mano", 512, (42, 56, 10))])
+def test_baseline_sizes_default_vs_independent_kernel_set(hip_libs, tmp_path, joint_set, B, seeds):
+    """(c) BASELINE configs[2] (SMPL-like coco graph, B=256, train) and configs[4] (MANO-like, B=512, train).  No CPU
+    oracle can run these sizes (float64 needs ~140 GB for configs[2]), so the default kernel set (bf16x3 contraction on
+    the BF16 pipe, fake-vertex split, LDS-tiled basis, wave-specialised GEMM) is compared with an INDEPENDENT one (native
+    f32 MFMA, unsplit rows, row-per-wave gather, 4-wave GEMM) that test_independent_kernel_set_vs_oracle_train pins to the
+    float64 oracle at network level.  Forward: per-vertex L2.  Backward: the two runs' ReLU masks are compared bit by
+    bit -- the handful of differing elements (fp32 kinks) is counted, and the gradient tolerance is the one that count
+    explains; plus 4 eval samples of the SAME batch against the oracle."""
+    ws, xs, gs = seeds
+    ind = _child_run(tmp_path, INDEPENDENT_SET, joint_set, B, "train", ws, xs, gs)
+    hip = _hip_run(joint_set, B, "train", ws, xs, gs, tap=True)
+    tag = f"c_{joint_set}_B{B}"
     err = helpers.max_vertex_l2(hip["out"].cpu(), ind["out"])
-    _record("c_coco_B256_vertex_l2_default_vs_independent", err)
+    _record(f"{tag}_vertex_l2_default_vs_independent", err)
     assert err <= 5e-5                    # two fp32 evaluation orders of a 21-layer network, |y| ~ 3; the bar is 1e-4
     nflip, nel = 0, 0
     for k in (k for k in hip if k.startswith("mask::")):
         a = np.packbits(hip[k].cpu().numpy().reshape(-1))
         nflip += int(np.unpackbits(a ^ ind[k]).sum())
         nel += hip[k].numel()
-    _record("c_coco_B256_mask_bits_differing", {"flipped": nflip, "relu_elements": nel})
+    _record(f"{tag}_mask_bits_differing", {"flipped": nflip, "relu_elements": nel})
     assert nflip <= 4e-6 * nel, (nflip, nel)          # ~1 element per million sits within fp32 rounding of the kink
     grads_h = {k[6:]: v for k, v in hip.items() if k.startswith("grad::")}
     grads_i = {k[6:]: ind[k] for k in ind.files if k.startswith("grad::")}
     # each differing mask bit moves the upstream gradients by ~1/sqrt(rows x features) of their norm; the sum over the
     # counted flips stays below 1e-2 (measured: see gpurun_out/parity_maxima.json).  With the masks ALIGNED the same
     # kernels agree with float64 to 3e-5 (tests (a), (b)).
-    _compare_grads(grads_h, grads_i, 1e-2, "c_coco_B256_grads_default_vs_independent", True)
+    _compare_grads(grads_h, grads_i, 1e-2, f"{tag}_grads_default_vs_independent", True)
     for k in ind.files:
         if k.startswith("state::"):
             assert np.abs(hip[k].cpu().numpy() - ind[k]).max() < 1e-5, k
@@ -181,25 +224,25 @@ def test_configs2_default_vs_independent_kernel_set(hip_libs, tmp_path):
     torch.cuda.empty_cache()
     # eval slices of the same batch vs the oracle (eval-mode samples are independent)
     from pose2mesh_release_amd import meshnet
-    gL, _, _ = helpers.golden_graphs("coco")
-    net = meshnet.get_model(5, 3, gL, mano=False)
-    sd = helpers.numpy_state(net.state_dict(), 41)
+    gL, _, _ = helpers.golden_graphs(joint_set)
+    mano = joint_set == "mano"
+    net = meshnet.get_model(5, 3, gL, mano=mano)
+    sd = helpers.numpy_state(net.state_dict(), ws)
     net.load_state_dict(sd)
     net = net.cuda().eval()
-    x = helpers.meshnet_input(256, 19, seed=55)
+    x = helpers.meshnet_input(B, int(gL[-1].shape[0]), seed=xs)
     with torch.no_grad():
         big = net(x.cuda())
-    idx = [0, 85, 170, 255]
+    idx = [0, B // 3, 2 * B // 3, B - 1]
     torch.set_num_threads(ORACLE_THREADS)
-    ref, _, _ = helpers.oracle_run(sd, helpers.oracle_graphs(gL), x[idx], False, False)
+    ref, _, _ = helpers.oracle_run(sd, helpers.oracle_graphs(gL), x[idx], mano, False)
     err = helpers.max_vertex_l2(big[idx].cpu(), ref)
-    _record("c_coco_B256_eval_slices_vertex_l2", err)
+    _record(f"{tag}_eval_slices_vertex_l2", err)
     assert err <= VERTEX_TOL
 
 
 @pytest.mark.parametrize("env,fwd_bitwise", [({"P2M_CLASSES": "0"}, False), ({"P2M_PAIR_BWD": "0"}, True),
-                                             ({"P2M_BN_BWD_EPILOGUE": "1"}, True),
-                                             ({"P2M_PROJECT_COMBINE": "1"}, False)])
+                                             ({"P2M_TILE_GEMM": "1"}, False)])
 def test_algebraic_shortcuts_against_their_plain_forms(hip_libs, tmp_path, env, fwd_bitwise):
     """The default path's exact algebraic shortcuts -- classes of identical fake rows (only one representative of a run of
     identical padding rows is computed), the backward of un-pooled convs at the coarse resolution -- and the opt-in
@@ -316,14 +359,15 @@ def test_three_adam_steps_vs_oracle(hip_libs):
     assert step.opt.step_count == 3
 
 
-@pytest.mark.parametrize("joint_set", ["mano", "coco"])
+@pytest.mark.parametrize("joint_set", ["mano", "coco", "human36"])
 @pytest.mark.parametrize("with_edge", [True, False])
 def test_fused_mesh_loss_vs_reference_golden(hip_libs, joint_set, with_edge):
     """p2m_mesh_loss (perm-reverse gather + J-regression + 4 losses + gradient) against fixtures
-    made by the REAL lib/core/loss.py driven as lib/core/base.py:130-143 does; masks in the reference's shapes."""
+    made by the REAL lib/core/loss.py driven as lib/core/base.py:130-143 does; masks in the reference's shapes.
+    human36 runs with the reference's own regressor file (J_regressor_h36m_correct.npy, 107 nnz, embedded in the fixture)."""
     from pose2mesh_release_amd import loss as L
     z = helpers.golden(f"loss_{joint_set}.npz")
-    c = helpers.loss_case(joint_set)
+    c = helpers.loss_case(joint_set, jreg=helpers.golden_regressor() if joint_set == "human36" else None)
     tag = "edge" if with_edge else "noedge"
     fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy(), w_normal=1e-1,
                             w_edge=20.0 if with_edge else 0.0, w_joint=1e-3)

@@ -135,12 +135,13 @@ import demo_oracle as do
 import loss_oracle as lo
 
 
-@pytest.mark.parametrize("joint_set", ["mano", "coco"])
+@pytest.mark.parametrize("joint_set", ["mano", "coco", "human36"])
 @pytest.mark.parametrize("with_edge", [True, False])
 def test_loss_oracle_vs_reference_golden(joint_set, with_edge):
-    """oracle/loss_oracle.py against lib/core/loss.py driven as lib/core/base.py:130-143 does (values + gradients)."""
+    """oracle/loss_oracle.py against lib/core/loss.py driven as lib/core/base.py:130-143 does (values + gradients);
+    human36 with the reference's own J_regressor_h36m_correct.npy (embedded in the fixture)."""
     z = helpers.golden(f"loss_{joint_set}.npz")
-    c = helpers.loss_case(joint_set)
+    c = helpers.loss_case(joint_set, jreg=helpers.golden_regressor() if joint_set == "human36" else None)
     tag = "edge" if with_edge else "noedge"
     cam = c["cam_mesh"].clone().requires_grad_(True)
     lift = c["lift_pose"].clone().requires_grad_(True)
@@ -173,7 +174,7 @@ def test_demo_preprocessing_oracle_vs_reference_golden():
     with torch.no_grad():
         cam_mesh, pose3d = mo.flat_forward(sd, helpers.oracle_graphs(gL), torch.from_numpy(x[None]), False, False)
     assert helpers.max_vertex_l2(cam_mesh, z["cam_mesh"]) < 5e-6
-    mesh, joints = do.demo_mesh_epilogue(cam_mesh.numpy(), rev, 6890, synth.synthetic_regressor(17, 6890))
+    mesh, joints = do.demo_mesh_epilogue(cam_mesh.numpy(), rev, 6890, helpers.golden_regressor("demo_h36m.npz"))
     assert mesh.shape == (1, 6890, 3) and np.abs(mesh - z["mesh"]).max() < 5e-6
     assert np.abs(joints - z["joints"]).max() < 5e-6
 
