@@ -82,8 +82,14 @@ class BucketedAllReduce:
         self._handles = []
         self._seen = 0
         self._streams = [set() for _ in self.buckets]      # streams that carry gradient-writing kernels of each bucket
+        self._done = set()
 
     def _arrived(self, i):
+        # once per parameter and step: torch fires the post-accumulate hook of a parameter even when the backward
+        # returned None for it (in-place accumulation), i.e. AFTER notify() has already reported it
+        if i in self._done:
+            return
+        self._done.add(i)
         b = self._bucket_of[i]
         self._pending[b] -= 1
         self._seen += 1

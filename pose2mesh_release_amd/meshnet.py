@@ -445,9 +445,15 @@ class _MeshNetFn(torch.autograd.Function):
                     Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
                     dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1)
                 nco = K_CHEB * L.Fout
-                grads[P[f"cl.{L.ci}.weight"]] = dW32[:nco].view(K_CHEB, L.Fout, L.Fin).permute(1, 2, 0) \
-                    .reshape(L.Fout, L.Fin * K_CHEB).contiguous()
-                grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
+                dWn = dW32[:nco].view(K_CHEB, L.Fout, L.Fin).permute(1, 2, 0).reshape(L.Fout, L.Fin * K_CHEB)
+                tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                if tg is not None:
+                    tg[0].add_(dWn)
+                    tg[1].add_(db32[:L.Fout])
+                    ready(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                else:
+                    grads[P[f"cl.{L.ci}.weight"]] = dWn.contiguous()
+                    grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 Wpt, Wptx = wc.get((L.ci, "narrow_bwd"), Wl, lambda: _transposed_operands(Wp))
                 if gph.classes:
@@ -586,8 +592,13 @@ class _MeshNetFn(torch.autograd.Function):
                 if T1 is None:          # forward was fused: rebuild the (small) basis for this odd-shaped layer
                     T1, T2 = ops.cheb_basis_fwd(gph, X, B, L.Fin, x_shift)
                 Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
-                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB)
-                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
+                tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                if tg is not None:
+                    ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, dW=tg[0], db=tg[1])
+                    ready(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
+                else:
+                    dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB)
+                    grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb
                 d, _ = ops.gemm_planes([gy], L.Fout, 0, W2, None, M, K_CHEB * L.Fin, K_CHEB, False)
                 dX = ops.cheb_basis_bwd(gph, d[0], d[1], d[2], G if fuse_res else None, B, L.Fin, x_shift)
@@ -741,8 +752,8 @@ class Pose2Mesh(nn.Module):
 
     def set_grad_sink(self, sink):
         """sink(list of parameters): called from the backward, on the stream that just received the kernels writing those
-        parameters' gradients, when the gradients are accumulated in place (accumulate_grads_in_place) - autograd never
-        sees them, so hooks cannot report them.  dist.BucketedAllReduce.notify is the intended sink: the gradient
+        parameters' gradients, when the gradients are accumulated in place (accumulate_grads_in_place) - autograd gets
+        None for them, and its post-accumulate hooks only fire once the whole backward has returned.  dist.BucketedAllReduce.notify is the intended sink: the gradient
         all-reduce of a finished bucket then starts under the backward of the coarser levels."""
         self._grad_sink = sink
         return self

@@ -38,9 +38,10 @@ for m in net.modules():
         m.p = 0.0
 opt = optim.FlatAdam(net.parameters(), lr=1e-3)
 # the bench's configuration: MeshNet gradients accumulate in place and are reported to the reducer per layer from inside
-# the backward (no autograd hooks fire for them); small buckets so that several of them lie inside the MeshNet slice
+# the backward (autograd's hooks only fire once the whole backward has returned); small buckets so that several of them
+# lie inside the MeshNet slice
 net.pose2mesh.accumulate_grads_in_place(True)
-red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=4 << 20)
+red = pd.BucketedAllReduce(opt.params, opt.offsets, opt.flat_grad, bucket_bytes=1 << 20)
 net.pose2mesh.set_grad_sink(red.notify)
 fused = L.FusedMeshLoss(c["faces"], c["perm_reverse"], c["J_regressor"].numpy())
 stock = L.get_loss(c["faces"])

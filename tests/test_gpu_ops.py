@@ -386,9 +386,14 @@ def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
 
 @pytest.mark.parametrize("V,Fin,Fout,B,fuse", [(1472, 128, 64, 3, True), (736, 256, 128, 5, False),
                                                (2944, 64, 256, 2, True)])
-def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, V, Fin, Fout, B, fuse):
+@pytest.mark.parametrize("tile_gemm", [False, True])
+def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, monkeypatch, tile_gemm, V, Fin, Fout, B, fuse):
     """Backward of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"): S L g / S L2 g from the
-    paired tile plan, row sets 3 / 4, against the fine-resolution backward followed by the pair-sum."""
+    paired tile plan, row sets 3 / 4, against the fine-resolution backward followed by the pair-sum.  tile_gemm: the
+    real rows through p2m_cheb_tile_gemm (plan 2: the planes are formed inside the contraction; opt-in P2M_TILE_GEMM=1)."""
+    if tile_gemm and arith != "bf16x3":
+        pytest.skip("the basis-inside-the-contraction kernel is a bf16x3 kernel")
+    monkeypatch.setattr(ops, "TILE_GEMM", tile_gemm)
     L = _band_graph(V, 31 + V)
     g = ops.DeviceGraph(L, "cuda:0")
     assert g.plan_tiles[2] > 0 and g.pair and g.n_pair_real + g.n_pair_fake == V // 2 and g.n_pair_fake > 0
@@ -575,6 +580,7 @@ def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkey
     (same entry order, same fmaf chain), BatchNorm statistics through their own finalize, addend, fused activation.
     B is deliberately not a multiple of the 4 samples a block tile holds."""
     monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
+    monkeypatch.setattr(ops, "TILE_GEMM", True)          # opt-in path (P2M_TILE_GEMM=1)
     L = _band_graph(V, 7 + V + shift)
     g = ops.DeviceGraph(L, "cuda:0")
     assert g.plan_tiles[shift] > 0 and ops.tile_gemm_ok(g, shift, Fin, Fout)

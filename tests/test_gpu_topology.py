@@ -105,7 +105,8 @@ def test_high_degree_vertices_take_the_no_plan_paths_inside_the_network(hip_libs
     def expect(info):
         split_lv = [i for i, s in enumerate(info["split"]) if s]
         assert split_lv, info
-        # the finest levels carry the poles: no tile plan there -> row kernels, no paired operator, no classes
-        assert any(info["plans"][i] == (0, 0, 0) for i in split_lv), info
-        assert not any(info["classes"]), info
+        # the finest level carries the poles: their merged rows (145 entries) exceed the tile caps, so that level has no
+        # tile plan for its own resolution and no paired operator -> row kernels, fine-resolution backward, no classes
+        assert any(info["plans"][i][0] == 0 and info["plans"][i][2] == 0 for i in split_lv), str(info["plans"])
+        assert not any(info["classes"]), str(info["classes"])
     _run("uv_sphere", 3, expect)
