@@ -13,8 +13,8 @@
  *  - all matrices fp32 row-major; a "row" is one (sample, vertex) pair, r = b*V + v;
  *  - return 0 on success, negative p2m_status on error; p2m_last_error_string() has the detail;
  *    nothing throws across the boundary;
- *  - thread-safe: no mutable global state besides the thread-local error string; kernel-variant knobs
- *    (P2M_GEMM_WS, P2M_TN_WS, P2M_GEMM_KB, P2M_BASIS_TILED) are read once from the environment and never change;
+ *  - thread-safe: no mutable global state besides the thread-local error string; the one kernel-variant knob of the
+ *    library (P2M_BASIS_TILED) is read once from the environment and never changes;
  *  - `shift` arguments implement the reference's nearest x2 vertex un-pooling
  *    (lib/models/meshnet.py:71-78) *virtually*: a tensor stored at V/2 vertices is read as if it
  *    had V vertices through row index r>>1 (valid because V is even and r = b*V+v).
@@ -241,15 +241,6 @@ int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float*
                          int32_t N, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
                          void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
-/* The same contraction when C is the gradient flowing into a BatchNorm + ReLU layer (a backward step's dX): bn_y = that
- * layer's raw input [rows of C][N], bn_co = its coefficients [4][N] (mean, invstd, scale, shift: the layout
- * p2m_bn_finalize* writes), bn_part = [B * p2m_rows_tiles_per_sample][2][N].  The epilogue also emits the partials
- * p2m_bn_bwd_reduce would (sum g, sum g*yhat with g = C masked by the ReLU) -- that separate pass over C and bn_y is
- * then skipped; p2m_bn_bwd_finalize consumes bn_part.                                                              */
-int p2m_gemm_planes_rows_bnbwd(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
-                               const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
-                               const float* Bm, const void* Bsplit, const float* addend, float* C, int32_t N,
-                               const float* bn_y, const float* bn_co, float* bn_part, void* stream);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
@@ -298,25 +289,6 @@ int p2m_bn_finalize_tiles(p2m_graph_t g, int32_t plan, const float* stats_real, 
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                           int32_t N, void* stream);
 
-/* ---- project-then-combine form of an un-pooled conv -----------------------------------------------------------
- * A conv whose input was un-pooled x2 sees X_fine[r] = X[r >> 1] (meshnet.py:71-78,111), so
- *     y = [X_fine | L X_fine | L2 X_fine] W = Z0[r >> 1] + sum_j a_j Z1[col_j >> 1] + b_j Z2[col_j >> 1],
- *     Z = X [W0 | W1 | W2]:   [B * V/2, 3 N], ONE contraction over the coarse rows (p2m_gemm_planes[_rows], K = Fin),
- * and the sparse stage gathers N-wide rows of Z1 | Z2 (LDS-staged, the level's in_shift = 1 tile plan) instead of
- * writing two Fin-wide planes.  p2m_cheb_project_combine computes the real rows of Y [B*V, N] (N % 64 == 0), optionally
- * with the fused eval-mode BatchNorm + ReLU, or with BatchNorm partials stats[B * ntiles(plan 1)][2][N] for
- * p2m_bn_finalize_combine; _fake computes the fake rows (row set 2: y = Z0[p] + a Z1[p] + b Z2[p], p the parent),
- * whose partials are p2m_gemm_planes_rows-style tiles (no classes) or p2m_stats_rows_w (classes).                    */
-int p2m_cheb_project_combine(p2m_graph_t g, const float* Z, const float* bias, const float* act_scale,
-                             const float* act_shift, int32_t act_relu, float* Y, float* stats, int32_t B, int32_t N,
-                             void* stream);
-int p2m_cheb_project_combine_fake(p2m_graph_t g, const float* Z, const float* bias, float* Y, int32_t B, int32_t N,
-                                  void* stream);
-int p2m_bn_finalize_combine(p2m_graph_t g, const float* stats_real, const float* stats_fake, int32_t B,
-                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                            int32_t N, void* stream);
-
 /* ---- classes of identical fake rows ------------------------------------------------------------------------
  * Inside the coarse-to-fine stack every descendant of a fake vertex is fake, isolated and produced by the same per-row
  * arithmetic from the same un-pooled value (meshnet.py:71-78: both children copy the parent): in the tree order the
@@ -338,23 +310,6 @@ int p2m_graph_class_info(p2m_graph_t g, int32_t counts[3] /* has classes, repres
 int p2m_stats_rows_w(p2m_graph_t g, const float* y, int32_t B, int32_t N, float* stats, void* stream);
 /* out[r] = sum of in over the class of r (representatives), in[r] (real vertices), 0 (holes); in, out: [B*V, F] */
 int p2m_class_reduce(p2m_graph_t g, const float* in, float* out, int32_t B, int32_t F, void* stream);
-
-/* ---- fused Chebyshev convolution: recurrence + contraction in ONE persistent kernel -------------
- *   C[r, :] = [ A[r] | (L A)[r] | (L2 A)[r] ] * Bm (+ bias) (+ addend[r]),   r = b*V + v, M = B*V rows
- * A: [B*(V>>a_shift), Ka] (Ka % 32 == 0), Bm: [3*Ka, N] (N in {64,128,256}), C: [M, N] or, with
- * pair_out, [M/2, N] holding the sum of the two children of every coarse vertex (un-pool backward).
- * stats (optional, excludes pair_out): BatchNorm partials per T-row tile, T = p2m_fused_stats_tile_rows(N),
- *   [ceil(M/T) + 4][2][N] (the last tile may write up to 3 phantom rows);
- * E1/E2 (optional, a_shift == 0): the gathered planes L A and L2 A, [M, Ka] each, written as a by-product
- * (the backward uses them for dW = X^T [g|Lg|L2g]).
- * forward: A = x, Bm = Wt  (cheby_graph_conv.py:16-37).  backward: A = dL/dy, Bm = W3 (L symmetric).
- * Bm must be given FRAGMENT-MAJOR (p2m_frag_pack of the row-major [3*Ka, N] matrix): the MFMA waves then fetch
- * the B operands of 4 k-steps with one coalesced 16-byte load per lane.                                       */
-int p2m_frag_pack(const float* Bm, float* Bpk, int32_t Ktot, int32_t N, void* stream);
-int p2m_cheb_gemm_fused(p2m_graph_t g, const float* A, int32_t Ka, int32_t a_shift, const float* Bm,
-                        const float* bias, const float* addend, float* C, int32_t N, int32_t pair_out,
-                        float* stats, float* E1, float* E2, int32_t B, void* stream);
-int32_t p2m_fused_stats_tile_rows(int32_t N);   /* rows per BatchNorm partial of the fused kernel (64 for N=128, else 32) */
 
 /* ---- composite: one Chebyshev graph convolution (cheby_graph_conv.py:5-40, K=3) ------------
  * Y = [X|L X|L2 X] Wt + bias, BatchNorm partials in `stats` (may be NULL).  T1/T2 are caller

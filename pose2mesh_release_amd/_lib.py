@@ -34,8 +34,6 @@ HIP_SYMBOLS = {
     "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "p2m_graph_split_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2), _c.POINTER(_f32 * 2)]),
     "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "p2m_gemm_planes_rows_bnbwd": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                              _i32, _vp, _vp, _vp, _vp]),
     "p2m_graph_pair_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2)]),
     "p2m_graph_plan_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_cheb_basis_pair": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -51,10 +49,6 @@ HIP_SYMBOLS = {
                                         _vp, _vp, _vp, _i32, _vp]),
     "p2m_bn_finalize_split": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
                                          _vp]),
-    "p2m_cheb_project_combine": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_cheb_project_combine_fake": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_bn_finalize_combine": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
-                                           _vp]),
     "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
     "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32,
                                       _i32, _vp]),
@@ -65,10 +59,6 @@ HIP_SYMBOLS = {
     "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_stats_rows_w": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2m_class_reduce": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_cheb_gemm_fused": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32,
-                                       _vp]),
-    "p2m_frag_pack": (_c.c_int, [_vp, _vp, _i32, _i32, _vp]),
-    "p2m_fused_stats_tile_rows": (_i32, [_i32]),
     "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i64, _vp, _vp, _vp, _i32, _vp]),
     "p2m_weight_split_elems": (_i64, [_i32, _i32]),

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-HIP_SOURCES = ["capi.hip", "basis.hip", "gemm.hip", "bn.hip", "optim.hip", "fused.hip", "loss.hip", "chebtile.hip"]
+HIP_SOURCES = ["capi.hip", "basis.hip", "gemm.hip", "bn.hip", "optim.hip", "loss.hip", "chebtile.hip"]
 HIP_HEADERS = ["p2m_common.h", "p2m_split.h", os.path.join("..", "..", "include", "p2m.h")]
 HIP_LIB = os.path.join(LIBDIR, "libp2m_hip.so")
 HOST_LIB = os.path.join(LIBDIR, "libp2m_host.so")

@@ -19,23 +19,14 @@
 
 namespace p2m {
 
-#ifndef P2M_BASIS_ROWS
-#define P2M_BASIS_ROWS 4           // rows per block (one per wave): small tiles keep an XCD's working window in its L2
-                                   // (measured B=256,V=11776,F=128: bwd 1.5 -> 2.6 TB/s going from 16 to 4)
-#endif
-constexpr int ROWS_PER_BLOCK = P2M_BASIS_ROWS;
+constexpr int ROWS_PER_BLOCK = 4;   // rows per block (one per wave): small tiles keep an XCD's working window in its L2
+                                    // (measured B=256,V=11776,F=128: bwd 1.5 -> 2.6 TB/s going from 16 to 4)
 
-// P2M_BASIS_TILED=0 falls back to the row-per-wave gather kernel for the real rows of split levels
-// samples a tile block walks (amortises the tile tables; P2M_BASIS_SPB for probe runs, read once)
-static int basis_spb() {
-  static const int v = [] {
-    const char* e = getenv("P2M_BASIS_SPB");
-    const int n = e ? atoi(e) : 8;
-    return n >= 1 && n <= 256 ? n : 8;
-  }();
-  return v;
-}
+// samples a tile block walks (amortises the tile tables; measured 8 -> 4 -> 2 -> 1: 3 198 -> 3 112 -> 2 977 -> 2 631 GB/s)
+static int basis_spb() { return 8; }
 
+// P2M_BASIS_TILED=0 falls back to the row-per-wave gather kernel for the real rows of split levels (the independent
+// kernel set of the parity tests)
 static bool basis_tiled() {
   static int v = [] { const char* e = getenv("P2M_BASIS_TILED"); return e ? atoi(e) : 1; }();
   return v != 0;
@@ -293,7 +284,6 @@ __global__ __launch_bounds__(256) void k_expand_small(Graph g, const float* __re
 // row contributes are staged once per (tile, sample) instead of being fetched once per referencing row (~21x through
 // L1/L2, a 128-byte line each): 537 -> ~170 us per launch at the finest level.  Entry order and fmaf chains are
 // those of the row kernels: bitwise the same results.
-#if P2M_TILE_RMAX == 32
 constexpr int SMALL_SPB = 8;
 template <int NC>
 __global__ __launch_bounds__(256) void k_combine_small_tile(TilePlan pl, const int* __restrict__ real_ids, int V,
@@ -394,7 +384,6 @@ __global__ __launch_bounds__(256) void k_expand_small_tile(TilePlan pl, const in
   }
   for (int c = 3 * NC; c < lde; c++) e[c] = 0.f;
 }
-#endif
 
 }  // namespace p2m
 
@@ -410,7 +399,6 @@ static int combine_small_launch(p2m_graph_t gh, const float* P, int32_t ldp, int
   if (tot == 0) return P2M_OK;
   hipStream_t s = (hipStream_t)stream;
   int skip_real = 0;
-#if P2M_TILE_RMAX == 32
   // rows with neighbours through the tile plan (when the level has one); the row kernel then covers the rest
   const TilePlan& pl = g.plan[0];
   if (pl.ntiles > 0 && basis_tiled() && nc == 3) {
@@ -419,7 +407,6 @@ static int combine_small_launch(p2m_graph_t gh, const float* P, int32_t ldp, int
     if (real_only) return check_launch("cheb_combine_small(tiled)");
     skip_real = 1;
   }
-#endif
 #define P2M_COMBINE(NCv) hipLaunchKernelGGL(k_combine_small<NCv>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, P, ldp, bias, \
                                             Y, B, ids, nset, out_index, out_rows, scale, skip_real)
   switch (nc) {
@@ -457,14 +444,12 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
   const long tot = (long)B * g.V;
   hipStream_t s = (hipStream_t)stream;
   int skip_real = 0;
-#if P2M_TILE_RMAX == 32
   const TilePlan& pl = g.plan[0];
   if (pl.ntiles > 0 && basis_tiled() && nc == 3) {
     hipLaunchKernelGGL(k_expand_small_tile<3>, dim3(pl.ntiles * cdiv(B, SMALL_SPB)), dim3(256), 0, s, pl, g.real_ids, g.V,
                        G, E, lde, B);
     skip_real = 1;
   }
-#endif
   switch (nc) {
     case 1: hipLaunchKernelGGL(k_expand_small<1>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
     case 2: hipLaunchKernelGGL(k_expand_small<2>, dim3(cdiv(tot, 256)), dim3(256), 0, s, g, G, E, lde, B, skip_real); break;
@@ -488,11 +473,8 @@ extern "C" int p2m_cheb_expand_small(p2m_graph_t gh, const float* G, int32_t nc,
 namespace p2m {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#ifndef P2M_TILE_MINBLK
-#define P2M_TILE_MINBLK 2      // resident blocks per CU the register budget is sized for (probe builds: 3 with small tiles)
-#endif
 template <int LPR>
-__global__ __launch_bounds__(512, P2M_TILE_MINBLK) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
+__global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
                                                         float* __restrict__ T1, float* __restrict__ T2, int B, int F,
                                                         long x_rows, int nset, int spb) {
   constexpr int NT = 512;
@@ -587,182 +569,6 @@ __global__ __launch_bounds__(512, P2M_TILE_MINBLK) void k_basis_tile(TilePlan pl
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Project-then-combine form of a conv whose input was un-pooled x2 (X_fine[r] = X[r >> 1], meshnet.py:71-78,111):
-//     y = [X_fine | L X_fine | L2 X_fine] W = Z0[r >> 1] + sum_j a_j Z1[col_j >> 1] + b_j Z2[col_j >> 1],
-//     Z = X [W0 | W1 | W2]   -- ONE contraction over the V/2 coarse rows (3 Fout columns),
-// so the dense work runs at the coarse resolution and the sparse stage gathers Fout-wide rows of Z1 | Z2 instead of
-// producing 2 Fin-wide planes.  Same tile plan (in_shift = 1), same staging scheme as k_basis_tile with TWO staged
-// arrays (the Z1 and Z2 slices of the union rows, 64 features each: 2 x 30 KB); a lane group owns one output row.
-// Optional fused eval-mode BatchNorm + ReLU (the two roundings of the separate pass), optional BatchNorm partials per
-// (sample, tile): (sum y, sum (y - tile mean)^2), weight = the tile's row count (TilePlan::tile_cnt).
-// ---------------------------------------------------------------------------------------------
-#if P2M_TILE_RMAX <= 32          // (probe builds with larger tiles leave the opt-in combine kernel out)
-template <bool STATS>
-__global__ __launch_bounds__(512, 2) void k_combine_tile(TilePlan pl, const int* __restrict__ real_ids,
-                                                          const float* __restrict__ Z, const float* __restrict__ bias,
-                                                          const float* __restrict__ act_scale,
-                                                          const float* __restrict__ act_shift, int act_relu,
-                                                          float* __restrict__ Y, float* __restrict__ stats, int B, int N,
-                                                          int V, int spb) {
-  constexpr int NT = 512, LPR = 16, FB = 64;
-  constexpr int RPI = NT / LPR;               // 32 lane groups: one output row each (TILE_RMAX <= 32)
-  constexpr int NPF = (TILE_UCAP + RPI - 1) / RPI;
-  static_assert(TILE_RMAX <= RPI, "one lane group per tile row");
-  __shared__ __attribute__((aligned(16))) float xs1[TILE_UCAP * FB];
-  __shared__ __attribute__((aligned(16))) float xs2[TILE_UCAP * FB];
-  __shared__ __attribute__((aligned(16))) f32x4v ents[TILE_ECAP];
-  __shared__ int rowoff[TILE_RMAX + 1];
-  __shared__ __attribute__((aligned(16))) float red[8 * FB];
-
-  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int nsg = (B + spb - 1) / spb;
-  const int nslice = N / FB;
-  if (lid >= pl.ntiles * nsg * nslice) return;
-  const int tile = lid % pl.ntiles;
-  const int sgrp = (lid / pl.ntiles) % nsg;
-  const int slice = lid / (pl.ntiles * nsg);
-  const int t = threadIdx.x;
-  const int grp = t / LPR;
-  const int lf = (t % LPR) * 4;
-  const int c4 = slice * FB + lf;             // first of this lane's 4 output columns
-  const int ldz = 3 * N;
-  const long z_rows = V >> 1;
-  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
-  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
-  const int e0 = pl.erow[r0], nE = pl.erow[r0 + R] - e0;
-  for (int i = t; i < nE; i += NT) ents[i] = *reinterpret_cast<const f32x4v*>(&pl.ent[e0 + i]);
-  if (t <= R) rowoff[t] = pl.erow[r0 + t] - e0;
-  long zoff[NPF];
-#pragma unroll
-  for (int q = 0; q < NPF; q++) {
-    const int u = grp + q * RPI;
-    zoff[q] = (long)pl.ucol[u0 + (u < U ? u : U - 1)] * ldz + N + c4;   // the Z1 slice; Z2 is N floats further
-  }
-  const bool has_row = grp < R;
-  const int v = has_row ? real_ids[r0 + grp] : 0;
-  f32x4v bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = bv;
-  if (bias) bv = *reinterpret_cast<const f32x4v*>(bias + c4);
-  if (act_scale) {
-    sc = *reinterpret_cast<const f32x4v*>(act_scale + c4);
-    sh = *reinterpret_cast<const f32x4v*>(act_shift + c4);
-  }
-
-  const int b0 = sgrp * spb;
-  int b1 = b0 + spb;
-  if (b1 > B) b1 = B;
-  f32x4v pf1[NPF], pf2[NPF], z0;
-  auto issue = [&](int b) {
-    const float* Zb = Z + (long)b * z_rows * ldz;
-#pragma unroll
-    for (int q = 0; q < NPF; q++) {
-      pf1[q] = *reinterpret_cast<const f32x4v*>(Zb + zoff[q]);
-      pf2[q] = *reinterpret_cast<const f32x4v*>(Zb + zoff[q] + N);
-    }
-    z0 = *reinterpret_cast<const f32x4v*>(Zb + (long)(v >> 1) * ldz + c4);
-  };
-  issue(b0);
-  for (int b = b0; b < b1; b++) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NPF; q++) {
-      const int u = grp + q * RPI;
-      if (u < U) {
-        *reinterpret_cast<f32x4v*>(&xs1[u * FB + lf]) = pf1[q];
-        *reinterpret_cast<f32x4v*>(&xs2[u * FB + lf]) = pf2[q];
-      }
-    }
-    f32x4v acc = z0 + bv;
-    __syncthreads();
-    issue(b + 1 < b1 ? b + 1 : b);
-    if (has_row) {
-      const int s = rowoff[grp], e = rowoff[grp + 1];
-      for (int j = s; j < e; j++) {
-        const f32x4v en = ents[j];
-        const int o = __float_as_int(en[2]) * FB + lf;
-        const f32x4v x1 = *reinterpret_cast<const f32x4v*>(&xs1[o]);
-        const f32x4v x2 = *reinterpret_cast<const f32x4v*>(&xs2[o]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) acc[c] = fmaf(en[1], x2[c], fmaf(en[0], x1[c], acc[c]));
-      }
-      f32x4v out = acc;
-      if (act_scale) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) out[c] = fmaf(out[c], sc[c], sh[c]);
-      }
-      if (act_relu) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) out[c] = fmaxf(out[c], 0.f);
-      }
-      *reinterpret_cast<f32x4v*>(Y + ((long)b * V + v) * N + c4) = out;
-    }
-    if (STATS) {
-      // column sums over the tile's rows: 4 lane groups per wave (lanes l, l+16, l+32, l+48), then the 8 waves via LDS
-      f32x4v s1 = has_row ? acc : f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        s1[c] += __shfl_xor(s1[c], 16);
-        s1[c] += __shfl_xor(s1[c], 32);
-      }
-      const int wave = t >> 6;
-      if ((t & 63) < LPR) *reinterpret_cast<f32x4v*>(&red[wave * FB + lf]) = s1;
-      __syncthreads();
-      f32x4v tot = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int w = 0; w < 8; w++) tot += *reinterpret_cast<const f32x4v*>(&red[w * FB + lf]);
-      const float inv = 1.f / (float)R;
-      f32x4v m2 = {0.f, 0.f, 0.f, 0.f};
-      if (has_row) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const float d = acc[c] - tot[c] * inv;
-          m2[c] = d * d;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        m2[c] += __shfl_xor(m2[c], 16);
-        m2[c] += __shfl_xor(m2[c], 32);
-      }
-      __syncthreads();
-      if ((t & 63) < LPR) *reinterpret_cast<f32x4v*>(&red[wave * FB + lf]) = m2;
-      __syncthreads();
-      if (t < LPR) {
-        f32x4v q2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < 8; w++) q2 += *reinterpret_cast<const f32x4v*>(&red[w * FB + lf]);
-        float* st = stats + ((long)b * pl.ntiles + tile) * 2 * N;
-        *reinterpret_cast<f32x4v*>(st + c4) = tot;
-        *reinterpret_cast<f32x4v*>(st + N + c4) = q2;
-      }
-    }
-  }
-}
-
-#endif
-
-// the fake rows of the same conv: isolated, so y = Z0[p] + a Z1[p] + b Z2[p] (+ bias), p = the parent row
-__global__ __launch_bounds__(256) void k_combine_fake(const int* __restrict__ ids, int n, const float* __restrict__ Z,
-                                                       const float* __restrict__ bias, float fa, float fb,
-                                                       float* __restrict__ Y, int B, int N, int V) {
-  const int N4 = N >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * n * N4) return;
-  const int c4 = (int)(idx % N4) * 4;
-  const long bi = idx / N4;
-  const int i = (int)(bi % n), b = (int)(bi / n);
-  const int v = ids[i];
-  const float* z = Z + ((long)b * (V >> 1) + (v >> 1)) * 3 * N + c4;
-  const f32x4v z0 = *reinterpret_cast<const f32x4v*>(z);
-  const f32x4v z1 = *reinterpret_cast<const f32x4v*>(z + N);
-  const f32x4v z2 = *reinterpret_cast<const f32x4v*>(z + 2 * N);
-  f32x4v o = z0;
-  if (bias) o += *reinterpret_cast<const f32x4v*>(bias + c4);
-#pragma unroll
-  for (int c = 0; c < 4; c++) o[c] = fmaf(fb, z2[c], fmaf(fa, z1[c], o[c]));
-  *reinterpret_cast<f32x4v*>(Y + ((long)b * V + v) * N + c4) = o;
-}
-
 }  // namespace p2m
 
 static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
@@ -794,45 +600,6 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
       return P2M_ERR_INVALID;
   }
   return check_launch("cheb_basis_fwd");
-}
-
-extern "C" int p2m_cheb_project_combine(p2m_graph_t gh, const float* Z, const float* bias, const float* act_scale,
-                                        const float* act_shift, int32_t act_relu, float* Y, float* stats,
-                                        int32_t B, int32_t N, void* stream) {
-  P2M_CHECK_ARG(gh && Z && Y && N > 0 && N % 64 == 0, "null pointer, or N not a multiple of 64");
-  P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
-  P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
-  const Graph& g = *reinterpret_cast<const Graph*>(gh);
-  const TilePlan& pl = g.plan[1];
-  P2M_CHECK_ARG(pl.ntiles > 0 && !(g.V & 1), "this level has no in_shift = 1 tile plan (p2m_graph_plan_info)");
-  if (B <= 0) return P2M_OK;
-#if P2M_TILE_RMAX > 32
-  set_error("p2m_cheb_project_combine: not built (tiles of more than 32 rows)");
-  return P2M_ERR_INVALID;
-#else
-  hipStream_t s = (hipStream_t)stream;
-  const int spb = 8;
-  const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (N / 64), 8) * 8);
-  if (stats)
-    hipLaunchKernelGGL(k_combine_tile<true>, grid, dim3(512), 0, s, pl, g.real_ids, Z, bias, act_scale, act_shift,
-                       act_relu, Y, stats, B, N, g.V, spb);
-  else
-    hipLaunchKernelGGL(k_combine_tile<false>, grid, dim3(512), 0, s, pl, g.real_ids, Z, bias, act_scale, act_shift,
-                       act_relu, Y, stats, B, N, g.V, spb);
-  return check_launch("cheb_project_combine");
-#endif
-}
-
-extern "C" int p2m_cheb_project_combine_fake(p2m_graph_t gh, const float* Z, const float* bias, float* Y, int32_t B,
-                                             int32_t N, void* stream) {
-  P2M_CHECK_ARG(gh && Z && Y && N > 0 && N % 4 == 0, "null pointer, or N not a multiple of 4");
-  const Graph& g = *reinterpret_cast<const Graph*>(gh);
-  P2M_CHECK_ARG(!(g.V & 1), "the un-pooled form needs an even vertex count");
-  if (B <= 0 || g.n_fake == 0) return P2M_OK;
-  const long tot = (long)B * g.n_fake * (N / 4);
-  hipLaunchKernelGGL(k_combine_fake, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, g.fake_ids, g.n_fake, Z,
-                     bias, g.fake_a, g.fake_b, Y, B, N, g.V);
-  return check_launch("cheb_project_combine_fake");
 }
 
 extern "C" int p2m_cheb_basis_pair(p2m_graph_t gh, const float* G, float* P1c, float* P2c, int32_t B, int32_t F,

@@ -916,21 +916,6 @@ extern "C" int p2m_bn_finalize_split(p2m_graph_t gh, const float* stats_real, co
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
 }
 
-// the same when the real-vertex partials come from p2m_cheb_project_combine: one tile of the in_shift = 1 plan each
-extern "C" int p2m_bn_finalize_combine(p2m_graph_t gh, const float* stats_real, const float* stats_fake, int32_t B,
-                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                       float momentum, float eps, float* mean, float* invstd, float* scale,
-                                       float* shift, int32_t N, void* stream) {
-  P2M_CHECK_ARG(gh, "null graph");
-  const Graph& g = *reinterpret_cast<const Graph*>(gh);
-  P2M_CHECK_ARG(g.plan[1].ntiles > 0, "this level has no in_shift = 1 tile plan");
-  const int tile_rows = p2m_stats_tile_rows();
-  const int rows_fake = g.w ? g.n_fake_all : g.n_fake;
-  return finalize_rows(stats_real, g.plan[1].ntiles, g.n_real, g.plan[1].tile_cnt, g.n_fake > 0 ? stats_fake : nullptr,
-                       cdiv(g.n_fake, tile_rows), rows_fake, g.w ? g.fake_tile_w : nullptr, B, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, stream);
-}
-
 // the same when the real-vertex partials come from p2m_cheb_tile_gemm: one (sum, M2) pair per (sample, tile) of the given
 // tile plan of the level (0: level input, 1: un-pooled input), weight = the tile's row count
 extern "C" int p2m_bn_finalize_tiles(p2m_graph_t gh, int32_t plan, const float* stats_real, const float* stats_fake,

@@ -28,8 +28,6 @@
 // LDS: 80 640 (A image) + 61 440 (union rows) + 15 872 (entries, rows padded to 4) + tables = 158.5 KB -> one block per CU:
 // 4 MFMA waves + 8 producer waves (two per SIMD: the gather is a chain of dependent LDS reads, a second wave fills its
 // latencies) for N <= 128, 4 + 4 for N = 256 (the 128-register accumulator needs the 256-register budget).
-#include <cstdlib>
-
 #include "p2m_split.h"
 
 namespace p2m {
@@ -67,8 +65,6 @@ struct TileGemmArgs {
   float* E2;
   long x_rows, a0_rows, c_rows;
   int act_relu, a0_shift, B, Ka, N, Npad, nset, gpb;
-  int debug;                   // probe runs only (P2M_TILE_GEMM_DEBUG): 1 no gather, 2 no MFMAs, 4 no split, 8 no C stores,
-                               // 16 no B loads, 32 no image stores, 64 no xs stores, 128 no union loads
 };
 
 // TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
@@ -207,7 +203,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
         const int i = ri[ps];
         const int e = rowoff[i + 1];
-        for (int j = (g.debug & 1) ? e : rowoff[i]; j < e; j += 4) {
+        for (int j = rowoff[i]; j < e; j += 4) {
           f32x4 en[4], x[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) en[k] = ents[j + k];
@@ -231,24 +227,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
             __builtin_nontemporal_store(t2, reinterpret_cast<f32x4*>(g.E2 + o));
           }
         }
-        if (g.debug & 4) {
-#pragma unroll
-          for (int sl = 0; sl < 3; sl++) {
-            sp[ps][0][sl] = u32x2{__float_as_uint(p0[ps][0]), __float_as_uint(p0[ps][sl])};
-            sp[ps][1][sl] = u32x2{__float_as_uint(t1[0]), __float_as_uint(t1[sl])};
-            sp[ps][2][sl] = u32x2{__float_as_uint(t2[0]), __float_as_uint(t2[sl])};
-          }
-        } else {
-          split3_pack4(p0[ps][0], p0[ps][1], p0[ps][2], p0[ps][3], sp[ps][0][0], sp[ps][0][1], sp[ps][0][2]);
-          split3_pack4(t1[0], t1[1], t1[2], t1[3], sp[ps][1][0], sp[ps][1][1], sp[ps][1][2]);
-          split3_pack4(t2[0], t2[1], t2[2], t2[3], sp[ps][2][0], sp[ps][2][1], sp[ps][2][2]);
-        }
+        split3_pack4(p0[ps][0], p0[ps][1], p0[ps][2], p0[ps][3], sp[ps][0][0], sp[ps][0][1], sp[ps][0][2]);
+        split3_pack4(t1[0], t1[1], t1[2], t1[3], sp[ps][1][0], sp[ps][1][1], sp[ps][1][2]);
+        split3_pack4(t2[0], t2[1], t2[2], t2[3], sp[ps][2][0], sp[ps][2][1], sp[ps][2][2]);
       }
       lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
                                                         //        every producer is done reading xs(w)
 #pragma unroll
       for (int ps = 0; ps < NRP; ps++) {
-        if (g.debug & 32) break;
         unsigned short* d = As + (s * 32 + ri[ps]) * CT_LDA + s * CT_SPAD + q * 4;
 #pragma unroll
         for (int p = 0; p < 3; p++)
@@ -258,9 +244,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       lds_block_barrier();                              // B1(w): image of unit w visible - the MFMA waves go; everything
                                                         //        below runs under their MFMAs, not in front of them
       if (w + 1 < nunits) {
-        if (!(g.debug & 64)) store_xs();                // xs(w + 1) from the registers loaded a unit ago
+        store_xs();                                     // xs(w + 1) from the registers loaded a unit ago
         load_p0();
-        if (w + 2 < nunits && !(g.debug & 128)) load_union();
+        if (w + 2 < nunits) load_union();
       }
       if (++fc == nchunks) { fc = 0; grp++; }
       lds_block_barrier();                              // B3(w): xs(w + 1) visible to every producer (the MFMA waves pass
@@ -314,17 +300,15 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         // B fragments NB - 1 steps ahead (they do not depend on the producers; the last steps fetch the next unit's first).
         // sched_barrier: the loads must be ISSUED here - left alone, the scheduler sinks them to just above the first
         // MFMA that reads them and the L2 latency (longer than one step's MFMAs under load) is exposed at every step
-        if (!(g.debug & 16)) {
-          constexpr int AH = NB - 1;                    // steps of lead; 6 % NB == 0: the ring position of a step is st % NB
-          if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
-          else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
-        }
+        constexpr int AH = NB - 1;                      // steps of lead; 6 % NB == 0: the ring position of a step is st % NB
+        if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
+        else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 fh[TM], fm[TM];
         read_a(0, st, fh);
         read_a(1, st, fm);
 #define P2M_PAIR(FA, SB)                                                                       \
-  if (!(g.debug & 2)) _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], fb[st % NB][SB][j], acc[i][j], 0, 0, 0);
         P2M_PAIR(fl, 0)
         __builtin_amdgcn_sched_barrier(0);
@@ -374,7 +358,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
               if (g.act_relu) v = fmaxf(v, 0.f);
               if (ok) {
                 if (Ab != nullptr) v += Ab[voff[r]];
-                if (!(g.debug & 8)) Cb[voff[r]] = v;
+                Cb[voff[r]] = v;
                 csum += v;
               }
               acc[i][j][r] = ok ? v : 0.f;
@@ -488,10 +472,6 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   a.Npad = cdiv(N, 128) * 128;          // the layout p2m_weight_split writes
   a.gpb = pick_gpb(a.pl.ntiles, cdiv(B, CT_S));
   hipStream_t s = (hipStream_t)stream;
-  static const int dbg = [] { const char* e = getenv("P2M_TILE_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
-  a.debug = dbg;
-  static const int npw = [] { const char* e = getenv("P2M_TILE_GEMM_NPW"); return e ? atoi(e) : 8; }();   // probe knob
   if (N == 256) return launch_tile_gemm<4, 2, 4>(a, s);
-  if (npw == 4) return N == 128 ? launch_tile_gemm<4, 1, 4>(a, s) : launch_tile_gemm<2, 1, 4>(a, s);
   return N == 128 ? launch_tile_gemm<4, 1, 8>(a, s) : launch_tile_gemm<2, 1, 8>(a, s);
 }

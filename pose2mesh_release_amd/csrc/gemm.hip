@@ -51,16 +51,6 @@ struct GemmArgs {
   // split-bf16 mode (k_gemm_planes_bx): Bx[k / 16][s][n][k % 16], s < 3, n < Npad, k < Ktot = nplanesA * Ka
   const unsigned short* Bx;
   int Npad, Ktot;
-  // optional (EXTRA kernels): the result C is the gradient w.r.t. the output of a BatchNorm + ReLU layer whose raw
-  // input is bn_y [rows of C][N]; the reduction pass of that layer's backward rides in this epilogue:
-  //   bn_part[tile][0][n] = sum_rows g,  bn_part[tile][1][n] = sum_rows g (y - mean) invstd,   g = C masked by the ReLU
-  // (the partial layout of k_bn_bwd_reduce, consumed by p2m_bn_bwd_finalize).
-  const float* bn_y;
-  const float* bn_scale;
-  const float* bn_shift;
-  const float* bn_mean;
-  const float* bn_invstd;
-  float* bn_part;
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -127,51 +117,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         }
       }
     }
-  if (EXTRA && g.bn_part != nullptr) {
-    // BatchNorm-backward reduction of the layer that produced this contraction's input rows (see GemmArgs::bn_y)
-    float* red = smem;  // [2 (kind)][2 (wm)][BN]
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int n = ncol[j];
-      float s0 = 0.f, s1 = 0.f;
-      if (n < g.N) {
-        const float bsc = g.bn_scale[n], bsh = g.bn_shift[n], bmu = g.bn_mean[n], bis = g.bn_invstd[n];
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            const long row = ROWS ? (long)rowtab[ml] : m0 + ml;
-            const bool rok = ROWS ? (row >= 0) : (row < g.M);
-            if (rok) {
-              const float yv = g.bn_y[row * g.N + n];
-              const float gv = fmaf(yv, bsc, bsh) > 0.f ? acc[i][j][r] : 0.f;
-              s0 += gv;
-              s1 = fmaf(gv, (yv - bmu) * bis, s1);
-            }
-          }
-      }
-      s0 += __shfl_xor(s0, 32);
-      s1 += __shfl_xor(s1, 32);
-      if (lhi == 0) {
-        red[wm * BN + wn * WTN + j * 32 + l31] = s0;
-        red[2 * BN + wm * BN + wn * WTN + j * 32 + l31] = s1;
-      }
-    }
-    __syncthreads();
-    if (wm == 0 && lhi == 0) {
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int cl = wn * WTN + j * 32 + l31;
-        const int n = n0 + cl;
-        if (n < g.N) {
-          float* pt = g.bn_part + (long)mt * 2 * g.N;
-          pt[n] = red[cl] + red[BN + cl];
-          pt[g.N + n] = red[2 * BN + cl] + red[3 * BN + cl];
-        }
-      }
-    }
-  }
   if (g.stats == nullptr) return;
 
   // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
@@ -371,237 +316,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
 // (m l', l m', l l') are <= 2^-23 |x y| together - one fp32 rounding.  tests/test_gpu_ops.py checks the result against
 // float64 with the same bound as the native f32 MFMA kernel.  Six bf16 MFMAs cost 6/16 of one f32 MFMA per flop.
 //
-// Same block/wave tiling, row addressing, staging pipeline and epilogue as k_gemm_planes.  A is split while it is
-// staged (fp32 global -> 3 bf16 planes in LDS); the weights arrive pre-split and k-contiguous (p2m_weight_split), so
-// their staging is a straight 16-byte copy.  LDS rows hold KB bf16 + 8 pad: the 48 / 80-byte row stride makes the
-// 16-lane groups of ds_read_b128 hit all 64 banks once.
+// Same block/wave tiling, row addressing and epilogue as k_gemm_planes.  A is split while it is staged (fp32 global ->
+// 3 bf16 planes in LDS, split3_pack4 in p2m_split.h); the weights arrive pre-split and k-contiguous (p2m_weight_split),
+// so their staging is a straight 16-byte copy.  LDS rows hold 16 bf16 + 8 pad: the 48-byte row stride makes the 16-lane
+// groups of ds_read_b128 hit all 64 banks once.
 // ---------------------------------------------------------------------------------------------
-// (the exact 3-way bf16 split of an fp32 value: split3 / split3_pack4 in p2m_split.h)
-template <int BN, int KB, bool EXTRA, bool ROWS = false>
-__global__ __launch_bounds__(256, 2) void k_gemm_planes_bx(GemmArgs g) {
-  constexpr int NS = 3;          // slices per operand
-  static_assert(KB == 16 && (BN == 128 || BN == 64), "one 16-byte B segment per thread and slice");
-  constexpr int WTN = BN / 2;
-  constexpr int TN = WTN / 32;
-  constexpr int TM = 2;
-  constexpr int LDX = KB + 8;                     // bf16 elements per LDS row
-  constexpr int APASS = BM * KB / 4 / 256;        // float4 A loads per thread per chunk
-  constexpr int AROWS = 256 / (KB / 4);
-  constexpr int A_BUF = NS * BM * LDX;            // bf16 elements of one A buffer
-  constexpr int B_BUF = NS * BN * LDX;
-  constexpr int SM_WORDS = (2 * A_BUF + 2 * B_BUF) / 2 + (ROWS ? BM : 0);
-  static_assert(SM_WORDS >= 2 * BN, "epilogue scratch");
-  __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
-  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* Bs = As + 2 * A_BUF;
-  int* rowtab = reinterpret_cast<int*>(smem + (2 * A_BUF + 2 * B_BUF) / 2);
-
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
-  const long m0 = (long)mt * BM;
-  const int n0 = nt * BN;
-  const int t = threadIdx.x;
-  const int rs_b = ROWS ? mt / g.tps : 0;
-  const int rs_i0 = ROWS ? (mt - rs_b * g.tps) * BM : 0;
-  if (ROWS && t < BM) {
-    const int i = rs_i0 + t;
-    rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
-  }
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int cpp = g.Ka / KB;
-  const int nchunks = g.nplanesA * cpp;
-
-  // two register stages: chunk kc+1 waits in one while chunk kc+2 is still in flight into the other.  This kernel
-  // is HBM/L2-latency bound once the MFMA work is 6/16 of the f32 kernel's, so the loads need > 1 chunk of lead and
-  // the block barrier must not drain them (lds_barrier below instead of __syncthreads).
-  // (native vector types: HIP's struct vector types kept these arrays in scratch)
-  f32x4 ra0[APASS], ra1[APASS];
-  u32x4 rb0[NS], rb1[NS];
-  const int a_row = t / (KB / 4), a_k4 = (t % (KB / 4)) * 4;
-  // source rows of this thread's APASS tile rows (full layout; compact layout for planes 1,2 of a row set).  Rows past
-  // the end are CLAMPED to the last valid row, not predicated: a conditional load makes hipcc drain vmcnt, and what
-  // such a row accumulates is never stored (the epilogue masks it).
-  long off0[APASS], off12[APASS];     // element offsets of the thread's rows in plane 0 / planes 1,2
-#pragma unroll
-  for (int ps = 0; ps < APASS; ps++) {
-    long rf, rc;
-    if (ROWS) {
-      int i = rs_i0 + ps * AROWS + a_row;
-      if (i >= g.nset) i = g.nset - 1;
-      rf = (long)rs_b * g.V + g.ids[i];
-      rc = g.compact ? (long)rs_b * g.nset + i : rf;
-    } else {
-      rf = m0 + ps * AROWS + a_row;
-      if (rf >= g.M) rf = g.M - 1;
-      rc = rf;
-    }
-    off0[ps] = (rf >> g.a0_shift) * g.Ka + a_k4;
-    off12[ps] = rc * g.Ka + a_k4;
-  }
-  // Bx is chunk-major: [k / 16][slice][n < Npad][16]: the 128 x 16 slice of one chunk is one contiguous 4 KB run
-  const int b_n = (t % (BN * 2)) >> 1, b_half = (t & 1) * 8;     // BN = 64: the upper 128 threads duplicate the lower
-  const unsigned short* bx_base = g.Bx + ((long)(n0 + b_n) * 16 + b_half);
-  const long bx_slice = (long)g.Npad * 16;        // elements between two slices of one chunk
-
-  auto load_chunk = [&](int kc, f32x4 (&ra)[APASS], u32x4 (&rb)[NS]) {
-    const int p = kc / cpp;
-    const int k0 = (kc - p * cpp) * KB;
-    const float* Ap = g.A[p] + k0;
-#pragma unroll
-    for (int ps = 0; ps < APASS; ps++)
-      ra[ps] = *reinterpret_cast<const f32x4*>(Ap + (p == 0 ? off0[ps] : off12[ps]));
-    const unsigned short* src = bx_base + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice);
-    rb[0] = *reinterpret_cast<const u32x4*>(src);
-    rb[1] = *reinterpret_cast<const u32x4*>(src + bx_slice);
-    rb[2] = *reinterpret_cast<const u32x4*>(src + 2 * bx_slice);
-  };
-  auto store_chunk = [&](int buf, f32x4 (&ra)[APASS], const u32x4 (&rb)[NS]) {
-    unsigned short* as = As + buf * A_BUF;
-    // opaque use: keeps the optimiser from starting the slice arithmetic (and so the wait for these loads) earlier
-#pragma unroll
-    for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(ra[ps]));
-#pragma unroll
-    for (int ps = 0; ps < APASS; ps++) {
-      u32x2 ph, pm, pl;
-      split3_pack4(ra[ps][0], ra[ps][1], ra[ps][2], ra[ps][3], ph, pm, pl);
-      unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
-      *reinterpret_cast<u32x2*>(d) = ph;
-      *reinterpret_cast<u32x2*>(d + BM * LDX) = pm;
-      *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = pl;
-    }
-    unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
-    *reinterpret_cast<u32x4*>(d) = rb[0];
-    *reinterpret_cast<u32x4*>(d + BN * LDX) = rb[1];
-    *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = rb[2];
-  };
-
-  auto compute = [&](int cur) {
-    const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
-    const unsigned short* bs = Bs + cur * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KB / 16; ks++) {
-      bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; i++) {
-        const unsigned short* q = as + i * 32 * LDX + ks * 16;
-        ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-        am[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BM * LDX));
-        al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BM * LDX));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const unsigned short* q = bs + j * 32 * LDX + ks * 16;
-        bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-        bm[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BN * LDX));
-        bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BN * LDX));
-      }
-      // smallest pairs first; the TM*TN accumulators are independent, so consecutive MFMAs never chain
-#define P2M_PAIR(XA, XB)                                                                       \
-  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA[i], XB[j], acc[i][j], 0, 0, 0);
-      P2M_PAIR(al, bh)
-      P2M_PAIR(ah, bl)
-      P2M_PAIR(am, bm)
-      P2M_PAIR(am, bh)
-      P2M_PAIR(ah, bm)
-      P2M_PAIR(ah, bh)
-#undef P2M_PAIR
-    }
-  };
-  // LDS-only barrier: waits for this wave's LDS traffic, leaves its global loads in flight
-  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  // Software pipeline, two chunks of lead.  Invariant at the top of an even phase: LDS buffer 0 holds chunk kc,
-  // stage 1 holds (or is receiving) chunk kc+1.  The steady-state loop issues its loads UNCONDITIONALLY: the
-  // compiler's vmcnt bookkeeping needs a static number of loads per phase - one conditional load and every wait in
-  // the loop degrades to vmcnt(0).  sched_barrier(0) keeps the scheduler from hoisting the slice arithmetic of the
-  // waiting stage above the MFMA phase (that would wait for its loads a whole phase early).
-  load_chunk(0, ra0, rb0);
-  load_chunk(nchunks > 1 ? 1 : 0, ra1, rb1);
-  store_chunk(0, ra0, rb0);
-  lds_barrier();
-  int kc = 0;
-  for (; kc + 3 < nchunks; kc += 2) {
-    load_chunk(kc + 2, ra0, rb0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(0);
-    __builtin_amdgcn_sched_barrier(0);
-    store_chunk(1, ra1, rb1);
-    lds_barrier();
-    load_chunk(kc + 3, ra1, rb1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_chunk(0, ra0, rb0);
-    lds_barrier();
-  }
-  // tail: 1..3 chunks left, same invariant
-  const int left = nchunks - kc;
-  if (left == 3) load_chunk(kc + 2, ra0, rb0);
-  compute(0);
-  if (left >= 2) {
-    store_chunk(1, ra1, rb1);
-    lds_barrier();
-    compute(1);
-    if (left == 3) {
-      store_chunk(0, ra0, rb0);
-      lds_barrier();
-      compute(0);
-    }
-  }
-  __syncthreads();   // every wave is done with the staging buffers: the epilogue reuses them
-  gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
-}
-
+// Wave-specialised: 512 threads = 4 consumer waves (fragment reads + MFMAs, the 2 x 2 wave tiling of k_gemm_planes) +
+// 4 producer waves (global loads, slice arithmetic, LDS stores).  The hardware places waves i and i+4 of a block on the
+// same SIMD, so each SIMD runs one MFMA stream and one VALU/memory stream side by side instead of one wave doing both
+// in turn (a 4-wave form of the same kernel spent 24 % of a wave's phase in MFMAs).
+//   * producers: two register stages of lead (they hold no accumulators), loads unconditional in the steady state,
+//     LDS ring of two 16-wide chunks; during iteration kc they store chunk kc+1 and refill that stage with chunk kc+3;
+//   * one LDS-only block barrier per chunk.  2 blocks (16 waves) per CU, 74 KB of LDS each.
+// (Measured and removed in round 3: the 4-wave form, a 3-chunk ring with double-buffered fragments at 1 block per CU
+//  (-1.4 % on the step), the BatchNorm-backward reduction in this kernel's epilogue (its 4-byte strided reads of the
+//  layer's raw input cost the contraction +4.5 ms, the pass they replace 3.3 ms).)
 // ---------------------------------------------------------------------------------------------
-// Wave-specialised form of k_gemm_planes_bx: 512 threads = 4 consumer waves (fragment reads + MFMAs, the 2 x 2 wave
-// tiling of the other kernels) + 4 producer waves (global loads, slice arithmetic, LDS stores).  The hardware places
-// waves i and i+4 of a block on the same SIMD, so each SIMD runs one MFMA stream and one VALU/memory stream side by
-// side instead of one wave doing both in turn (k_gemm_planes_bx: 24 % of a wave's phase is MFMA).
-//   * producers: FOUR register stages of lead (they hold no accumulators), loads unconditional in the steady state,
-//     LDS ring of three chunks; during iteration kc they store chunk kc+2 and refill that stage with chunk kc+6;
-//   * consumers: fragments double-buffered in registers - the 12 ds_read_b128 of chunk kc+1 are issued under the 24
-//     MFMAs of chunk kc;
-//   * one LDS-only block barrier per chunk.  1 block (8 waves) per CU, 110 KB of LDS.
-// ---------------------------------------------------------------------------------------------
-// probe builds only (tools/probes/ablate_gemm.sh build|run): -DP2M_ABLATE=mask removes 1 A loads, 2 B loads, 4 slice arithmetic,
-// 8 LDS stores, 16 fragment reads, 32 MFMAs from k_gemm_planes_ws to see what the chunk time is made of
-#ifndef P2M_ABLATE
-#define P2M_ABLATE 0
-#endif
-// probe builds only (tools/probes/gemm_trace.py): -DP2M_GEMM_TRACE=1 stamps s_memtime at the phase boundaries of one
-// producer wave and one consumer wave of 8 blocks in the middle of the launch (LDS scratch, dumped to p2m_gemm_trace at
-// the end) to see where an iteration's cycles go
-#ifndef P2M_GEMM_TRACE
-#define P2M_GEMM_TRACE 0
-#endif
-#if P2M_GEMM_TRACE
-constexpr int TRACE_IT = 40, TRACE_ST = 6, TRACE_BLK0 = 4096;
-__device__ unsigned long long p2m_gemm_trace[8 * 2 * TRACE_IT * TRACE_ST];
-#define P2M_STAMP(role, it, k)                                                                                  \
-  do {                                                                                                          \
-    if (tracing && (it) < TRACE_IT && wave == 0 && lane == 0)                                                   \
-      trace_lds[((role) * TRACE_IT + (it)) * TRACE_ST + (k)] = __builtin_amdgcn_s_memtime();                   \
-  } while (0)
-#else
-#define P2M_STAMP(role, it, k) do { } while (0)
-#endif
-template <int BN, bool EXTRA, bool ROWS, int NBUF, int NST>
-__global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmArgs g) {
+template <int BN, bool EXTRA, bool ROWS>
+__global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   constexpr int NS = 3, KB = 16;
+  constexpr int NBUF = 2, NST = 2;    // LDS ring of two chunks, two register stages of lead
   constexpr int AHEAD = NBUF - 1;     // the producers store chunk kc + AHEAD during iteration kc
-  static_assert((NBUF == 2 || NBUF == 3) && NST >= AHEAD, "ring / stage configuration");
   constexpr int WTN = BN / 2;
   constexpr int TN = WTN / 32;
   constexpr int TM = 2;
@@ -610,21 +345,11 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
   constexpr int AROWS = 256 / (KB / 4);
   constexpr int A_BUF = NS * BM * LDX;
   constexpr int B_BUF = NS * BN * LDX;
-#if P2M_GEMM_TRACE
-  constexpr int TRACE_WORDS = 2 * 2 * TRACE_IT * TRACE_ST;
-#else
-  constexpr int TRACE_WORDS = 0;
-#endif
-  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0) + TRACE_WORDS;
+  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0);
   __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);
   unsigned short* Bs = As + NBUF * A_BUF;
   int* rowtab = reinterpret_cast<int*>(smem + NBUF * (A_BUF + B_BUF) / 2);
-#if P2M_GEMM_TRACE
-  unsigned long long* trace_lds = reinterpret_cast<unsigned long long*>(smem + NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0));
-  const bool tracing = blockIdx.x >= TRACE_BLK0 && blockIdx.x < TRACE_BLK0 + 8;
-  if (tracing && threadIdx.x < TRACE_WORDS / 2) trace_lds[threadIdx.x] = 0;
-#endif
 
   int mt, nt;
   if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
@@ -655,9 +380,6 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   if (producer) {
-#ifdef P2M_PRODUCER_PRIO
-    __builtin_amdgcn_s_setprio(P2M_PRODUCER_PRIO);
-#endif
     // LDS stores without bank conflicts.  A row of a slice image is LDX = 24 bf16 = 12 dwords; a ds_write_b64 is serviced
     // in groups of 16 consecutive lanes (4 rows x 4 k-quads, an 8-dword window per row) over 32 banks, and rows r, r+3
     // overlap (12 * 3 = 36 = 4 mod 32): 2-way conflicts on every store, 33 % of all LDS cycles of the round-2 kernel
@@ -705,57 +427,34 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
 
     f32x4 ra[NST][APASS];
     u32x4 rb[NST][NS];
-    if (P2M_ABLATE & 3) {
-#pragma unroll
-      for (int i = 0; i < NST; i++) {
-#pragma unroll
-        for (int ps = 0; ps < APASS; ps++) ra[i][ps] = f32x4{1.f, 2.f, 3.f, 4.f};
-#pragma unroll
-        for (int sl = 0; sl < NS; sl++) rb[i][sl] = u32x4{1u, 2u, 3u, 4u};
-      }
-    }
     auto load_chunk = [&](int kc, f32x4 (&a)[APASS], u32x4 (&b)[NS]) {
       const int p = kc / cpp;
       const int k0 = (kc - p * cpp) * KB;
       const char* Ab = reinterpret_cast<const char*>(g.A[p] + (p == 0 ? sbase0 : sbase12) + k0);     // uniform
-      if (!(P2M_ABLATE & 1)) {
 #pragma unroll
-        for (int ps = 0; ps < APASS; ps++)
-          a[ps] = *reinterpret_cast<const f32x4*>(Ab + (p == 0 ? voff0[ps] : voff12[ps]));
-      }
+      for (int ps = 0; ps < APASS; ps++)
+        a[ps] = *reinterpret_cast<const f32x4*>(Ab + (p == 0 ? voff0[ps] : voff12[ps]));
       const char* src0 = reinterpret_cast<const char*>(g.Bx + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice));   // uniform
       const char* src1 = src0 + 2 * bx_slice;
       const char* src2 = src1 + 2 * bx_slice;
-      if (!(P2M_ABLATE & 2)) {
-        b[0] = *reinterpret_cast<const u32x4*>(src0 + bx_voff);
-        b[1] = *reinterpret_cast<const u32x4*>(src1 + bx_voff);
-        b[2] = *reinterpret_cast<const u32x4*>(src2 + bx_voff);
-      }
+      b[0] = *reinterpret_cast<const u32x4*>(src0 + bx_voff);
+      b[1] = *reinterpret_cast<const u32x4*>(src1 + bx_voff);
+      b[2] = *reinterpret_cast<const u32x4*>(src2 + bx_voff);
     };
     auto store_chunk = [&](int kc, f32x4 (&a)[APASS], const u32x4 (&b)[NS]) {
       const int buf = kc % NBUF;
       unsigned short* as = As + buf * A_BUF;
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(a[ps]));
-      P2M_STAMP(0, kc - AHEAD, 1);            // the A loads of this chunk have arrived
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
         u32x2 ph, pm, pl;
-        if (P2M_ABLATE & 4) {
-          ph = u32x2{__float_as_uint(a[ps][0]), __float_as_uint(a[ps][2])};
-          pm = ph;
-          pl = ph;
-        } else {
-          split3_pack4(a[ps][0], a[ps][1], a[ps][2], a[ps][3], ph, pm, pl);
-        }
-        if (P2M_ABLATE & 8) continue;
+        split3_pack4(a[ps][0], a[ps][1], a[ps][2], a[ps][3], ph, pm, pl);
         unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
         *reinterpret_cast<u32x2*>(d) = ph;
         *reinterpret_cast<u32x2*>(d + BM * LDX) = pm;
         *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = pl;
       }
-      if (P2M_ABLATE & 8) return;
-      P2M_STAMP(0, kc - AHEAD, 5);            // A slices computed and their LDS stores issued
       unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
       *reinterpret_cast<u32x4*>(d) = b[0];
       *reinterpret_cast<u32x4*>(d + BN * LDX) = b[1];
@@ -777,13 +476,9 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
     for (; kc + (NST - 1) + AHEAD + NST < n; kc += NST) {     // steady state: every load below is in range
 #pragma unroll
       for (int i = 0; i < NST; i++) {
-        P2M_STAMP(0, kc + i, 0);
         store_chunk(kc + i + AHEAD, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
-        P2M_STAMP(0, kc + i, 2);              // slices written (s_memtime waits for the LDS stores)
         load_chunk(kc + i + AHEAD + NST, ra[(i + AHEAD) % NST], rb[(i + AHEAD) % NST]);
-        P2M_STAMP(0, kc + i, 3);              // next loads issued
         lds_barrier();
-        P2M_STAMP(0, kc + i, 4);              // barrier passed
       }
     }
     for (; kc < n; kc += NST) {                                // tail: same rotation, range-checked
@@ -798,19 +493,7 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
     }
   } else {
     bf16x8 fa[NBUF - 1][NS][TM], fb[NBUF - 1][NS][TN];       // [register set][slice h,m,l][tile]
-    if (P2M_ABLATE & 16) {
-#pragma unroll
-      for (int q = 0; q < NBUF - 1; q++)
-#pragma unroll
-        for (int sl = 0; sl < NS; sl++) {
-#pragma unroll
-          for (int i = 0; i < TM; i++) fa[q][sl][i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 2u, 3u, 4u});
-#pragma unroll
-          for (int j = 0; j < TN; j++) fb[q][sl][j] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 5u, 3u, 4u});
-        }
-    }
     auto read_frags = [&](int kc, bf16x8 (&a)[NS][TM], bf16x8 (&b)[NS][TN]) {
-      if (P2M_ABLATE & 16) return;
       const int buf = kc % NBUF;
       const unsigned short* as = As + buf * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
       const unsigned short* bs = Bs + buf * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
@@ -825,7 +508,6 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
       }
     };
     auto mfmas = [&](const bf16x8 (&a)[NS][TM], const bf16x8 (&b)[NS][TN]) {
-      if (P2M_ABLATE & 32) return;
 #define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SA][i], b[SB][j], acc[i][j], 0, 0, 0);
@@ -838,42 +520,16 @@ __global__ __launch_bounds__(512, NBUF == 2 ? 2 : 1) void k_gemm_planes_ws(GemmA
 #undef P2M_PAIR
     };
     lds_barrier();                              // the first AHEAD chunks are in LDS
-    if (NBUF == 3) {                            // fragments of chunk kc+1 are read under the MFMAs of chunk kc
-      read_frags(0, fa[0], fb[0]);
-      int kc = 0;
-      for (; kc + 1 < n; kc += 2) {
-        read_frags(kc + 1, fa[1], fb[1]);
-        mfmas(fa[0], fb[0]);
-        lds_barrier();
-        if (kc + 2 < n) read_frags(kc + 2, fa[0], fb[0]);
-        mfmas(fa[1], fb[1]);
-        lds_barrier();
-      }
-      if (kc < n) {
-        mfmas(fa[0], fb[0]);
-        lds_barrier();
-      }
-    } else {
-      for (int kc = 0; kc < n; kc++) {
-        P2M_STAMP(1, kc, 0);
-        read_frags(kc, fa[0], fb[0]);
-        P2M_STAMP(1, kc, 1);                  // fragments in registers (s_memtime waits for the LDS reads)
-        mfmas(fa[0], fb[0]);
-        P2M_STAMP(1, kc, 2);                  // MFMAs issued
-        lds_barrier();
-        P2M_STAMP(1, kc, 3);                  // barrier passed
-      }
+    for (int kc = 0; kc < n; kc++) {
+      read_frags(kc, fa[0], fb[0]);
+      mfmas(fa[0], fb[0]);
+      lds_barrier();
     }
   }
   __syncthreads();   // staging buffers are free: the epilogue reuses them
-#if P2M_GEMM_TRACE
-  if (tracing && t < TRACE_WORDS / 2) p2m_gemm_trace[(blockIdx.x - TRACE_BLK0) * (TRACE_WORDS / 2) + t] = trace_lds[t];
-  __syncthreads();
-#endif
   if (!producer) {
     gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
   } else {
-    if (EXTRA && g.bn_part != nullptr) __syncthreads();   // the block barrier of the BatchNorm-backward reduction
     if (g.stats != nullptr) {                   // the three block barriers of the statistics reduction
       __syncthreads();
       __syncthreads();
@@ -1110,233 +766,22 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient on the BF16 matrix pipe (same 3-slice split as k_gemm_planes_bx).
+// Weight gradient on the BF16 matrix pipe (same 3-slice split as k_gemm_planes_ws).
 //
 // Both operands are activations stored row-major over the REDUCTION index r ([r][kk], [r][n]), while the MFMA wants
 // each lane to hold 8 consecutive r of one kk / n.  The transpose happens in registers on the way into LDS: a staging
 // thread owns a 4 (r) x 4 (kk) block (four float4 loads, rows r..r+3), cuts it into slices and writes, per kk, the
-// four r of a slice as ONE 8-byte store into the kk-major image [slice][kk][16 r + 8 pad].  Waves 0,1 stage A, waves
-// 2,3 stage G (wave-uniform roles, identical instruction stream); all four waves run the MFMAs.
+// four r of a slice as ONE 8-byte store into the kk-major image [slice][kk][16 r + 8 pad].  Staging waves 4,5 stage A,
+// waves 6,7 stage G (wave-uniform roles, identical instruction stream); waves 0..3 run the MFMAs.
 // Loads are unconditional (rows past the end are clamped and their values zeroed; columns past Ktot / N are clamped
-// and never stored), with two register stages of lead and an LDS-only barrier, as in k_gemm_planes_bx.  In ROWS mode
+// and never stored), with two register stages of lead and an LDS-only barrier, as in k_gemm_planes_ws.  In ROWS mode
 // the vertex ids of a stage are fetched two phases before the data loads that depend on them (g.ids is zero-padded
 // by 64 entries at bake time, so those 16-byte id loads need no bounds).
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int BN, bool ROWS = false>
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_bx(TnArgs g) {
-  constexpr int NS = 3;
-  constexpr int RK = 16;                 // rows (reduction) per stage = one bf16 MFMA k-step
-  constexpr int LDX = RK + 8;            // bf16 per LDS row: 48-byte stride, conflict-free ds_read_b128
-  constexpr int WTN = BN / 2;
-  constexpr int TN = WTN / 32;
-  constexpr int TM = 2;
-  constexpr int A_BUF = NS * BM * LDX;
-  constexpr int G_BUF = NS * BN * LDX;
-  __shared__ __attribute__((aligned(16))) float smem[(2 * A_BUF + 2 * G_BUF) / 2];
-  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* Gs = As + 2 * A_BUF;
-
-  const int tile = blockIdx.x;
-  const int kt = tile / g.ntn, nt = tile % g.ntn;
-  const int chunk = blockIdx.y;
-  const int kk0 = kt * BM, n0 = nt * BN;
-  const int rs_b = ROWS ? chunk / g.splits : 0;
-  const long r_begin = ROWS ? (long)(chunk - rs_b * g.splits) * g.chunk_rows : (long)chunk * g.chunk_rows;
-  long r_end = r_begin + g.chunk_rows;
-  if (r_end > (ROWS ? (long)g.nset : g.M)) r_end = ROWS ? (long)g.nset : g.M;
-  const int nst = r_end > r_begin ? (int)((r_end - r_begin + RK - 1) / RK) : 0;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  // staging role of this thread: a 4-row x 4-column block of the A tile (t < 128) or of the G tile
-  const bool is_a = t < 128;
-  const int st = t & 127;
-  const int rq = st & 3;                                   // row quad of the 16-row stage
-  const int c4 = is_a ? (st >> 2) : (st >> 2) % (BN / 4);  // column quad (BN = 64: the upper threads duplicate)
-  const float* src;       // plane base + column offset
-  int pitch, shift;
-  bool compact_rows;      // ROWS: read at the compact row b*nset + r instead of b*V + ids[r]
-  unsigned short* dst;    // LDS image (buffer 0, slice 0) of this thread's first column, at its row quad
-  int slice_stride;
-  {
-    if (is_a) {
-      int kk = kk0 + c4 * 4;
-      if (kk >= g.Ktot) kk = 0;                            // clamped: those rows of P are never stored
-      const int ap = kk / g.Ka;
-      src = g.A[ap] + (kk - ap * g.Ka);
-      pitch = g.Ka;
-      shift = (ap == 0) ? g.a0_shift : 0;
-      compact_rows = false;
-      dst = As + (c4 * 4) * LDX + rq * 4;
-      slice_stride = BM * LDX;
-    } else {
-      int n = n0 + c4 * 4;
-      if (n >= g.N) n = 0;
-      const int gq = n / g.Gc;
-      src = g.G[gq] + (n - gq * g.Gc);
-      pitch = g.Gc;
-      shift = 0;
-      compact_rows = ROWS && gq != 0 && g.compact;
-      dst = Gs + (c4 * 4) * LDX + rq * 4;
-      slice_stride = BN * LDX;
-    }
-  }
-  const int buf_stride = is_a ? A_BUF : G_BUF;
-  const int* idp = ROWS ? g.ids + r_begin + rq * 4 : nullptr;
-  const long row_base = ROWS ? (long)rs_b * g.V : 0;
-  const long crow_base = ROWS ? (long)rs_b * g.nset : 0;
-
-  f32x4 x0[4], x1[4];       // two register stages (native vector types: no scratch)
-  i32x4 id0 = {0, 0, 0, 0}, id1 = {0, 0, 0, 0};
-  f32x4 dbs = {0.f, 0.f, 0.f, 0.f};
-
-  auto load_ids = [&](int kc, i32x4& id) {
-    if (ROWS) id = *reinterpret_cast<const i32x4*>(idp + (long)kc * RK);
-  };
-  auto load_stage = [&](int kc, f32x4 (&x)[4], const i32x4& id) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-      long r = r_begin + (long)kc * RK + rq * 4 + ps;
-      if (r >= r_end) r = r_end - 1;
-      long row;
-      if (ROWS) row = compact_rows ? crow_base + r : row_base + id[ps];
-      else row = r;
-      x[ps] = *reinterpret_cast<const f32x4*>(src + (row >> shift) * pitch);
-    }
-  };
-  auto store_stage = [&](int buf, int kc, f32x4 (&x)[4]) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ps++) asm volatile("" : "+v"(x[ps]));     // see k_gemm_planes_bx
-    const long rlast = r_end - (r_begin + (long)kc * RK + rq * 4);        // rows of this quad that exist
-#pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-      if (ps >= rlast) x[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dbs += x[ps];
-    }
-    unsigned short* d = dst + buf * buf_stride;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      u32x2 ph, pm, pl;
-      split3_pack4(x[0][e], x[1][e], x[2][e], x[3][e], ph, pm, pl);
-      *reinterpret_cast<u32x2*>(d + e * LDX) = ph;
-      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = pm;
-      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = pl;
-    }
-  };
-  auto compute = [&](int cur) {
-    const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
-    const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + l31) * LDX + lhi * 8;
-    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const unsigned short* q = as + i * 32 * LDX;
-      ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-      am[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BM * LDX));
-      al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BM * LDX));
-    }
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const unsigned short* q = gs + j * 32 * LDX;
-      bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-      bm[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BN * LDX));
-      bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BN * LDX));
-    }
-#define P2M_PAIR(XA, XB)                                                                       \
-  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA[i], XB[j], acc[i][j], 0, 0, 0);
-    P2M_PAIR(al, bh)
-    P2M_PAIR(ah, bl)
-    P2M_PAIR(am, bm)
-    P2M_PAIR(am, bh)
-    P2M_PAIR(ah, bm)
-    P2M_PAIR(ah, bh)
-#undef P2M_PAIR
-  };
-  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  if (nst > 0) {
-    // invariant at the top of an even phase: LDS buffer 0 holds stage kc, x1 holds (or receives) stage kc+1,
-    // id0 / id1 hold the ids of stages kc+2 / kc+3
-    load_ids(0, id0);
-    load_ids(1, id1);
-    load_stage(0, x0, id0);
-    load_ids(2, id0);
-    load_stage(nst > 1 ? 1 : 0, x1, id1);
-    load_ids(3, id1);
-    store_stage(0, 0, x0);
-    lds_barrier();
-    int kc = 0;
-    for (; kc + 3 < nst; kc += 2) {
-      load_stage(kc + 2, x0, id0);
-      load_ids(kc + 4, id0);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(0);
-      __builtin_amdgcn_sched_barrier(0);
-      store_stage(1, kc + 1, x1);
-      lds_barrier();
-      load_stage(kc + 3, x1, id1);
-      load_ids(kc + 5, id1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(1);
-      __builtin_amdgcn_sched_barrier(0);
-      store_stage(0, kc + 2, x0);
-      lds_barrier();
-    }
-    const int left = nst - kc;
-    if (left == 3) load_stage(kc + 2, x0, id0);
-    compute(0);
-    if (left >= 2) {
-      store_stage(1, kc + 1, x1);
-      lds_barrier();
-      compute(1);
-      if (left == 3) {
-        store_stage(0, kc + 2, x0);
-        lds_barrier();
-        compute(0);
-      }
-    }
-  }
-  __syncthreads();
-
-  float* Pc = g.P + (long)chunk * g.Ktot * g.N;
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int n = n0 + wn * WTN + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = acc[i][j][r];
-      }
-    }
-  if (kt == 0 && g.Pdb != nullptr) {
-    // bias gradient: column sums of G over this chunk; the four row quads of a column quad meet through LDS
-    float* red = smem;  // [4 (rq)][BN]
-    if (!is_a && (st >> 2) < BN / 4) *reinterpret_cast<f32x4*>(red + rq * BN + c4 * 4) = dbs;
-    __syncthreads();
-    if (t < BN) {
-      const float sum = red[t] + red[BN + t] + red[2 * BN + t] + red[3 * BN + t];
-      if (n0 + t < g.N) g.Pdb[(long)chunk * g.N + n0 + t] = sum;
-    }
-  }
-}
-
-// Wave-specialised form of k_gemm_tn_bx (4 MFMA waves + 4 staging waves, one LDS-only barrier per 16-row stage):
-// same staging, LDS image and epilogue; see k_gemm_planes_ws.
+// Wave-specialised (4 MFMA waves + 4 staging waves, one LDS-only barrier per 16-row stage, two register stages of lead);
+// see k_gemm_planes_ws.
 template <int BN, bool ROWS = false>
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   constexpr int NS = 3;
@@ -1637,10 +1082,7 @@ __global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ W
 // 8 groups (256 threads): alone on the GPU 32 groups are faster, but this kernel runs on the side stream next to the
 // GEMM blocks that own most of the CUs' registers and LDS, and small blocks find a slot sooner (whole step, meshes/s:
 // 2 groups 4213, 4: 4222-4230, 8: 4206-4253, 16: 4209, 32: 4174-4189).
-#ifndef P2M_UNP_CG
-#define P2M_UNP_CG 8
-#endif
-constexpr int UNP_CG = P2M_UNP_CG;
+constexpr int UNP_CG = 8;
 __global__ __launch_bounds__(32 * UNP_CG) void k_weight_grad_unpack(
     const float* __restrict__ P, const float* __restrict__ Pdb, int nchunks, float* __restrict__ dW,
     float* __restrict__ db, int Fout, int Fin, int K, int accumulate, int layout, int pdb_stride,
@@ -1719,23 +1161,6 @@ using namespace p2m;
 
 extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
 
-#if P2M_GEMM_TRACE
-extern "C" int p2m_debug_gemm_trace(unsigned long long* host, int n) {      // probe builds only
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(p2m_gemm_trace), sizeof(unsigned long long) * n);
-}
-#endif
-
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-// tuning knob: K chunk per barrier of the native kernel (P2M_GEMM_KB=16|32)
-static int gemm_kb() { static int kb = env_int("P2M_GEMM_KB", 32) == 16 ? 16 : 32; return kb; }
-// bf16x3 plane contraction: the wave-specialised kernel with a 2-chunk ring and 2 blocks/CU (2, default: +1.4 % on the
-// whole step, 4296 vs 4237 meshes/s), with a 3-chunk ring and 1 block/CU (1), or the 4-wave kernel (0)
-static int gemm_ws() { static int v = env_int("P2M_GEMM_WS", 2); return v; }
-// the weight-gradient contraction follows P2M_GEMM_WS unless P2M_TN_WS = 0 / 1 says otherwise
-static bool tn_ws() { static int v = env_int("P2M_TN_WS", -1); return v < 0 ? gemm_ws() != 0 : v != 0; }
 
 extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
   if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
@@ -1756,33 +1181,18 @@ template <bool ROWS>
 static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
   const bool wide = (g.N % 128 == 0);
   g.ntn = wide ? g.N / 128 : cdiv(g.N, 64);
-  const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn), block(256);
-#define P2M_LAUNCH(KERNEL, BNv, KBv, EX) hipLaunchKernelGGL((KERNEL<BNv, KBv, EX, ROWS>), grid, block, 0, s, g)
-  if (g.Bx != nullptr && gemm_ws()) {
-#define P2M_LAUNCH_WS(BNv, EX)                                                                              \
-  do {                                                                                                      \
-    if (gemm_ws() == 2) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2, 2>), grid, dim3(512), 0, s, g); \
-    else hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 3, 4>), grid, dim3(512), 0, s, g);              \
-  } while (0)
+  const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn);
+  if (g.Bx != nullptr) {
+#define P2M_LAUNCH_WS(BNv, EX) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS>), grid, dim3(512), 0, s, g)
     if (wide) { if (extra) P2M_LAUNCH_WS(128, true); else P2M_LAUNCH_WS(128, false); }
     else { if (extra) P2M_LAUNCH_WS(64, true); else P2M_LAUNCH_WS(64, false); }
 #undef P2M_LAUNCH_WS
-  } else if (g.Bx != nullptr) {
-    if (wide) { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 128, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 128, 16, false); }
-    else { if (extra) P2M_LAUNCH(k_gemm_planes_bx, 64, 16, true); else P2M_LAUNCH(k_gemm_planes_bx, 64, 16, false); }
   } else {
-    const bool kb16 = !ROWS && !extra && gemm_kb() == 16;
-    if (wide) {
-      if (extra) P2M_LAUNCH(k_gemm_planes, 128, 32, true);
-      else if (kb16) P2M_LAUNCH(k_gemm_planes, 128, 16, false);
-      else P2M_LAUNCH(k_gemm_planes, 128, 32, false);
-    } else {
-      if (extra) P2M_LAUNCH(k_gemm_planes, 64, 32, true);
-      else if (kb16) P2M_LAUNCH(k_gemm_planes, 64, 16, false);
-      else P2M_LAUNCH(k_gemm_planes, 64, 32, false);
-    }
-  }
+#define P2M_LAUNCH(BNv, EX) hipLaunchKernelGGL((k_gemm_planes<BNv, 32, EX, ROWS>), grid, dim3(256), 0, s, g)
+    if (wide) { if (extra) P2M_LAUNCH(128, true); else P2M_LAUNCH(128, false); }
+    else { if (extra) P2M_LAUNCH(64, true); else P2M_LAUNCH(64, false); }
 #undef P2M_LAUNCH
+  }
 }
 
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
@@ -1804,7 +1214,6 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   P2M_CHECK_ARG((addend == nullptr && !pair_out) || nplanesC == 1, "addend / pair_out need a single output plane");
   P2M_CHECK_ARG(!(pair_out && stats), "pair_out and stats are mutually exclusive");
   g.Bm = Bm; g.bias = bias; g.addend = addend; g.pair_out = pair_out; g.stats = stats; g.M = M;
-  g.bn_y = g.bn_scale = g.bn_shift = g.bn_mean = g.bn_invstd = nullptr; g.bn_part = nullptr;
   g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
@@ -1833,16 +1242,12 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   return check_launch("gemm_planes");
 }
 
-static int gemm_planes_rows_impl(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
-                                const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
-                                const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
-                                const float* act_shift, int32_t act_relu, const float* bn_y, const float* bn_co,
-                                float* bn_part, void* stream) {
+extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
+                                    const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
+                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
+                                    const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
+                                    const float* act_shift, int32_t act_relu, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
-  P2M_CHECK_ARG((bn_y == nullptr) == (bn_part == nullptr) && (bn_y == nullptr) == (bn_co == nullptr),
-                "bn_y / bn_co / bn_part must all be given or all NULL");
-  P2M_CHECK_ARG(!(bn_part && (stats || act_scale || act_relu)), "the BatchNorm-backward reduction excludes stats / activation");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
@@ -1865,33 +1270,8 @@ static int gemm_planes_rows_impl(p2m_graph_t gh, int32_t row_set, int32_t B, con
   g.Ktot = nplanesA * Ka;
   g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
   g.ntm = B * g.tps;
-  g.bn_y = bn_y; g.bn_part = bn_part;
-  g.bn_mean = bn_co; g.bn_invstd = bn_co ? bn_co + N : nullptr;
-  g.bn_scale = bn_co ? bn_co + 2 * N : nullptr; g.bn_shift = bn_co ? bn_co + 3 * N : nullptr;
-  launch_gemm_planes<true>(g, addend != nullptr || bn_part != nullptr, (hipStream_t)stream);
+  launch_gemm_planes<true>(g, addend != nullptr, (hipStream_t)stream);
   return check_launch("gemm_planes_rows");
-}
-
-extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
-                                    const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
-                                    const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
-                                    const float* act_shift, int32_t act_relu, void* stream) {
-  return gemm_planes_rows_impl(gh, row_set, B, A0, A1, A2, nplanesA, Ka, a0_shift, planes_compact, Bm, Bsplit, bias,
-                               addend, C, N, stats, act_scale, act_shift, act_relu, nullptr, nullptr, nullptr, stream);
-}
-
-// The dX contraction of a backward step whose result feeds a BatchNorm + ReLU layer: bn_y = that layer's raw input
-// [rows of C][N], bn_co = its coefficients [4][N] (mean, invstd, scale, shift as p2m_bn_finalize* writes them), bn_part =
-// [B * p2m_rows_tiles_per_sample(g, row_set)][2][N] partials in the layout p2m_bn_bwd_finalize reads (the separate
-// p2m_bn_bwd_reduce pass over C and bn_y is then not needed).
-extern "C" int p2m_gemm_planes_rows_bnbwd(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
-                                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                          int32_t planes_compact, const float* Bm, const void* Bsplit,
-                                          const float* addend, float* C, int32_t N, const float* bn_y,
-                                          const float* bn_co, float* bn_part, void* stream) {
-  return gemm_planes_rows_impl(gh, row_set, B, A0, A1, A2, nplanesA, Ka, a0_shift, planes_compact, Bm, Bsplit, nullptr,
-                               addend, C, N, nullptr, nullptr, nullptr, 0, bn_y, bn_co, bn_part, stream);
 }
 
 // rows per sample tile count of a row set (for the BatchNorm finalize): tiles_per_sample = ceil(n / 128)
@@ -1935,14 +1315,12 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, false>), grid, dim3(512), 0, s, g);
-    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, false>), grid, dim3(256), 0, s, g);
+    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, false>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, false>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<64, false>), grid, dim3(512), 0, s, g);
-    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, false>), grid, dim3(256), 0, s, g);
+    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, false>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, false>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn");
@@ -1978,14 +1356,12 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<128, true>), grid, dim3(512), 0, s, g);
-    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<128, true>), grid, dim3(256), 0, s, g);
+    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, true>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx && tn_ws()) hipLaunchKernelGGL((k_gemm_tn_ws<64, true>), grid, dim3(512), 0, s, g);
-    else if (bx) hipLaunchKernelGGL((k_gemm_tn_bx<64, true>), grid, dim3(256), 0, s, g);
+    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, true>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, true>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn_rows");

@@ -25,14 +25,11 @@ struct TilePlan {
   float4* ent = nullptr;      // per entry {a, b, bits(local index into the tile's union), 0}, merged-CSR order
   float* tile_cnt = nullptr;  // [ntiles]    rows of each tile (as float: the weight of a tile's BatchNorm partials)
 };
-#ifndef P2M_TILE_RMAX
-#define P2M_TILE_RMAX 32
-#define P2M_TILE_UCAP 120
-#define P2M_TILE_ECAP 896
-#endif
-constexpr int TILE_RMAX = P2M_TILE_RMAX;     // rows per tile
-constexpr int TILE_UCAP = P2M_TILE_UCAP;     // union rows per tile: 120 x 512 B = 60 KB of LDS at 128 features
-constexpr int TILE_ECAP = P2M_TILE_ECAP;     // entries per tile: 14 KB of LDS
+// (measured and rejected: 64-row tiles / 240 union rows - halving the resident blocks costs more than the 22 % fewer L2-side
+//  reads bring; 80 / 512 and 100 / 768 at three resident blocks: DESIGN.md section 6)
+constexpr int TILE_RMAX = 32;      // rows per tile
+constexpr int TILE_UCAP = 120;     // union rows per tile: 120 x 512 B = 60 KB of LDS at 128 features
+constexpr int TILE_ECAP = 896;     // entries per tile: 14 KB of LDS
 
 // Device-side CSR of one coarsening level.  `col/a/b` is the *merged* pattern of L and
 // L2 = 2*L*L - I: T1 = sum a*x[col], T2 = sum b*x[col] are produced by ONE gather pass.

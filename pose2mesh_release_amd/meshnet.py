@@ -82,23 +82,6 @@ def _transposed_operands(Wp):
     return Wpt, ops.weight_split(Wpt)
 
 
-def _wcat_operands(W3):
-    """[Fin, 3*Fout] operand of the project-then-combine form: columns k*Fout + fo = W[fo][fin*3 + k] (W3 transposed)."""
-    Wc = W3.t().contiguous()
-    return Wc, ops.weight_split(Wc)
-
-
-def _project_combine(net, L, g, graphs, x_shift, real_only):
-    """Un-pooled convs whose forward takes the project-then-combine form (include/p2m.h): split level with an in_shift = 1
-    tile plan, widths the combine kernel supports; in train mode the fake rows' statistics need the classes."""
-    if not (ops.PROJECT_COMBINE and x_shift and g.split and L.first_in_block and L.ci > 0 and _bwd_forward_form(L)):
-        return False
-    if g.plan_tiles[1] == 0 or L.Fout % 64 or ops.fused_supported(L.Fin, L.Fout):
-        return False
-    gc = graphs[net._layers[L.ci - 1].graph]
-    return gc.V * 2 == g.V and (real_only or g.classes)
-
-
 def _fc_operands(fw):
     fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
     return fwt, (ops.weight_split(fwt) if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
@@ -147,18 +130,11 @@ def _forward_inference(net, graphs, x, params):
             co = wc.get((L.ci, "bn_eval"), (gamma, beta, bn.running_mean, bn.running_var),
                         lambda: ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps))
             act = (co[2], co[3], True)
-        want_w3 = ops.fused_supported(L.Fout, L.Fin) or _bwd_forward_form(L)
+        want_w3 = _bwd_forward_form(L)
         Wt, _, _ = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
                                                                     need_w3=want_w3))
         mfma = L.Fin % 32 == 0 and L.Fout % 32 == 0
-        if _project_combine(net, L, g, graphs, cur_shift, True):
-            gc = graphs[net._layers[L.ci - 1].graph]
-            _, _, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=False, need_w3=True))
-            Wcat, Wcatx = wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
-            Z = ops.conv_project(gc, B, cur, L.Fin, Wcat, Wcatx, K_CHEB * L.Fout, real_only=True)
-            y, _ = ops.cheb_project_combine(g, gc, Z, bvec, B, L.Fout, act=act)
-            T1 = T2 = Z = None
-        elif g.split and mfma:
+        if g.split and mfma:
             y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
             Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
             T1 = T2 = None
@@ -210,13 +186,8 @@ class _MeshNetFn(torch.autograd.Function):
         training = net.training
         wc = net._weight_cache
         J, cin = net.num_joint, net.num_joint_input_chan
-        if net._prefetch_event is not None:       # operands built on the helper stream (prefetch_operands)
-            torch.cuda.current_stream().wait_event(net._prefetch_event)
-            net._prefetch_event = None
         if training:
-            if not net._epoch_bumped:
-                ops.bump_weight_epoch()   # running statistics change behind torch's back: cached eval coefficients are stale
-            net._epoch_bumped = False
+            ops.bump_weight_epoch()       # running statistics change behind torch's back: cached eval coefficients are stale
         elif not keep and net._infer_real_only:
             ctx.saved = None
             return _forward_inference(net, graphs, x, params)
@@ -251,24 +222,13 @@ class _MeshNetFn(torch.autograd.Function):
                 cur, cur_shift = out, 0
                 continue
             need_stats = L.has_bn and training
-            fwd_fused = ops.fused_supported(L.Fin, L.Fout)
-            bwd_fused = ops.fused_supported(L.Fout, L.Fin)
             bwd_fwdform = _bwd_forward_form(L)
             # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache)
-            want_w3 = bwd_fused or bwd_fwdform
+            want_w3 = bwd_fwdform
             Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
                                                                            need_w3=want_w3))
-            split = g.split and bwd_fwdform and not fwd_fused
-            if split and _project_combine(net, L, g, graphs, cur_shift, False):
-                # un-pooled input: the contraction at the coarse resolution, then the sparse combine on Fout-wide rows
-                gc = graphs[net._layers[L.ci - 1].graph]
-                Wcat, Wcatx = wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
-                Z = ops.conv_project(gc, B, cur, L.Fin, Wcat, Wcatx, K_CHEB * L.Fout)
-                y, st = ops.cheb_project_combine(g, gc, Z, bvec, B, L.Fout, stats=need_stats)
-                st2 = ops.cheb_project_combine_fake(g, Z, bvec, y, B, L.Fout, stats=need_stats)
-                T1 = T2 = Z = None
-                tile_rows = "combine"
-            elif split:
+            split = g.split and bwd_fwdform
+            if split:
                 # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
@@ -277,10 +237,6 @@ class _MeshNetFn(torch.autograd.Function):
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
                                                         g.fake_b, need_stats, operands=opf, want_planes=False)
                 tile_rows = ("tiles", cur_shift) if tiled else "rows"
-            elif fwd_fused:        # recurrence + contraction in one kernel: the basis planes never reach HBM
-                T1 = T2 = None
-                y, st, _ = ops.cheb_gemm_fused(g, cur, L.Fin, cur_shift, Wt, bvec, None, L.Fout, B, stats=need_stats)
-                tile_rows = ops.fused_stats_tile_rows(L.Fout)
             else:
                 T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
                 Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) \
@@ -291,11 +247,7 @@ class _MeshNetFn(torch.autograd.Function):
             if L.has_bn:
                 bn = net.bn[L.ci]
                 gamma, beta = params[P[f"bn.{L.ci}.weight"]], params[P[f"bn.{L.ci}.bias"]]
-                if training and tile_rows == "combine":
-                    co = ops.bn_finalize_combine(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
-                                                 bn_momentum(bn), bn.eps)
-                    bn.num_batches_tracked.add_(1)
-                elif training and isinstance(tile_rows, tuple):
+                if training and isinstance(tile_rows, tuple):
                     co = ops.bn_finalize_tiles(g, tile_rows[1], B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
                                                bn_momentum(bn), bn.eps)
                     bn.num_batches_tracked.add_(1)
@@ -323,9 +275,9 @@ class _MeshNetFn(torch.autograd.Function):
             else:
                 out = y                                               # final conv: no BN, no ReLU (:52-55,99)
             if keep:
-                if bwd_fused or bwd_fwdform:
+                if bwd_fwdform:
                     T1 = T2 = None          # the backward never needs the basis of X (dW = X^T [g|Lg|L2g])
-                saved.append((cur, cur_shift, T1, T2, y, co, W3 if (bwd_fused or bwd_fwdform) else W2))
+                saved.append((cur, cur_shift, T1, T2, y, co, W3 if bwd_fwdform else W2))
             cur, cur_shift = out, 0
             if L.last_in_block:
                 if L.block == 0:                                      # fc lift (:104-106)
@@ -409,7 +361,6 @@ class _MeshNetFn(torch.autograd.Function):
                     self.cm.__exit__(*a)
                 return False
         Gs_block = None    # S G of the current block (pair-sum of the gradient w.r.t. the block output), when produced
-        bn_part = None     # backward-reduction partials of the NEXT conv to be processed, when its dX contraction made them
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
@@ -469,18 +420,10 @@ class _MeshNetFn(torch.autograd.Function):
             Fblk = net.CL_F[L.block][-1]
             fuse_res = has_res and (L.Fin == Fblk)
             pair_path = _bwd_forward_form(L) and gph.split and x_shift and gph.pair \
-                and (L.Fout in (32, 64) or L.Fout % 128 == 0) and not ops.fused_supported(L.Fout, L.Fin)
+                and (L.Fout in (32, 64) or L.Fout % 128 == 0)
             # pair-sums this block's first conv will need come out of the BatchNorm-backward pass as by-products:
             # S G (the residual gradient at the coarser resolution) when G is read as g_cur by the block's last conv,
             # S gy (plane 0 of the paired operator) when the first conv's own gy is written
-            # dX of this conv is the gradient flowing into the previous conv's BatchNorm + ReLU (same tensor, nothing
-            # added afterwards): that layer's backward reduction then rides in the epilogue of the dX contraction
-            prev = net._layers[L.ci - 1] if L.ci > 0 else None
-            bn_next = None
-            if ops.BN_BWD_IN_EPILOGUE and prev is not None and prev.has_bn and _bwd_forward_form(L) and gph.split \
-                    and not ops.fused_supported(L.Fout, L.Fin) and not (has_res and not fuse_res) \
-                    and (prev.block == L.block or L.block >= 2) and (pair_path or not x_shift):
-                bn_next = (saved[prev.ci][4], saved[prev.ci][5])           # (y, co) of the previous conv
             want_Gs = want_P0 = False
             if L.has_bn and M % 2 == 0 and L.Fout in (32, 64, 128, 256):
                 if L.last_in_block and not L.first_in_block:
@@ -494,8 +437,7 @@ class _MeshNetFn(torch.autograd.Function):
                 tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
                 res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
-                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, part=bn_part, **kw)
-                bn_part = None
+                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, **kw)
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
@@ -507,16 +449,7 @@ class _MeshNetFn(torch.autograd.Function):
                     P0 = res[4]
             else:
                 gy = g_cur
-            if ops.fused_supported(L.Fout, L.Fin):
-                # dX = [gy | L gy | L2 gy] W3 in one kernel (L symmetric); its gathered planes give
-                # dW = X^T [gy | L gy | L2 gy] without ever forming the basis of X
-                dX, _, (E1, E2) = ops.cheb_gemm_fused(gph, gy, L.Fout, 0, W2, None, G if fuse_res else None, L.Fin, B,
-                                                      pair_out=bool(x_shift), want_planes=True)
-                Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
-                dW, db = ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, layout=1)
-                grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
-                del Pw, Pb, E1, E2
-            elif pair_path:
+            if pair_path:
                 # the input was un-pooled (X_fine[r] = X[r >> 1]): with S = the pair-sum, dX = [S g | S L g | S L2 g] W3
                 # and dW = X^T [S g | S L g | S L2 g] -- both contractions run over V/2 rows; S L and S L2 are one
                 # baked operator (the level's paired tile plan), its rows split into "has a real child" / "both
@@ -530,7 +463,7 @@ class _MeshNetFn(torch.autograd.Function):
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                P0, E1, E2, bn_part = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0, bn=bn_next)
+                P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0)
                 with side_ctx(keep, X, P0, E1, E2):
                     Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False)
@@ -550,8 +483,8 @@ class _MeshNetFn(torch.autograd.Function):
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
                              lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
-                E1, E2, bn_part, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
-                                                       gph.fake_b, operands=opb, bn=bn_next)
+                E1, E2, _, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
+                                                 gph.fake_b, operands=opb)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
@@ -589,8 +522,6 @@ class _MeshNetFn(torch.autograd.Function):
                     grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
             else:
-                if T1 is None:          # forward was fused: rebuild the (small) basis for this odd-shaped layer
-                    T1, T2 = ops.cheb_basis_fwd(gph, X, B, L.Fin, x_shift)
                 Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
                 tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                 if tg is not None:
@@ -675,7 +606,6 @@ class Pose2Mesh(nn.Module):
         self._layers = layers
         self._block_first = {L.block: i for i, L in enumerate(layers) if L.first_in_block}
         self._class_rep = {}
-        self._prefetch_event, self._epoch_bumped = None, False
         self._graph_cache = ops.GraphCache(graph_L, class_plan=self._class_plan)
         self._weight_cache = ops.WeightCache()
         self._direct_grad = False
@@ -706,7 +636,7 @@ class Pose2Mesh(nn.Module):
             g = graphs[L.graph]
             if L.graph not in chain or not g.split or _narrow(L):
                 continue
-            if not _bwd_forward_form(L) or ops.fused_supported(L.Fin, L.Fout) or ops.fused_supported(L.Fout, L.Fin):
+            if not _bwd_forward_form(L):
                 return None
             if L.first_in_block and 2 <= L.block <= nblk - 2 \
                     and not (g.pair and (L.Fout in (32, 64) or L.Fout % 128 == 0)):
@@ -787,60 +717,6 @@ class Pose2Mesh(nn.Module):
             t = torch.from_numpy(inv).to(device)
             self._out_index[device] = t
         return t
-
-    def prefetch_operands(self):
-        """Train mode only: build this step's derived weight operands (packed / transposed / pre-split / fake-vertex
-        effective copies: ~110 tiny launches that would otherwise sit one by one in front of the convs that use them) on
-        the helper stream, ordered after everything already issued, while the caller keeps the main stream busy with
-        something else (FlatPose2Mesh: PoseNet).  The next forward waits for them once.  Same builders and cache keys as
-        the forward / backward (tests/test_gpu_train.py asserts that nothing is left for them to build)."""
-        if not (self.training and torch.is_grad_enabled() and ops.PREFETCH_OPERANDS):
-            return
-        names, params = self._param_list()
-        dev = params[0].device
-        if dev.type != "cuda" or not ops.DW_SIDE_STREAM:
-            return
-        P, wc = self._param_index, self._weight_cache
-        with torch.cuda.device(dev):
-            graphs = self._graph_cache.on(dev)
-            main = torch.cuda.current_stream()
-            side = ops.side_stream(dev)
-            side.wait_stream(main)
-            ops.bump_weight_epoch()
-            self._epoch_bumped = True
-            with torch.cuda.stream(side):
-                fw = params[P["fc.weight"]]
-                wc.get("fc", fw, lambda: _fc_operands(fw))
-                wc.get("fc_bwd", fw, lambda: ops.weight_split(fw)
-                       if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
-                for L in self._layers:
-                    g = graphs[L.graph]
-                    W = params[P[f"cl.{L.ci}.weight"]]
-                    if _narrow(L):
-                        Wp, _ = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
-                        wc.get((L.ci, "narrow_bwd"), W, lambda: _transposed_operands(Wp))
-                        continue
-                    fwd_fused = ops.fused_supported(L.Fin, L.Fout)
-                    bwd_fused = ops.fused_supported(L.Fout, L.Fin)
-                    fform = _bwd_forward_form(L)
-                    want_w3 = bwd_fused or fform
-                    Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
-                                                                                   need_w3=want_w3))
-                    x_shift = int(L.first_in_block and 2 <= L.block <= len(self.CL_F) - 2)
-                    if g.split and fform and not fwd_fused and _project_combine(self, L, g, graphs, x_shift, False):
-                        wc.get((L.ci, "wcat"), W, lambda: _wcat_operands(W3))
-                    elif g.split and fform and not fwd_fused:
-                        wc.get((L.ci, "split_fwd"), W,
-                               lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
-                    elif not fwd_fused and L.Fin % 32 == 0 and L.Fout % 32 == 0:
-                        wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
-                    if not bwd_fused and fform:
-                        if g.split:
-                            wc.get((L.ci, "split_bwd"), W,
-                                   lambda: ops.split_operands(W3, L.Fout, L.Fin, g.fake_a, g.fake_b))
-                        else:
-                            wc.get((L.ci, "w3x"), W, lambda: ops.weight_split(W3))
-                self._prefetch_event = side.record_event()
 
     def forward(self, x):
         _, params = self._param_list()

@@ -94,29 +94,19 @@ def _timed(name, work):
     return _NOB if TIMER is None else TIMER.bracket(name + getattr(_tls, "phase", ""), work)
 
 
+# Kernel-variant knobs (environment, read once).  The defaults are the measured-fastest forms;
+# the other settings exist as the INDEPENDENT kernel set of the parity tests and as A/B forms of the algebraic shortcuts.
+# Variants measured and removed in round 3 (results in DESIGN.md section 6): the 4-wave / 3-chunk-ring contractions, the
+# BatchNorm-backward reduction in the contraction epilogue, the project-then-combine forward of un-pooled convs, operand
+# prefetch on a helper stream, the gather-in-GEMM f32 kernel.
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
-DW_SIDE_STREAM = _os.environ.get("P2M_DW_SIDE_STREAM", "1") == "1"
+DW_SIDE_STREAM = True      # weight-gradient contractions on a side stream (nothing downstream in backward reads them)
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
 PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
-# forward of un-pooled convs in project-then-combine form (include/p2m.h): the contraction at the coarse resolution.
-# OFF by default: measured 5 510 vs 5 584 meshes/s (train) and 4.04 vs 4.13 ms (inference, B=64) on the same box -- the
-# contraction saves 0.8 ms, but the combine has to stage Z1 | Z2 rows twice as wide as the x rows the basis kernel
-# stages (+1.1 ms); as an opt-in it is covered by the A/B parity test
-PROJECT_COMBINE = _os.environ.get("P2M_PROJECT_COMBINE", "0") == "1"
-# derived weight operands of a train step built on the helper stream under PoseNet (Pose2Mesh.prefetch_operands).
-# OFF by default: measured neutral (5 677 / 5 690 with, 5 704 / 5 706 meshes/s without, same box) -- the ~110 tiny
-# launches cost the in-order main stream less than their stand-alone durations suggest
-PREFETCH_OPERANDS = _os.environ.get("P2M_PREFETCH", "0") == "1"
-# the BatchNorm-backward reduction of a layer in the epilogue of the contraction that produces its incoming gradient
-# (p2m_gemm_planes_rows_bnbwd).  OFF by default: measured 5 330 vs 5 660 meshes/s -- the epilogue's 4-byte reads of the
-# layer's raw input cost the contraction more (+4.5 ms) than the separate streaming pass they replace (3.3 ms)
-BN_BWD_IN_EPILOGUE = _os.environ.get("P2M_BN_BWD_EPILOGUE", "0") == "1"
 # classes of identical fake rows inside the coarse-to-fine stack (include/p2m.h): only one representative of every run of
 # identical padding rows is computed; 0 = every row (the A/B form)
 CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
-
-
 # Chebyshev basis inside the contraction (p2m_cheb_tile_gemm, include/p2m.h): the real rows of a conv on a level with a
 # tile plan in ONE kernel, no T1 / T2 planes in HBM.  OPT-IN: correct (op and network parity tests) and it removes the
 # plane traffic, but measured slower than basis kernel + plane contraction on MI355X -- 51.2 vs 43.5 ms per train step,
@@ -347,7 +337,7 @@ def bump_weight_epoch():
 class WeightCache:
     def __init__(self):
         self._d = {}
-        self.builds = 0          # builder calls so far (tests: a prefetched step builds nothing in its forward / backward)
+        self.builds = 0          # builder calls so far
 
     def get(self, key, W, builder):
         """W: the source tensor, or a tuple of source tensors."""
@@ -367,10 +357,8 @@ class WeightCache:
 
 
 def gemm_kernel_name():
-    """Name prefix of the plane-contraction kernel the current knobs select (rocprof kernel names start with it)."""
-    if GEMM_ARITH != "bf16x3":
-        return "k_gemm_planes<"
-    return "k_gemm_planes_ws" if _os.environ.get("P2M_GEMM_WS", "2") != "0" else "k_gemm_planes_bx"
+    """Name prefix of the plane-contraction kernel the current arithmetic selects (rocprof kernel names start with it)."""
+    return "k_gemm_planes_ws" if GEMM_ARITH == "bf16x3" else "k_gemm_planes<"
 
 
 def arith_code():
@@ -389,12 +377,9 @@ def weight_split(Bm):
     return Bx
 
 
-def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None,
-                     bn=None):
-    """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake).  Returns stats or None.
-    Bx: the pre-split copy of Bm (weight_split) when the caller has it cached.
-    bn = (y, co, part): C is the gradient flowing into the BatchNorm + ReLU layer with raw input y and coefficients co;
-    the epilogue also writes that layer's backward-reduction partials into part[B * tiles][2][N] (bn_part_rows)."""
+def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None):
+    """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake, 3 / 4 the paired sets).  Returns stats
+    or None.  Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
     n = g.set_size(row_set)
     st = None
     weighted = stats and row_set == 2 and g.classes     # representatives count once per class member: separate pass
@@ -404,14 +389,6 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     fl = 2.0 * B * n * len(A) * Ka * N
     # algorithmic HBM bytes: every A plane row once, the output once (weights come from L2)
-    if bn is not None:
-        with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + 2 * N))):
-            check(_lib.hip().p2m_gemm_planes_rows_bnbwd(
-                g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift, int(compact), _p(_req(Bm, "B")),
-                _p(Bx if Bx is not None else weight_split(Bm)), _p(addend if addend is None else _req(addend, "addend")),
-                _p(C), N, _p(_req(bn[0], "bn y")), _p(_req(bn[1], "bn coefficients")), _p(bn[2]), _stream()),
-                "p2m_gemm_planes_rows_bnbwd")
-        return None
     with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + N))):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
                                               int(compact), _p(_req(Bm, "B")),
@@ -461,68 +438,6 @@ def cheb_basis_pair(g, G, B, F):
     return P1, P2
 
 
-def bn_part_rows(g, sets, B, N, device):
-    """Partials buffer of a BatchNorm-backward reduction fused into the two row-set launches of one contraction:
-    (whole buffer, slice of the first set, slice of the second set)."""
-    lib = _lib.hip()
-    t = [B * int(lib.p2m_rows_tiles_per_sample(g.handle, rs)) if g.set_size(rs) > 0 else 0 for rs in sets]
-    part = torch.empty((t[0] + t[1], 2, N), device=device, dtype=torch.float32)
-    return part, part[:t[0]], part[t[0]:]
-
-
-def conv_project(gc, B, Xc, Ka, Wcat, Wcatx, N3, real_only=False):
-    """Z = Xc [W0 | W1 | W2] over the rows of the coarse level gc that the fine level reads (real vertices, plus the fake
-    ones / their representatives unless real_only): [B * gc.V, N3]."""
-    Mc = B * gc.V
-    if gc.split:
-        Z = torch.empty((Mc, N3), device=Xc.device, dtype=torch.float32)
-        for rs in ((1,) if real_only else (1, 2)):
-            gemm_planes_rows(gc, rs, B, [Xc], Ka, 0, False, Wcat, None, None, Z, N3, Bx=Wcatx)
-        return Z
-    (Z,), _ = gemm_planes([Xc], Ka, 0, Wcat, None, Mc, N3, 1, False, Bx=Wcatx)
-    return Z
-
-
-def cheb_project_combine(g, gc, Z, bias, B, N, stats=False, act=None):
-    """Real rows of the un-pooled conv from Z (conv_project): Y [B*V, N] (other rows untouched), BatchNorm partials per
-    (sample, tile of the in_shift = 1 plan) when stats, fused eval BatchNorm + ReLU when act = (scale, shift, relu)."""
-    Y = torch.empty((B * g.V, N), device=Z.device, dtype=torch.float32)
-    st = torch.empty((B * g.plan_tiles[1], 2, N), device=Z.device, dtype=torch.float32) if stats else None
-    moved = 4.0 * B * N * (g.n_real + 3.0 * gc.n_real)           # Y rows written, the Z rows of the real parents read
-    with _timed("cheb_basis_fwd", (moved, 12.0 * B * g.V * N)):
-        check(_lib.hip().p2m_cheb_project_combine(g.handle, _p(_req(Z, "Z")), _p(bias if bias is None else _req(bias, "bias")),
-                                                  _p(None if act is None else act[0]),
-                                                  _p(None if act is None else act[1]), int(bool(act and act[2])),
-                                                  _p(Y), _p(st), B, N, _stream()), "p2m_cheb_project_combine")
-    return Y, st
-
-
-def cheb_project_combine_fake(g, Z, bias, Y, B, N, stats=False):
-    """Fake rows (row set 2; with classes: the representatives) of the same conv; returns their weighted partials."""
-    if g.n_fake == 0:
-        return None
-    check(_lib.hip().p2m_cheb_project_combine_fake(g.handle, _p(_req(Z, "Z")), _p(bias if bias is None else _req(bias, "bias")),
-                                                   _p(Y), B, N, _stream()), "p2m_cheb_project_combine_fake")
-    if not stats:
-        return None
-    if not g.classes:
-        raise P2MError("BatchNorm partials of the fake rows of a project-then-combine conv need classes")
-    tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, 2))
-    st = torch.empty((B * tps, 2, N), device=Y.device, dtype=torch.float32)
-    check(_lib.hip().p2m_stats_rows_w(g.handle, _p(Y), B, N, _p(st), _stream()), "p2m_stats_rows_w")
-    return st
-
-
-def bn_finalize_combine(g, B, st_real, st_fake, gamma, beta, running_mean, running_var, momentum, eps):
-    N = gamma.shape[0]
-    co = torch.empty((4, N), device=gamma.device, dtype=torch.float32)
-    check(_lib.hip().p2m_bn_finalize_combine(g.handle, _p(st_real), _p(st_fake), B, _p(_req(gamma, "bn.weight")),
-                                             _p(_req(beta, "bn.bias")), _p(running_mean), _p(running_var),
-                                             float(momentum), float(eps), _p(co[0]), _p(co[1]), _p(co[2]), _p(co[3]), N,
-                                             _stream()), "p2m_bn_finalize_combine")
-    return co
-
-
 def tile_gemm_ok(g, plan, Ka, N):
     """True when the real rows of this conv can take the basis-inside-the-contraction kernel."""
     return bool(TILE_GEMM and GEMM_ARITH == "bf16x3" and _lib.hip().p2m_cheb_tile_gemm_supported(g.handle, plan, Ka, N))
@@ -558,29 +473,24 @@ def bn_finalize_tiles(g, plan, B, st_real, st_fake, gamma, beta, running_mean, r
     return co
 
 
-def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, bn=None):
+def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
     """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
     C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
     P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
     if P0 is None:
         P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
     Bx, We, Wex = operands
-    if bn is None and tile_gemm_ok(g, 2, Ka, N):
+    if tile_gemm_ok(g, 2, Ka, N):
         # planes S L g, S L2 g formed inside the contraction; written out (compact) only for the weight gradient
         _, (P1c, P2c) = cheb_tile_gemm(g, 2, Gy, P0, Ka, Bx, None, addend, C, N, B, want_planes=True)
-        gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
-        return P0, P1c, P2c, None
-    P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
-    part, pa, pb = bn_part_rows(g, (3, 4), B, N, C.device) if bn is not None else (None, None, None)
-    gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx,
-                     bn=None if bn is None else (bn[0], bn[1], pa))
-    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex,
-                     bn=None if bn is None else (bn[0], bn[1], pb))
-    return P0, P1c, P2c, part
+    else:
+        P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
+        gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
+    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
+    return P0, P1c, P2c
 
 
-def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, bn=None,
-               want_planes=True):
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, want_planes=True):
     """One split contraction: the real-vertex rows [X | L X | L2 X] Bm (K = 3*Ka), then the fake-vertex GEMM (K = Ka,
     W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's basis on a side
     stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
@@ -588,20 +498,13 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
     (p2m_bn_finalize_split)."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
-    if bn is None and tile_gemm_ok(g, a0_shift, Ka, N):
+    if tile_gemm_ok(g, a0_shift, Ka, N):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
                                      want_planes=want_planes)
         st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
         T1c, T2c = planes if planes is not None else (None, None)
         return T1c, T2c, st1, st2, True
     T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
-    if bn is not None:          # backward use: bn = (y, co) of the layer C flows into; returns the reduction partials
-        part, pa, pb = bn_part_rows(g, (1, 2), B, N, C.device)
-        gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, False, Bx=Bx,
-                         bn=(bn[0], bn[1], pa))
-        gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, False, Bx=Wex,
-                         bn=(bn[0], bn[1], pb))
-        return T1c, T2c, part, None, False
     st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx)
     st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
     return T1c, T2c, st1, st2, False
@@ -609,7 +512,7 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 
 # blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,
 # 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce)
-TN_TARGET_BLOCKS = int(_os.environ.get("P2M_TN_TARGET_BLOCKS", "768"))
+TN_TARGET_BLOCKS = 768
 
 
 def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
@@ -666,40 +569,6 @@ def weight_pack(W, Fin, K, need_w2=True, need_w3=False):
     check(_lib.hip().p2m_weight_pack(_p(_req(W, "weight")), _p(Wt), _p(W2), _p(W3), Fout, Fin, K, _stream()),
           "p2m_weight_pack")
     return Wt, W2, W3
-
-
-def cheb_gemm_fused(g, A, Ka, a_shift, Bm, bias, addend, N, B, pair_out=False, stats=False, want_planes=False):
-    """C = [A | L A | L2 A] Bm (+bias)(+addend).  Returns (C, stats or None, (E1, E2) or None)."""
-    M = B * g.V
-    dev = A.device
-    C = torch.empty((M >> 1 if pair_out else M, N), device=dev, dtype=torch.float32)
-    tr = int(_lib.hip().p2m_fused_stats_tile_rows(N))
-    st = torch.empty(((M + tr - 1) // tr + 4, 2, N), device=dev, dtype=torch.float32) if stats else None
-    E1 = torch.empty((M, Ka), device=dev, dtype=torch.float32) if want_planes else None
-    E2 = torch.empty((M, Ka), device=dev, dtype=torch.float32) if want_planes else None
-    Bpk = torch.empty_like(_req(Bm, "B"))                    # fragment-major copy of the (tiny) weight matrix
-    check(_lib.hip().p2m_frag_pack(_p(Bm), _p(Bpk), 3 * Ka, N, _stream()), "p2m_frag_pack")
-    with _timed("cheb_gemm_fused", 2.0 * M * 3 * Ka * N):
-        check(_lib.hip().p2m_cheb_gemm_fused(g.handle, _p(_req(A, "A")), Ka, a_shift, _p(Bpk),
-                                             _p(bias if bias is None else _req(bias, "bias")),
-                                             _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
-                                             int(pair_out), _p(st), _p(E1), _p(E2), B, _stream()),
-              "p2m_cheb_gemm_fused")
-    return C, st, ((E1, E2) if want_planes else None)
-
-
-def fused_stats_tile_rows(N):
-    return int(_lib.hip().p2m_fused_stats_tile_rows(N))
-
-
-# The fused (gather-in-GEMM) kernel is correct and tested, but on the coarsening-tree vertex order its gathers
-# miss L2 35 % of the time and it only breaks even with basis-kernel + plane-GEMM (DESIGN.md section 6), so the
-# network uses it only when asked: P2M_FUSED=1.
-USE_FUSED = _os.environ.get("P2M_FUSED", "0") == "1"
-
-
-def fused_supported(Ka, N):
-    return USE_FUSED and Ka % 32 == 0 and N in (64, 128, 256)
 
 
 def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend=None, pair_out=False, Bx=None,
@@ -778,8 +647,7 @@ def weight_grad_unpack(P, Pdb, nchunks, Fout, Fin, K, dW=None, db=None, layout=0
 
 
 def bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps, tile_rows=None):
-    """stats: per-tile partials [>= ceil(M/tile_rows)][2][N] from p2m_gemm_planes (128-row tiles) or
-    p2m_cheb_gemm_fused (64-row tiles)."""
+    """stats: per-tile partials [>= ceil(M/tile_rows)][2][N] from p2m_gemm_planes (128-row tiles)."""
     N = gamma.shape[0]
     if tile_rows is None:
         tile_rows = stats_tile_rows()
@@ -815,28 +683,23 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None):
 
 
 def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False,
-                classes=None, zero_holes=False, part=None):
+                classes=None, zero_holes=False):
     """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
     pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
     (gy, dgamma, dbeta, pair_gx or None, pair_gy or None).
     classes: the level's DeviceGraph (include/p2m.h "classes"): holes are skipped -- not read, not written; zero_holes:
     the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows)."""
     lib = _lib.hip()
-    have_part = part is not None        # the reduction already ran in the epilogue of the contraction that produced gx
     cls = classes.handle if (classes is not None and classes.classes) else None
-    if have_part:
-        nblk = part.shape[0]
-    else:
-        nblk = int(lib.p2m_bn_bwd_blocks(M, F) if cls is None else lib.p2m_bn_bwd_blocks_classes(cls, M, F))
-        part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
+    nblk = int(lib.p2m_bn_bwd_blocks(M, F) if cls is None else lib.p2m_bn_bwd_blocks_classes(cls, M, F))
+    part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
     acc = 1 if dgamma is not None else 0
     if dgamma is None:
         dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
         dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
-    if not have_part:
-        check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
-                                    int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
+    check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
+                                int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     alloc = torch.zeros if (zero_holes and cls is not None) else torch.empty

@@ -26,7 +26,6 @@ class FlatPose2Mesh(nn.Module):
         return self
 
     def forward(self, pose2d):
-        self.pose2mesh.prefetch_operands()       # the step's derived weight operands, on the helper stream, under PoseNet
         pose3d = self.pose_lifter(pose2d.view(len(pose2d), -1)).reshape(-1, self.num_joint, 3)
         # MeshNet gets no gradient path into PoseNet (pose2mesh_net.py:19)
         pose_combine = torch.cat((pose2d, pose3d.detach() / 1000), dim=2)

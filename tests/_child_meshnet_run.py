@@ -1,5 +1,5 @@
 """Helper (not a pytest file): one MeshNet forward+backward on the GPU under whatever kernel-variant environment the
-parent test set (P2M_GEMM_ARITH, P2M_SPLIT_FAKE, P2M_BASIS_TILED, P2M_GEMM_WS ...), results to an .npz.
+parent test set (P2M_GEMM_ARITH, P2M_SPLIT_FAKE, P2M_BASIS_TILED, P2M_TILE_GEMM ...), results to an .npz.
 usage: python _child_meshnet_run.py OUT.npz JOINT_SET B MODE(train|eval) WSEED XSEED GSEED"""
 import os
 import sys
@@ -50,4 +50,4 @@ if __name__ == "__main__":
     res = run(joint_set, int(B), mode, int(wseed), int(xseed), int(gseed), tap=os.environ.get("P2M_TEST_TAP") == "1")
     np.savez(out_path, **res)
     print("child ok", {k: os.environ.get(k) for k in ("P2M_GEMM_ARITH", "P2M_SPLIT_FAKE", "P2M_BASIS_TILED",
-                                                      "P2M_GEMM_WS")})
+                                                      "P2M_TILE_GEMM")})

@@ -210,51 +210,6 @@ def test_bn_relu_residual_fwd_bwd(ops, M, Fd, Fres, rshift, training):
         assert (dst.cpu() - rd.grad[:Mr]).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("V,Ka,N,shift,pair,B", [(96, 64, 128, 0, False, 5), (184, 256, 256, 1, False, 3),
-                                                 (1472, 128, 128, 1, True, 2), (736, 128, 64, 0, False, 3),
-                                                 (368, 32, 64, 0, True, 4), (17, 64, 64, 0, False, 9),
-                                                 (1472, 256, 128, 0, True, 2)])
-def test_cheb_gemm_fused(ops, V, Ka, N, shift, pair, B):
-    """C = [A | L A | L2 A] Bm + bias (+addend) with BatchNorm partials / gathered planes / pair-sum output,
-    against fp64 dense algebra (cheby_graph_conv.py:16-37 and its backward form)."""
-    L = _rand_graph(V, V + 1)
-    g = ops.DeviceGraph(L, "cuda:0")
-    Ld = torch.from_numpy(L.toarray())
-    L2 = 2 * Ld @ Ld - torch.eye(V, dtype=torch.float64)
-    gen = torch.Generator().manual_seed(V + Ka + N)
-    As = torch.randn(B, V >> shift, Ka, generator=gen)
-    A = As.repeat_interleave(1 << shift, dim=1).double()
-    Bm = torch.randn(3 * Ka, N, generator=gen) / np.sqrt(3 * Ka)
-    bias = torch.randn(N, generator=gen)
-    add = torch.randn(B * V, N, generator=gen)
-    Z = torch.cat([A, torch.einsum("vw,bwf->bvf", Ld, A), torch.einsum("vw,bwf->bvf", L2, A)], dim=2)
-    ref = (Z.reshape(B * V, 3 * Ka) @ Bm.double()) + bias.double() + add.double()
-    M = B * V
-    want_planes = (shift == 0)
-    C, st, planes = ops.cheb_gemm_fused(g, As.cuda().view(-1, Ka).contiguous(), Ka, shift, Bm.cuda(), bias.cuda(),
-                                        add.cuda(), N, B, pair_out=pair, stats=not pair, want_planes=want_planes)
-    torch.cuda.synchronize()
-    if pair:
-        refp = ref.view(M // 2, 2, N).sum(1)
-        assert (C.cpu() - refp).abs().max() < 5e-5
-    else:
-        assert (C.cpu() - ref).abs().max() < 3e-5
-        tr = ops.fused_stats_tile_rows(N)
-        nt = (M + tr - 1) // tr
-        for t in range(nt):
-            blk = ref[t * tr:(t + 1) * tr]
-            assert (st[t, 0].cpu() - blk.sum(0)).abs().max() < 1e-3
-            assert (st[t, 1].cpu() - ((blk - blk.mean(0)) ** 2).sum(0)).abs().max() < 2e-3
-        # the finalize kernel digests these partials
-        gamma, beta = torch.ones(N).cuda(), torch.zeros(N).cuda()
-        co = ops.bn_finalize(st, M, gamma, beta, None, None, 0.1, 1e-5, tr)
-        assert (co[0].cpu() - ref.mean(0)).abs().max() < 1e-5
-        assert (co[1].cpu() - 1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-4
-    if want_planes:
-        assert (planes[0].cpu().view(B, V, Ka) - Z[..., Ka:2 * Ka]).abs().max() < 5e-6
-        assert (planes[1].cpu().view(B, V, Ka) - Z[..., 2 * Ka:]).abs().max() < 1e-5
-
-
 def test_gemm_tn_with_planes_and_layout1(ops, arith):
     """dW = X^T [g | E1 | E2] unpacked to nn.Linear layout (the fused backward's weight gradient)."""
     M, Fin, Fout = 1500, 64, 128
@@ -552,19 +507,17 @@ def _real_ids(L):
     return np.where(~((deg == 1) & (L.indices[L.indptr[:-1].clip(max=L.nnz - 1)] == np.arange(L.shape[0]))))[0]
 
 
-@pytest.mark.parametrize("env", [{"P2M_GEMM_WS": "0", "P2M_BASIS_TILED": "0"}, {"P2M_GEMM_WS": "1"}])
-def test_non_default_kernel_variants_in_a_subprocess(env, hip_libs):
-    """The kernel variant knobs are read once per process (no mutable global state in the library), so the non-default
-    variants - 4-wave contractions k_gemm_planes_bx / k_gemm_tn_bx, row-per-wave basis kernel for the real rows, the
-    3-chunk-ring wave-specialised contraction - run the contraction / basis / split tests in a child process."""
+def test_row_kernel_basis_variant_in_a_subprocess(hip_libs):
+    """P2M_BASIS_TILED is read once per process by the library (no mutable global state), so the row-per-wave basis kernel
+    for the real rows of split levels - part of the independent kernel set of the parity tests - runs the basis / split
+    tests in a child process."""
     import os
     import subprocess
     import sys
-    child_env = dict(os.environ, **env)
+    child_env = dict(os.environ, P2M_BASIS_TILED="0")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-m", "gpu",
-                        "-p", "no:cacheprovider", "-k",
-                        "gemm_planes or gemm_tn or bf16x3 or fake_vertex or tiled_basis or cheb_basis"],
+                        "-p", "no:cacheprovider", "-k", "fake_vertex or tiled_basis or cheb_basis or paired_backward"],
                        env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

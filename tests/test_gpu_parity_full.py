@@ -117,7 +117,7 @@ def _kink_resolved_check(tag, joint_set, B, wseed, xseed, gseed, dtype=torch.flo
     return hip, st
 
 
-INDEPENDENT_SET = dict(P2M_GEMM_ARITH="f32", P2M_SPLIT_FAKE="0", P2M_BASIS_TILED="0", P2M_GEMM_WS="0", P2M_TN_WS="0")
+INDEPENDENT_SET = dict(P2M_GEMM_ARITH="f32", P2M_SPLIT_FAKE="0", P2M_BASIS_TILED="0")
 
 
 def _child_run(tmp_path, env, joint_set, B, mode, wseed, xseed, gseed):
@@ -246,9 +246,8 @@ def test_baseline_sizes_default_vs_independent_kernel_set(hip_libs, tmp_path, jo
 def test_algebraic_shortcuts_against_their_plain_forms(hip_libs, tmp_path, env, fwd_bitwise):
     """The default path's exact algebraic shortcuts -- classes of identical fake rows (only one representative of a run of
     identical padding rows is computed), the backward of un-pooled convs at the coarse resolution -- and the opt-in
-    project-then-combine forward of un-pooled convs and the opt-in
-    epilogue form of the BatchNorm-backward reduction, each against the same network with the knob flipped (child
-    process; human36, B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
+    basis-inside-the-contraction kernel, each against the same network with the knob flipped (child process; human36,
+    B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
     out = str(tmp_path / "plain.npz")
     r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, "human36", "3", "train",
                         "13", "21", "5"], env=dict(os.environ, P2M_TEST_TAP="1", **env), capture_output=True,

@@ -139,37 +139,6 @@ def test_in_place_gradient_accumulation_is_bitwise_the_autograd_path(hip_libs):
     assert float(flats[0].abs().max()) > 0
 
 
-def test_prefetched_operands_leave_nothing_to_build_and_change_nothing(hip_libs, monkeypatch):
-    """Pose2Mesh.prefetch_operands (helper stream, under PoseNet in FlatPose2Mesh.forward) builds exactly the derived
-    weight operands the step's forward and backward ask for, and the step's results are bitwise those without it."""
-    import helpers
-    from pose2mesh_release_amd import meshnet, ops
-    monkeypatch.setattr(ops, "PREFETCH_OPERANDS", True)          # opt-in knob (P2M_PREFETCH=1)
-    gL, _, _ = helpers.golden_graphs("human36")
-    outs = []
-    for prefetch in (False, True):
-        net = meshnet.get_model(5, 3, gL, mano=False)
-        net.load_state_dict(helpers.numpy_state(net.state_dict(), 3))
-        net = net.cuda().train()
-        x = helpers.meshnet_input(3, 17, seed=4).cuda()
-        w = torch.randn(3, gL[0].shape[0], 3, generator=torch.Generator().manual_seed(1)).cuda()
-        (net(x) * w).sum().backward()               # step 1: graphs, caches
-        for p in net.parameters():
-            p.grad = None
-            p.data.mul_(1.0)                          # bumps Tensor._version: every cached operand is stale now
-        if prefetch:
-            net.prefetch_operands()
-            before = net._weight_cache.builds
-        y = net(x)
-        (y * w).sum().backward()
-        if prefetch:
-            assert net._weight_cache.builds == before, "the forward / backward had to build an operand"
-        torch.cuda.synchronize()
-        outs.append([y.detach()] + [p.grad for p in net.parameters()])
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("opt_name", ["adam", "rmsprop"])
 def test_graphed_train_step_is_bitwise_the_eager_loop(hip_libs, opt_name):
     """train.GraphedTrainStep: 3 eager warm-up steps, capture, 3 replays (with an lr change in between, as MultiStepLR

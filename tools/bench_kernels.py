@@ -60,20 +60,6 @@ if "bn" in which:
         ms = timeit(lambda: ops.bn_relu_bwd(gx, y, co, gamma, True, True, M, F))
         ms2 = timeit(lambda: ops.bn_act_fwd(y, co, True, gx, F, 0, M, F))
         print(f"bn V={V} F={F}: bwd(reduce+fin+apply) {ms:7.3f} ms ({5*4.0*M*F/ms/1e6:7.1f} GB/s) | act_fwd+res {ms2:7.3f} ms ({3*4.0*M*F/ms2/1e6:7.1f} GB/s)", flush=True)
-if "fused" in which:
-    for V, Fin, Fout, sh in [(11776, 128, 128, 0), (11776, 128, 128, 1), (11776, 128, 64, 0), (2944, 256, 128, 1), (1472, 256, 256, 0), (184, 256, 256, 1)]:
-        g = graphs[V]
-        M = B * V
-        X = torch.randn(B * (V >> sh), Fin, device=dev)
-        W = torch.randn(3 * Fin, Fout, device=dev)
-        bias = torch.randn(Fout, device=dev)
-        ms = timeit(lambda: ops.cheb_gemm_fused(g, X, Fin, sh, W, bias, None, Fout, B, stats=True))
-        fl = 2.0 * M * 3 * Fin * Fout
-        ms2 = 0.0
-        if sh == 0:
-            ms2 = timeit(lambda: ops.cheb_gemm_fused(g, X, Fin, 0, W, None, None, Fout, B, want_planes=True))
-        print(f"fused V={V:6d} {Fin}->{Fout} sh={sh}: fwd {ms:7.3f} ms {fl/ms/1e9:6.1f} TF | +planes {ms2:7.3f} ms", flush=True)
-        del X
 if "rcm" in which:
     import numpy as np, scipy.sparse as sp
     from scipy.sparse.csgraph import reverse_cuthill_mckee

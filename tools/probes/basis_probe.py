@@ -1,6 +1,5 @@
-"""Basis stage of the split SMPL-like levels at B=256 for timing / PMC passes: real-row kernel (k_basis_tile_w /
-k_basis_tile / k_basis_fwd with ids, selected by P2M_BASIS_TILE_W / P2M_BASIS_TILED / P2M_BASIS_SPB) per
-(level, F, shift).   python tools/probes/basis_probe.py [all|finest] [B]"""
+"""Basis stage of the split SMPL-like levels at B=256 for timing / PMC passes: real-row kernel (k_basis_tile, or
+k_basis_fwd with ids under P2M_BASIS_TILED=0) per (level, F, shift).   python tools/probes/basis_probe.py [all|finest] [B]"""
 import os
 import sys
 
@@ -51,5 +50,4 @@ for lvl, F, shift in CASES:
         moved = 4.0 * B * F * (g.V + 2.0 * g.n_pair_real)
         print(f"V={g.V:6d} pair={g.n_pair_real:5d} F={F:3d} paired : {ms:7.3f} ms  {moved / ms / 1e6:7.0f} GB/s moved", flush=True)
         del G
-print(f"TOTAL {tot_ms:.3f} ms  {tot_bytes / tot_ms / 1e6:.0f} GB/s moved   [TILE_W={os.environ.get('P2M_BASIS_TILE_W', '1')} "
-      f"SPB={os.environ.get('P2M_BASIS_SPB', '8')} TILED={os.environ.get('P2M_BASIS_TILED', '1')}]")
+print(f"TOTAL {tot_ms:.3f} ms  {tot_bytes / tot_ms / 1e6:.0f} GB/s moved   [TILED={os.environ.get('P2M_BASIS_TILED', '1')}]")
