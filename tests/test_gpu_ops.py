@@ -378,7 +378,7 @@ def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, monkeypatc
     opb = ops.split_operands(W3, Fout, Fin, g.fake_a, g.fake_b)
     dX = torch.full((Mc, Fin), float("nan"), device="cuda")
     add = ops.pair_sum(Gres, Mc, Fin) if fuse else None
-    P0, P1c, P2c, _ = ops.conv_pair(g, B, gy, Fout, W3, add, dX, Fin, opb)
+    P0, P1c, P2c = ops.conv_pair(g, B, gy, Fout, W3, add, dX, Fin, opb)
     assert torch.isfinite(dX).all()
     assert (dX - dX_ref).abs().max() < 2e-5 * max(1.0, dX_ref.abs().max().item())
     Q1, Qb1, n1 = ops.gemm_tn_rows(g, 3, B, Xc, Fin, 0, [P0, P1c, P2c], Fout, True)
