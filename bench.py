@@ -454,6 +454,26 @@ def main():
                         "achieved": round(achf, 2), "frac": round(achf / peak, 4),
                         "frac_of_f32_mfma_peak": round(achf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "launches": f["launches"], "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
+            tg = merged("cheb_tile_gemm", "cheb_tile_gemm_bwd")
+            if tg and tg["ms"] > 0:
+                # basis inside the contraction (k_cheb_tile_gemm): SURVEY 8(d)'s rule for a fused kernel -- the larger of
+                # dense FLOPs / MFMA peak and 4 V (Fin + Fout) bytes / 8 TB/s bounds it; both fractions are reported
+                peak_t = PEAK_BF16_MFMA_TFLOPS / 6.0
+                ach = tg["work"] / (tg["ms"] * 1e-3) / 1e12
+                gbs = tg["bytes"] / (tg["ms"] * 1e-3) / 1e9
+                tr, tr_src = _traffic_for("k_cheb_tile_gemm")
+                line["roofline_fused"] = {
+                    "bound": "mfma", "kernel": "k_cheb_tile_gemm (Chebyshev planes formed per tile in LDS, bf16x3 MFMA; "
+                                               "no T1/T2 planes in HBM)",
+                    "achieved": round(ach, 2), "peak": round(peak_t, 1), "unit": "TFLOP/s", "frac": round(ach / peak_t, 4),
+                    "hbm_achieved_GBps": round(gbs, 1), "hbm_frac_of_8000": round(gbs / PEAK_HBM_GBPS, 4),
+                    "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                    "algorithmic_bytes_per_launch": round(tg["bytes"] / tg["launches"]),
+                    "traffic_over_algorithmic": None if tr is None else round(
+                        tr["hbm_bytes_per_launch"] / (tg["bytes"] / tg["launches"]), 3),
+                    "launches": tg["launches"], "avg_launch_ms": round(tg["ms"] / tg["launches"], 4),
+                    "note": "algorithmic bytes = 4 rows (Fin + Fout): the input rows once, the output once (SURVEY 8(d), "
+                            "fused rule); which launches take this kernel: ops.TILE_GEMM (P2M_TILE_GEMM, default auto)"}
             sp = merged("cheb_basis_fwd", "cheb_basis_fwd_bwd", "cheb_basis_bwd", "cheb_basis_bwd_bwd")
             if sp and sp["ms"] > 0:
                 # achieved = the bytes the launches have to move (real-vertex rows only: read X once at the stored

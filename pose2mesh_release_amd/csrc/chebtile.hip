@@ -40,7 +40,8 @@ constexpr int CT_LDA = CT_KC + 8;             // bf16 per row of the A image: 20
 constexpr int CT_SPAD = 32;                   // + 64 bytes per sample: the two samples of a 16-lane ds_write_b64 group
                                               // land on disjoint bank halves
 constexpr int CT_SLICE = CT_S * 32 * CT_LDA + CT_S * CT_SPAD;     // bf16 per slice image
-constexpr int CT_ECAP = TILE_ECAP + 3 * TILE_RMAX;                // entries of a tile, every row padded to a multiple of 4
+constexpr int CT_ECAP = TILE_ECAP + 3 * TILE_RMAX + 8;            // entries of a tile, every row padded to a multiple of 4,
+                                                                  // + slack for the gather's read-ahead
 constexpr int CT_AS_BYTES = 3 * CT_SLICE * 2;
 constexpr int CT_XS_BYTES = TILE_UCAP * CT_S * CT_CF * 4;
 constexpr int CT_ENT_BYTES = CT_ECAP * 16;
@@ -69,7 +70,10 @@ struct TileGemmArgs {
 
 // TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
 // the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
-template <int TM, int TN, int NPW>
+// MODE: what the epilogue does besides bias + store - compiled in, because an epilogue that tests addend / activation /
+// statistics pointers per element is ~2 900 instructions with 250 branches, and nothing covers it (one block per CU)
+enum { CT_PLAIN = 0, CT_STATS = 1, CT_ADDEND = 2, CT_ACT = 3 };
+template <int TM, int TN, int NPW, int MODE>
 __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gemm(TileGemmArgs g) {
   constexpr int NT = 256 + 64 * NPW;          // 4 consumer waves + NPW producer waves
   constexpr int WM = CT_S / TM;               // consumer waves along the samples
@@ -203,13 +207,17 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
         const int i = ri[ps];
         const int e = rowoff[i + 1];
-        for (int j = rowoff[i]; j < e; j += 4) {
-          f32x4 en[4], x[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) en[k] = ents[j + k];
+        int j = rowoff[i];
+        f32x4 en[4];                                    // the block of 4 entries being used; the next one is fetched under
+#pragma unroll                                          // its FMAs (reading past the row's end is harmless: the table is
+        for (int k = 0; k < 4; k++) en[k] = ents[j + k];   // contiguous and has 4 entries of slack)
+        for (; j < e; j += 4) {
+          f32x4 x[4], nn[4];
 #pragma unroll
           for (int k = 0; k < 4; k++)
             x[k] = *reinterpret_cast<const f32x4*>(xs + (unsigned)__float_as_int(en[k][2]) + lane_off);
+#pragma unroll
+          for (int k = 0; k < 4; k++) nn[k] = ents[j + 4 + k];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -218,6 +226,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
               t2[c] = fmaf(en[k][1], x[k][c], t2[c]);
             }
           }
+#pragma unroll
+          for (int k = 0; k < 4; k++) en[k] = nn[k];
         }
         if (g.E1 != nullptr && i < R) {
           const int b = grp * CT_S + s;
@@ -324,66 +334,101 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
                                                         //        for, but s_barrier is block-wide)
       }
       if (fc == nchunks - 1) {
-        // ---- epilogue of this sample group: bias, activation, addend, store, BatchNorm partials; then a fresh accumulator
-        float bias_v[TN], sc_v[TN], sh_v[TN];
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int n = wn * TN * 32 + j * 32 + l31;
-          bias_v[j] = g.bias != nullptr ? g.bias[n] : 0.f;
-          sc_v[j] = g.act_scale != nullptr ? g.act_scale[n] : 1.f;
-          sh_v[j] = g.act_scale != nullptr ? g.act_shift[n] : 0.f;
-        }
+        // ---- epilogue of this sample group: bias (+ activation / addend), store, BatchNorm partials; then a fresh accumulator
         int voff[16];                                   // element offset of this lane's 16 accumulator rows inside one
 #pragma unroll                                          // sample of C (-1: no such row); < 2^31: V * N <= 3 M elements
         for (int r = 0; r < 16; r++) {
           const int vid = rowvid[(r & 3) + 8 * (r >> 2) + 4 * lhi];
           voff[r] = vid < 0 ? -1 : vid * g.N;
         }
+        // pass 1: values, in registers (no branches)
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-          const int b = grp * CT_S + wm * TM + i;
-          const bool bok = b < g.B;
-          const long sbase = (long)(bok ? b : 0) * g.c_rows * g.N;
+        for (int j = 0; j < TN; j++) {
+          const int n = wn * TN * 32 + j * 32 + l31;
+          const float bias_v = g.bias != nullptr ? g.bias[n] : 0.f;
+          float sc_v = 1.f, sh_v = 0.f;
+          if (MODE == CT_ACT) { sc_v = g.act_scale[n]; sh_v = g.act_shift[n]; }
 #pragma unroll
-          for (int j = 0; j < TN; j++) {
-            const int n = wn * TN * 32 + j * 32 + l31;
-            float* Cb = g.C + sbase + n;
-            const float* Ab = g.addend != nullptr ? g.addend + sbase + n : nullptr;
-            float csum = 0.f;
+          for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-              const bool ok = bok && voff[r] >= 0;
-              float v = acc[i][j][r] + bias_v[j];
-              if (g.act_scale != nullptr) v = fmaf(v, sc_v[j], sh_v[j]);
-              if (g.act_relu) v = fmaxf(v, 0.f);
-              if (ok) {
-                if (Ab != nullptr) v += Ab[voff[r]];
-                Cb[voff[r]] = v;
-                csum += v;
+              float v = acc[i][j][r] + bias_v;
+              if (MODE == CT_ACT) {
+                v = fmaf(v, sc_v, sh_v);
+                if (g.act_relu) v = fmaxf(v, 0.f);
               }
-              acc[i][j][r] = ok ? v : 0.f;
+              acc[i][j][r] = v;
             }
-            if (g.stats != nullptr) {
-              // column sums over the tile's rows of this sample: the other 16 rows sit in lane ^ 32
+        }
+        // pass 2: stores, accumulator row by accumulator row: the row-validity mask is the same for every tile, a
+        // sample's validity is wave-uniform
+        const int b0s = grp * CT_S + wm * TM;
+        float* Cb[TM][TN];
+        const float* Ab[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const long sbase = (long)(b0s + i < g.B ? b0s + i : 0) * g.c_rows * g.N;
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            Cb[i][j] = g.C + sbase + wn * TN * 32 + j * 32 + l31;
+            Ab[i][j] = MODE == CT_ADDEND ? g.addend + sbase + wn * TN * 32 + j * 32 + l31 : nullptr;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          if (voff[r] >= 0) {
+            if (MODE == CT_ADDEND) {
+              float ad[TM][TN];
+#pragma unroll
+              for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) ad[i][j] = b0s + i < g.B ? Ab[i][j][voff[r]] : 0.f;
+#pragma unroll
+              for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j][r] += ad[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+              if (b0s + i < g.B) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) Cb[i][j][voff[r]] = acc[i][j][r];
+              }
+            }
+          }
+        }
+        if (MODE == CT_STATS) {
+          // column sums over the tile's rows of each sample: the other 16 rows sit in lane ^ 32
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+              float csum = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; r++) csum += voff[r] >= 0 ? acc[i][j][r] : 0.f;
               csum += __shfl_xor(csum, 32);
               const float mean = csum / (float)R;
               float m2 = 0.f;
 #pragma unroll
               for (int r = 0; r < 16; r++) {
                 const float d = acc[i][j][r] - mean;
-                if (voff[r] >= 0) m2 += d * d;
+                m2 += voff[r] >= 0 ? d * d : 0.f;
               }
               m2 += __shfl_xor(m2, 32);
-              if (lhi == 0 && bok) {
-                float* st = g.stats + ((long)b * pl.ntiles + tile) * 2 * g.N;
+              if (lhi == 0 && b0s + i < g.B) {
+                float* st = g.stats + ((long)(b0s + i) * pl.ntiles + tile) * 2 * g.N;
+                const int n = wn * TN * 32 + j * 32 + l31;
                 st[n] = csum;
                 st[g.N + n] = m2;
               }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-          }
-        }
         grp++;
       }
       fc = fcn;
@@ -395,19 +440,21 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 
 using namespace p2m;
 
-// gpb: sample groups a block walks.  Enough blocks for a few waves of the 256 CUs, as few table loads as possible.
+// gpb: sample groups a block walks (tables loaded once per block).  At least ~8 blocks per CU so that the last round of
+// blocks is well filled (measured over the 16 real-row shapes of a train step: gpb 16 / 8 / 4 / 2 -> 21.4 / 19.0 / 18.4 /
+// 18.0 ms; the finest level alone prefers 8 by 2 %).
 static int pick_gpb(int ntiles, int ngroups) {
   int gpb = 8;
-  while (gpb > 1 && (long)ntiles * cdiv(ngroups, gpb) < 4 * 256) gpb >>= 1;
+  while (gpb > 1 && (long)ntiles * cdiv(ngroups, gpb) < 8 * 256) gpb >>= 1;
   return gpb;
 }
 
-template <int TM, int TN, int NPW>
-static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
+template <int TM, int TN, int NPW, int MODE>
+static int launch_tile_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
   static bool attr_set = false;     // once per process and instantiation (never inside a stream capture: the first call
                                     // of every shape happens in the eager warm-up steps)
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW>,
+    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_BYTES);
     if (e != hipSuccess) {
       set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", CT_LDS_BYTES, hipGetErrorString(e));
@@ -417,8 +464,16 @@ static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
   }
   const int ngroups = cdiv(a.B, CT_S);
   const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
-  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW>), dim3(nblocks), dim3(256 + 64 * NPW), CT_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE>), dim3(nblocks), dim3(256 + 64 * NPW), CT_LDS_BYTES, s, a);
   return check_launch("cheb_tile_gemm");
+}
+
+template <int TM, int TN, int NPW>
+static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
+  if (a.stats != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_STATS>(a, s);
+  if (a.addend != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_ADDEND>(a, s);
+  if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT>(a, s);
+  return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN>(a, s);
 }
 
 extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, int32_t Ka, int32_t N) {
@@ -438,6 +493,8 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   P2M_CHECK_ARG((E1 == nullptr) == (E2 == nullptr), "E1 / E2 must both be given or both NULL");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
+  P2M_CHECK_ARG(!(addend && (stats || act_scale || act_relu)), "addend excludes stats and the fused activation");
+  P2M_CHECK_ARG(!(act_relu && !act_scale), "act_relu needs act_scale / act_shift");
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
   if (!p2m_cheb_tile_gemm_supported(gh, plan, Ka, N)) {
     set_error("p2m_cheb_tile_gemm: plan %d of this level / Ka = %d / N = %d is not supported (p2m_cheb_tile_gemm_supported)",

@@ -138,7 +138,7 @@ def _forward_inference(net, graphs, x, params):
             y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
             Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
             T1 = T2 = None
-            if ops.tile_gemm_ok(g, cur_shift, L.Fin, L.Fout):
+            if ops.tile_gemm_ok(g, cur_shift, L.Fin, L.Fout, B=B):
                 ops.cheb_tile_gemm(g, cur_shift, cur, cur, L.Fin, Wtx, bvec, None, y, L.Fout, B, act=act)
             else:
                 T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)

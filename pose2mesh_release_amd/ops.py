@@ -108,12 +108,16 @@ PAIR_BWD = _os.environ.get("P2M_PAIR_BWD", "1") == "1"
 # identical padding rows is computed; 0 = every row (the A/B form)
 CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 # Chebyshev basis inside the contraction (p2m_cheb_tile_gemm, include/p2m.h): the real rows of a conv on a level with a
-# tile plan in ONE kernel, no T1 / T2 planes in HBM.  OPT-IN: correct (op and network parity tests) and it removes the
-# plane traffic, but measured slower than basis kernel + plane contraction on MI355X -- 51.2 vs 43.5 ms per train step,
-# 19.1 vs 16.6 ms over the 16 real-row shapes of the step stand-alone (DESIGN.md section 6 "basis inside the
-# contraction": 157 KB of LDS per block leave one block per CU, so nothing covers the MFMA waves' epilogue and the
-# image hand-over, which two resident blocks of the plain contraction cover for each other).
-TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "0") == "1"
+# tile plan in ONE kernel, no T1 / T2 planes in HBM.  "auto" (default): where it measured faster than basis kernel + plane
+# contraction on MI355X - forward-form launches (no planes written out) of the level's own / un-pooled plans on the big
+# levels; "1": wherever supported (the A/B form of the parity tests); "0": never.  DESIGN.md section 6 has the numbers:
+# 157 KB of LDS per block leave one block per CU, so the kernel only wins where the plane traffic it removes is large.
+TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
+if TILE_GEMM not in ("auto", "0", "1"):
+    raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
+TILE_GEMM_MIN_ROWS = 3000      # "auto": real rows of the level (the two finest SMPL-like levels: 6890, 3638) ...
+TILE_GEMM_MIN_BATCH = 128      # ... and enough sample groups per tile to amortise a block's tables (B = 64 inference: 4.14 vs
+                               # 3.83 ms per batch with the kernel on, measured)
 
 
 class DeviceGraph:
@@ -438,9 +442,15 @@ def cheb_basis_pair(g, G, B, F):
     return P1, P2
 
 
-def tile_gemm_ok(g, plan, Ka, N):
-    """True when the real rows of this conv can take the basis-inside-the-contraction kernel."""
-    return bool(TILE_GEMM and GEMM_ARITH == "bf16x3" and _lib.hip().p2m_cheb_tile_gemm_supported(g.handle, plan, Ka, N))
+def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
+    """True when the real rows of this conv take the basis-inside-the-contraction kernel (see TILE_GEMM)."""
+    if TILE_GEMM in ("0", False) or GEMM_ARITH != "bf16x3":
+        return False
+    if not _lib.hip().p2m_cheb_tile_gemm_supported(g.handle, plan, Ka, N):
+        return False
+    if TILE_GEMM in ("1", True):
+        return True
+    return plan != 2 and not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
 
 
 def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None):
@@ -480,7 +490,7 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
     if P0 is None:
         P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
     Bx, We, Wex = operands
-    if tile_gemm_ok(g, 2, Ka, N):
+    if tile_gemm_ok(g, 2, Ka, N, want_planes=True, B=B):
         # planes S L g, S L2 g formed inside the contraction; written out (compact) only for the weight gradient
         _, (P1c, P2c) = cheb_tile_gemm(g, 2, Gy, P0, Ka, Bx, None, addend, C, N, B, want_planes=True)
     else:
@@ -498,7 +508,7 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
     (p2m_bn_finalize_split)."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
-    if tile_gemm_ok(g, a0_shift, Ka, N):
+    if tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
                                      want_planes=want_planes)
         st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)

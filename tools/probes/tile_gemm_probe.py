@@ -10,6 +10,7 @@ import torch  # noqa: E402
 
 from pose2mesh_release_amd import ops, synth  # noqa: E402
 
+ops.TILE_GEMM = True                      # the probe measures the opt-in kernel (P2M_TILE_GEMM=1)
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 _, gL, _, J = synth.make_graphs("human36")
