@@ -76,20 +76,26 @@ def port_step():
     return float(loss)
 
 
-def bench(fn, n=3):
-    l0 = fn()
-    t = time.time()
+def bench_interleaved(fa, fb, n=3):
+    """Steps of the two implementations ALTERNATE: timing one after the other charged the second one with the first
+    one's allocator / page-cache state (round 2's 1.33x and a first 2.03x at B=32 were that artefact, not the code)."""
+    la, lb = fa(), fb()                     # warm-up (and the first-step losses)
+    ta = tb = 0.0
     for _ in range(n):
-        fn()
-    return (time.time() - t) / n, l0
+        t = time.time()
+        fa()
+        ta += time.time() - t
+        t = time.time()
+        fb()
+        tb += time.time() - t
+    return ta / n, la, tb / n, lb
 
 
-tr, lr = bench(ref_step)
-tp, lp = bench(port_step)
+tr, lr, tp, lp = bench_interleaved(ref_step, port_step)
 out = {"port_over_reference_time": round(tp / tr, 4), "batch": B, "threads": threads, "nproc": os.cpu_count(),
        "joint_set": joint_set, "reference_s_per_step": round(tr, 3), "port_s_per_step": round(tp, 3),
        "first_step_loss_reference": lr, "first_step_loss_port": lp, "torch": torch.__version__,
-       "where": "build container (the only place /root/reference exists)",
+       "where": "build container (the only place /root/reference exists)", "order": "steps interleaved (ref, port, ...)",
        "command": "python tools/cpu_port_vs_reference.py " + " ".join(sys.argv[1:])}
 with open(os.path.join(R, "profiles", "cpu_port_vs_reference.json"), "w") as f:
     json.dump(out, f, indent=1)

@@ -22,7 +22,14 @@ bash tools/rocprof_traffic.sh ${T} > gpurun_out/${T}_traffic.out 2>&1
 tail -12 gpurun_out/${T}_traffic.out
 PROBE_SHAPE=5888,128,128 PROBE_MODES=bf16x3 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_a "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
 PROBE_SHAPE=5888,128,128 PROBE_MODES=bf16x3 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
+# the basis-inside-the-contraction kernel (finest level, 128 -> 128, forward form): MFMA busy / VALU / waits, LDS conflicts,
+# HBM bytes
+for spec in "a:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+            "b:SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+            "c:FETCH_SIZE GRBM_GUI_ACTIVE" "d:WRITE_SIZE GRBM_GUI_ACTIVE"; do
+  PROBE_CASE=0,128,128,0 PROBE_ONLY_TILE=1 bash tools/rocprof_pmc.sh ${T}_pmc_tile_${spec%%:*} "${spec#*:}" python $R/tools/probes/tile_gemm_probe.py > /dev/null 2>&1
+done
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_a "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_b "FETCH_SIZE GRBM_GUI_ACTIVE" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_c "WRITE_SIZE GRBM_GUI_ACTIVE" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
-grep -h "gemm_planes_ws\|k_basis_tile" gpurun_out/${T}_pmc_*.csv | cut -c1-220
+grep -h "gemm_planes_ws\|k_basis_tile\|k_cheb_tile_gemm" gpurun_out/${T}_pmc_*.csv | cut -c1-60,150-260
