@@ -395,9 +395,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "gemm_arith": ("fp32 contraction as 3 exact bf16 slices x 6 products on the BF16 MFMA pipe, "
-                                      "fp32 accumulate (error vs float64 <= native f32 MFMA)"
-                                      if ops.GEMM_ARITH == "bf16x3" else "native f32 MFMA"),
+                       "gemm_arith": {"bf16x3": "fp32 contraction as 3 exact bf16 slices x 6 products on the BF16 MFMA pipe, "
+                                                "fp32 accumulate (error vs float64 <= native f32 MFMA)",
+                                      "f16x2": "fp32 contraction as 2 fp16 slices of each operand tensor scaled by a "
+                                               "power of two (device-side amax words) x 3 products on the FP16 MFMA "
+                                               "pipe, fp32 accumulate: 22-bit operands, error vs float64 within 4x of the "
+                                               "native f32 MFMA's (tests/test_gpu_ops.py::test_f16x2_error_is_fp32_class)",
+                                      "f32": "native f32 MFMA"}[ops.GEMM_ARITH],
                        "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if (world > 1 and not infer) else 0,
                        **({"train_step": "one captured hipGraph (train.GraphedTrainStep); kernel timings from the same "
                                          "launches issued one by one after the timed region"} if train_graph else {})},
@@ -427,6 +431,10 @@ def main():
                     kprefix = ops.gemm_kernel_name()
                     kname = kprefix + " (fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product)"
                     peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+                elif ops.GEMM_ARITH == "f16x2":
+                    kprefix = ops.gemm_kernel_name()
+                    kname = kprefix + " (fp32 as 2 scaled fp16 slices, 3 x v_mfma_f32_32x32x16_f16 per product)"
+                    peak = PEAK_BF16_MFMA_TFLOPS / 3.0       # the FP16 dense peak equals the BF16 one
                 else:
                     kprefix = "k_gemm_planes<"
                     kname, peak = "k_gemm_planes (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
@@ -439,8 +447,10 @@ def main():
                                     "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"]),
                                     "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                     "note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = pipe peak "
-                                            "in algorithmic fp32 FLOPs (BF16 dense 2500 / 6 slice products, or the "
-                                            "f32 MFMA 157.3)",
+                                            "in algorithmic fp32 FLOPs (16-bit dense 2500 / 3 fp16 or 6 bf16 slice "
+                                            "products, or the f32 MFMA 157.3)",
+                                    "hbm_achieved_GBps": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
+                                    "hbm_frac_of_8000": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                                     "frac_of_f32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
                 if tr is not None:
                     line["roofline"]["traffic_note"] = (
@@ -458,13 +468,13 @@ def main():
             if tg and tg["ms"] > 0:
                 # basis inside the contraction (k_cheb_tile_gemm): SURVEY 8(d)'s rule for a fused kernel -- the larger of
                 # dense FLOPs / MFMA peak and 4 V (Fin + Fout) bytes / 8 TB/s bounds it; both fractions are reported
-                peak_t = PEAK_BF16_MFMA_TFLOPS / 6.0
+                peak_t = PEAK_BF16_MFMA_TFLOPS / (3.0 if ops.GEMM_ARITH == "f16x2" else 6.0)
                 ach = tg["work"] / (tg["ms"] * 1e-3) / 1e12
                 gbs = tg["bytes"] / (tg["ms"] * 1e-3) / 1e9
                 tr, tr_src = _traffic_for("k_cheb_tile_gemm")
                 line["roofline_fused"] = {
-                    "bound": "mfma", "kernel": "k_cheb_tile_gemm (Chebyshev planes formed per tile in LDS, bf16x3 MFMA; "
-                                               "no T1/T2 planes in HBM)",
+                    "bound": "mfma", "kernel": f"k_cheb_tile_gemm (Chebyshev planes formed per tile in LDS, {ops.GEMM_ARITH} "
+                                               "MFMA; no T1/T2 planes in HBM)",
                     "achieved": round(ach, 2), "peak": round(peak_t, 1), "unit": "TFLOP/s", "frac": round(ach / peak_t, 4),
                     "hbm_achieved_GBps": round(gbs, 1), "hbm_frac_of_8000": round(gbs / PEAK_HBM_GBPS, 4),
                     "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),

@@ -36,11 +36,20 @@ typedef enum {
   P2M_ERR_NOMEM = -3
 } p2m_status;
 
-/* Arithmetic of the dense contractions.  Both compute the SAME fp32 contraction with fp32 accumulation:
+/* Arithmetic of the dense contractions.  All compute the SAME fp32 contraction with fp32 accumulation:
  * F32     native f32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain;
  * BF16X3  every fp32 operand cut EXACTLY into three bf16 slices (8+8+8 significand bits), the six slice products of
- *         weight >= 2^-16 on v_mfma_f32_32x32x16_bf16; dropped terms <= 2^-23 |a b| (one fp32 rounding).          */
-enum { P2M_ARITH_F32 = 0, P2M_ARITH_BF16X3 = 1 };
+ *         weight >= 2^-16 on v_mfma_f32_32x32x16_bf16; dropped terms <= 2^-23 |a b| (one fp32 rounding);
+ * F16X2   every operand TENSOR multiplied by a power of two 2^s that brings an upper bound U of its magnitudes into
+ *         [2^14, 2^15), then cut into two fp16 slices (11+11 significand bits, round to nearest); three slice products
+ *         on v_mfma_f32_32x32x16_f16, the accumulator rescaled exactly (v_ldexp) in the epilogue.  An operand carries
+ *         x (1 + d), |d| <= 2^-22, for |x| >= 2^-18 U and an absolute error <= 2^-40 U below; a product additionally
+ *         drops <= 2^-22 |a b|.  Half the matrix-core work of BF16X3.  U comes from an AMAX WORD: a uint32 in device
+ *         memory holding the bits of a non-negative float >= max |x| over the tensor, produced on the device by
+ *         whoever wrote the tensor (the amax_out arguments, p2m_amax, p2m_amax_rows) - it only has to BOUND the
+ *         magnitudes; `bits` arguments add binades of headroom for operands derived from the bounded tensor inside
+ *         the same call (Chebyshev planes: p2m_graph_plane_bits).                                                  */
+enum { P2M_ARITH_F32 = 0, P2M_ARITH_BF16X3 = 1, P2M_ARITH_F16X2 = 2 };
 
 typedef struct p2m_graph* p2m_graph_t;
 
@@ -128,25 +137,38 @@ int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, fl
  * coarse vertex -- backward of nn.Upsample (meshnet.py:74) in the epilogue.  The backward uses this entry
  * point in "forward form": dX = [g | L g | L2 g] W3 with the planes from p2m_cheb_basis_fwd(g).
  *
- * Arithmetic.  Bsplit == NULL: native f32 MFMA (bitwise an fmaf chain).  Bsplit != NULL (made from the same Bm by
- * p2m_weight_split): the same fp32 contraction on the BF16 matrix pipe - both operands are cut EXACTLY into three
- * bf16 slices (8+8+8 significand bits) and the six slice products of weight >= 2^-16 are accumulated in fp32 by
- * v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-23 |a b|, i.e. fp32-level error at 6/16 of the MFMA cost.
+ * Arithmetic (P2M_ARITH_* above).  arith = P2M_ARITH_F32: native f32 MFMA (bitwise an fmaf chain), Bsplit ignored.
+ * The slice arithmetics run the same fp32 contraction on the 16-bit matrix pipe and need Bsplit, made from the same Bm
+ * by p2m_weight_split with the SAME arith; P2M_ARITH_F16X2 also needs a_amax (amax word bounding ALL the A planes after
+ * a_bits binades of headroom).  amax_out (optional, MFMA path): atomic max of |value stored| into a zeroed amax word -
+ * the bound for whoever consumes C next.
  *
  * Fused activation (optional; inference): act_scale/act_shift != NULL applies v = fmaf(acc + bias, act_scale[n],
  * act_shift[n]) and act_relu != 0 then v = max(v, 0) before the store -- eval-mode BatchNorm (p2m_bn_eval_coeffs) and
  * F.relu (cheby_graph_conv.py:39, meshnet.py:100) folded into the contraction with the SAME two roundings as the
  * separate p2m_bn_act_fwd pass (bitwise the unfused result).  Excludes stats and pair_out.                          */
 int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                    int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias, const float* addend,
+                    int32_t a0_shift, const float* Bm, const void* Bsplit, int32_t arith, const void* a_amax,
+                    int32_t a_bits, const float* bias, const float* addend,
                     float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc, int32_t pair_out,
                     int64_t M, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
-                    void* stream);
-/* Bx[k / 16][s][n][k % 16] (uint16 bf16 bit patterns; s < 3 slices; n < ceil(N/128)*128, zero padded; K % 16 == 0):
- * s-th slice of Bm[k][n], Bm = slice 0 + slice 1 + slice 2 exactly.  p2m_weight_split_elems(K, N) = number of uint16
- * elements of Bx.                                                                                                  */
-int64_t p2m_weight_split_elems(int32_t K, int32_t N);
-int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream);
+                    void* amax_out, void* stream);
+/* Bx[k / 16][s][n][k % 16] (uint16 bit patterns; n < ceil(N/128)*128, zero padded; K % 16 == 0):
+ *   P2M_ARITH_BF16X3  s < 3 bf16 slices of Bm[k][n], Bm = slice 0 + slice 1 + slice 2 exactly;
+ *   P2M_ARITH_F16X2   s < 2 fp16 slices of Bm[k][n] 2^sb, followed by the amax word the scale came from, from which
+ *                     every consumer re-derives sb.  amax_in = NULL: max |Bm|, computed here (one extra small launch);
+ *                     else the word of a tensor that bounds Bm after amax_bits binades - e.g. the parameter Bm is a
+ *                     permutation of (0 bits), or W0 + a W1 + b W2 (p2m_weight_eff: ceil(log2(1 + |a| + |b|)) bits) -
+ *                     so that one amax pass per parameter serves all of its derived operands.
+ * p2m_weight_split_elems = number of uint16 elements of Bx (0: unsupported shape / arith).                          */
+int64_t p2m_weight_split_elems(int32_t K, int32_t N, int32_t arith);
+int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t arith, const void* amax_in, int32_t amax_bits,
+                     void* Bx, void* stream);
+/* amax words: atomic max of |x| into *word (uint32, device; the caller zeroes it before the first contribution).
+ * p2m_amax: n contiguous floats (n % 4 == 0, 16-byte aligned).  p2m_amax_rows: rows of a [B, V, F] tensor of a level -
+ * row_set 0 = every row that holds data (all rows; the live rows once classes are declared), 1..4 = that row set.   */
+int p2m_amax(const float* x, int64_t n, void* word, void* stream);
+int p2m_amax_rows(p2m_graph_t g, int32_t row_set, const float* x, int32_t B, int32_t F, void* word, void* stream);
 /* rows per BatchNorm partial tile and the number of tiles for M rows */
 int32_t p2m_stats_tile_rows(void);
 
@@ -156,7 +178,8 @@ int32_t p2m_stats_tile_rows(void);
  * (autograd of cheby_graph_conv.py:37 / meshnet.py:105.)                                       */
 int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                 int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
-                int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith, void* stream);
+                int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith,
+                const void* a_amax, int32_t a_bits, const void* g_amax, int32_t g_bits, void* stream);
 
 /* ---- BatchNorm1d over B*V rows + ReLU + residual (cheby_graph_conv.py:39, meshnet.py:100,108-115)
  * finalize: reduces the GEMM's partials to batch mean / biased var, writes
@@ -173,10 +196,12 @@ int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* x[r,f] = act(y[r,f]*scale[f] + shift[f]) + lerp_F(resid[r>>res_shift, 0..Fres))[f]
  * act = ReLU if relu!=0; scale/shift may be NULL (identity); resid may be NULL.
  * lerp_F is F.interpolate(mode='linear', align_corners=False) along the FEATURE axis
- * (meshnet.py:109,114).                                                                        */
+ * (meshnet.py:109,114).  amax_out (optional, F % 4 == 0): atomic max of |x stored| into a zeroed amax word
+ * (P2M_ARITH_F16X2 above) - the bound for the contraction that consumes x.                     */
 int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                    const float* resid, int32_t Fres, int32_t res_shift,
-                   float* x, int64_t M, int32_t F, p2m_graph_t classes /* or NULL: holes are skipped */, void* stream);
+                   float* x, int64_t M, int32_t F, p2m_graph_t classes /* or NULL: holes are skipped */,
+                   void* amax_out, void* stream);
 /* backward through ReLU + BatchNorm (train: batch statistics; eval: running statistics).
  *   go = gx * (y*scale+shift > 0 or !relu)
  *   reduce:   part[blk][0][f] = sum go, part[blk][1][f] = sum go * yhat       (nblk = p2m_bn_bwd_blocks(M,F))
@@ -194,11 +219,12 @@ int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamm
                         float* coef, int32_t accumulate, int32_t F, void* stream);
 /* pair_gx / pair_gy (optional, [M/2, F]; M even, F in {32,64,128,256}): by-products pair_gx[q] = gx[2q] + gx[2q+1] and
  * pair_gy[q] = gy[2q] + gy[2q+1] -- the pair-sums the backward of an un-pooled conv needs (residual gradient for the
- * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.               */
+ * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.
+ * amax_out (optional): atomic max of |gy stored| into a zeroed amax word (the pair sums are bounded by twice it).    */
 int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                      const float* mean, const float* invstd, const float* gamma, const float* coef,
                      int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
-                     p2m_graph_t classes, void* stream);
+                     p2m_graph_t classes, void* amax_out, void* stream);
 
 /* out[p, f] = in[2p, f] + in[2p+1, f]   (backward of the x2 nearest un-pool, meshnet.py:74) */
 int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, p2m_graph_t classes /* of `in`'s level, or NULL */,
@@ -237,15 +263,17 @@ int p2m_cheb_basis_pair(p2m_graph_t g, const float* G, float* P1c, float* P2c, i
  * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.                  */
 int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
-                         const float* Bm, const void* Bsplit, const float* bias, const float* addend, float* C,
+                         const float* Bm, const void* Bsplit, int32_t arith, const void* a_amax, int32_t a_bits,
+                         const float* bias, const float* addend, float* C,
                          int32_t N, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
-                         void* stream);
+                         void* amax_out, void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
                      const float* G0, const float* G1, const float* G2, int32_t nplanesG, int32_t Gc,
-                     int32_t planes_compact, int32_t splits, float* P, float* Pdb, int32_t arith, void* stream);
+                     int32_t planes_compact, int32_t splits, float* P, float* Pdb, int32_t arith,
+                     const void* a_amax, const void* g_amax, int32_t g_bits, void* stream);
 /* We[k][n] = Wt[k][n] + a Wt[Ka+k][n] + b Wt[2Ka+k][n]  (Wt = [3Ka, N]) */
 int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream);
 /* dW (nn.Linear layout) from the real-vertex partials P[c][fin][k*Fout+fo] plus the fake-vertex partials
@@ -279,11 +307,17 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * row set 2 / 4, with p2m_weight_eff).  Optional: stats[B * ntiles(plan)][2][N] BatchNorm partials per (sample, tile)
  * for p2m_bn_finalize_tiles; E1 / E2 [B * nset, Ka]: the two gathered planes, compact (bitwise those of
  * p2m_cheb_basis_fwd_real / p2m_cheb_basis_pair), for the weight gradient p2m_gemm_tn_rows; act_*: fused eval-mode
- * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  Arithmetic: P2M_ARITH_BF16X3.                              */
+ * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  arith: P2M_ARITH_BF16X3 or P2M_ARITH_F16X2 (Bx split with
+ * the same arith; x_amax = amax word bounding X and A0, the kernel adds the level's p2m_graph_plane_bits for the planes
+ * it forms).  amax_out as in p2m_gemm_planes.                                                                          */
 int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
 int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
-                       const float* bias, const float* addend, float* C, int32_t N, float* stats, float* E1, float* E2,
-                       const float* act_scale, const float* act_shift, int32_t act_relu, int32_t B, void* stream);
+                       int32_t arith, const void* x_amax, const float* bias, const float* addend, float* C, int32_t N,
+                       float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,
+                       int32_t act_relu, void* amax_out, int32_t B, void* stream);
+/* Binades of headroom that cover the Chebyshev planes of a level: ceil(log2(max(1, max_v sum_u |L_vu|, max_v sum_u
+ * |L2_vu|))) for plan 0 / 1 (|L x|, |L2 x| <= 2^bits max |x|), one more for plan 2 (the pair sums).                */
+int32_t p2m_graph_plane_bits(p2m_graph_t g, int32_t plan);
 int p2m_bn_finalize_tiles(p2m_graph_t g, int32_t plan, const float* stats_real, const float* stats_fake, int32_t B,
                           const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,

@@ -37,11 +37,11 @@ HIP_SYMBOLS = {
     "p2m_graph_pair_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2)]),
     "p2m_graph_plan_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_cheb_basis_pair": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                        _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32,
+                                        _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
-                                    _i32, _vp]),
+                                    _i32, _vp, _vp, _i32, _vp]),
     "p2m_weight_eff": (_c.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "p2m_weight_grad_unpack2": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _i32, _i32, _i32,
                                            _i32, _vp]),
@@ -50,8 +50,11 @@ HIP_SYMBOLS = {
     "p2m_bn_finalize_split": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
                                          _vp]),
     "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
-    "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32,
-                                      _i32, _vp]),
+    "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                      _vp, _i32, _vp, _i32, _vp]),
+    "p2m_graph_plane_bits": (_i32, [_vp, _i32]),
+    "p2m_amax": (_c.c_int, [_vp, _i64, _vp, _vp]),
+    "p2m_amax_rows": (_c.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "p2m_bn_finalize_tiles": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                          _i32, _vp]),
     "p2m_graph_fake_ids": (_c.c_int, [_vp, _vp]),
@@ -59,23 +62,23 @@ HIP_SYMBOLS = {
     "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_stats_rows_w": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "p2m_class_reduce": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                                   _i32, _i64, _vp, _vp, _vp, _i32, _vp]),
-    "p2m_weight_split_elems": (_i64, [_i32, _i32]),
-    "p2m_weight_split": (_c.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "p2m_gemm_planes": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
+                                   _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "p2m_weight_split_elems": (_i64, [_i32, _i32, _i32]),
+    "p2m_weight_split": (_c.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "p2m_stats_tile_rows": (_i32, []),
     "p2m_gemm_tn": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp,
-                               _i32, _vp]),
+                               _i32, _vp, _i32, _vp, _i32, _vp]),
     "p2m_bn_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                    _i32, _i32, _vp]),
     "p2m_bn_eval_coeffs": (_c.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "p2m_bn_bwd_blocks": (_i32, [_i64, _i32]),
     "p2m_bn_bwd_blocks_classes": (_i32, [_vp, _i64, _i32]),
     "p2m_bn_bwd_reduce": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     "p2m_bn_bwd_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "p2m_bn_bwd_apply": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp,
-                                    _vp]),
+                                    _vp, _vp]),
     "p2m_pair_sum": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "p2m_lerp_bwd_add": (_c.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "p2m_mesh_loss_workspace": (_i64, [_i32, _i32, _i32, _i32]),

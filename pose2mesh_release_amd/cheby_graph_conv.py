@@ -59,7 +59,8 @@ class _ChebConvFn(torch.autograd.Function):
             T1, T2 = ops.cheb_basis_fwd(g, xc, B, Fin, 0)
             Wt, W2, _ = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)
             stats = bn is not None and training
-            (y,), st = ops.gemm_planes([xc, T1, T2], Fin, 0, Wt, bias.contiguous(), M, Fout, 1, stats)
+            (y,), st = ops.gemm_planes([xc, T1, T2], Fin, 0, Wt, bias.contiguous(), M, Fout, 1, stats,
+                                       amax=ops.amax_of(xc), amax_bits=g.plane_bits)
             co = None
             out = y
             if bn is not None:
@@ -88,7 +89,7 @@ class _ChebConvFn(torch.autograd.Function):
                 gy, dgamma, dbeta = ops.bn_relu_bwd(gx, y, co, gamma.contiguous(), False, training, M, Fout)
             else:
                 gy = gx
-            P, Pdb, nch = ops.gemm_tn([xc, T1, T2], Fin, 0, gy, M, Fout)
+            P, Pdb, nch = ops.gemm_tn([xc, T1, T2], Fin, 0, gy, M, Fout, a_amax=ops.amax_of(xc), a_bits=g.plane_bits)
             dW, db = ops.weight_grad_unpack(P, Pdb, nch, Fout, Fin, 3)
             d, _ = ops.gemm_planes([gy], Fout, 0, W2, None, M, 3 * Fin, 3, False)
             dX = ops.cheb_basis_bwd(g, d[0], d[1], d[2], None, B, Fin, 0)

@@ -152,71 +152,82 @@ __device__ __forceinline__ float lerp_feat(const float* __restrict__ row, int Fr
 // One float4 column group per thread, ACT_UNROLL rows per thread with all loads issued before the arithmetic (a
 // single 16-byte load per thread leaves the memory pipe half empty: 3.3 TB/s -> see DESIGN.md).  Needs 256 % (F/4) == 0.
 constexpr int ACT_UNROLL = 4;
+constexpr int ACT_PASSES = 4;     // passes of ACT_UNROLL row groups per block: one amax commit (a wave reduction + a load of
+                                  // the word) per 16 rows of a thread instead of per 4
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, int relu,
                                                      const float* __restrict__ resid, int Fres, int res_shift,
-                                                     float* __restrict__ x, long M, int F, RowMap m) {
+                                                     float* __restrict__ x, long M, int F, RowMap m,
+                                                     unsigned* __restrict__ amax) {
   const int F4 = F >> 2;
   const int rpb = 256 / F4;                                  // rows per block pass
+  float vmax = 0.f;                                          // max |x stored| -> the tensor's amax word
   const int f = (threadIdx.x % F4) * 4;
-  const long rbase = (long)blockIdx.x * rpb * ACT_UNROLL + threadIdx.x / F4;   // logical rows (M of them)
-  float4 v[ACT_UNROLL], q[ACT_UNROLL];
-  long row[ACT_UNROLL];
-  const bool same = resid != nullptr && Fres == F;
-  const bool mapped = m.ids != nullptr;
-  RowPos p0 = {0u, 0u};
-  if (mapped && rbase < M) p0 = row_pos(rbase, m);
-#pragma unroll
-  for (int u = 0; u < ACT_UNROLL; u++) {
-    const long j = rbase + (long)u * rpb;
-    long r = j < M ? j : M - 1;                               // clamped: keeps the loads unconditional
-    if (mapped) {
-      const RowPos pu = j < M ? row_adv(p0, (unsigned)(u * rpb), m) : row_pos(M - 1, m);
-      r = (long)pu.b * m.V + m.ids[pu.i];
-    }
-    row[u] = r;
-    v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
-    if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
-  }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (scale != nullptr) {
     sc = *reinterpret_cast<const float4*>(scale + f);
     sh = *reinterpret_cast<const float4*>(shift + f);
   }
+  for (int pass = 0; pass < ACT_PASSES; pass++) {
+    const long rbase = ((long)blockIdx.x * ACT_PASSES + pass) * rpb * ACT_UNROLL + threadIdx.x / F4;   // logical rows (M of them)
+    if ((long)(blockIdx.x * ACT_PASSES + pass) * rpb * ACT_UNROLL >= M) break;                          // block-uniform
+    float4 v[ACT_UNROLL], q[ACT_UNROLL];
+    long row[ACT_UNROLL];
+    const bool same = resid != nullptr && Fres == F;
+    const bool mapped = m.ids != nullptr;
+    RowPos p0 = {0u, 0u};
+    if (mapped && rbase < M) p0 = row_pos(rbase, m);
 #pragma unroll
-  for (int u = 0; u < ACT_UNROLL; u++) {
-    if (rbase + (long)u * rpb >= M) break;
-    const long r = row[u];
-    float4 o = v[u];
-    if (scale != nullptr) {
-      o.x = fmaf(o.x, sc.x, sh.x); o.y = fmaf(o.y, sc.y, sh.y);
-      o.z = fmaf(o.z, sc.z, sh.z); o.w = fmaf(o.w, sc.w, sh.w);
+    for (int u = 0; u < ACT_UNROLL; u++) {
+      const long j = rbase + (long)u * rpb;
+      long r = j < M ? j : M - 1;                               // clamped: keeps the loads unconditional
+      if (mapped) {
+        const RowPos pu = j < M ? row_adv(p0, (unsigned)(u * rpb), m) : row_pos(M - 1, m);
+        r = (long)pu.b * m.V + m.ids[pu.i];
+      }
+      row[u] = r;
+      v[u] = *reinterpret_cast<const float4*>(y + r * F + f);
+      if (same) q[u] = *reinterpret_cast<const float4*>(resid + (r >> res_shift) * Fres + f);
     }
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+#pragma unroll
+    for (int u = 0; u < ACT_UNROLL; u++) {
+      if (rbase + (long)u * rpb >= M) break;
+      const long r = row[u];
+      float4 o = v[u];
+      if (scale != nullptr) {
+        o.x = fmaf(o.x, sc.x, sh.x); o.y = fmaf(o.y, sc.y, sh.y);
+        o.z = fmaf(o.z, sc.z, sh.z); o.w = fmaf(o.w, sc.w, sh.w);
+      }
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      if (same) {
+        o.x += q[u].x; o.y += q[u].y; o.z += q[u].z; o.w += q[u].w;
+      } else if (resid != nullptr) {
+        const float* rr = resid + (r >> res_shift) * Fres;
+        o.x += lerp_feat(rr, Fres, F, f);
+        o.y += lerp_feat(rr, Fres, F, f + 1);
+        o.z += lerp_feat(rr, Fres, F, f + 2);
+        o.w += lerp_feat(rr, Fres, F, f + 3);
+      }
+      *reinterpret_cast<float4*>(x + r * F + f) = o;
+      vmax = amax4(vmax, &o.x);
     }
-    if (same) {
-      o.x += q[u].x; o.y += q[u].y; o.z += q[u].z; o.w += q[u].w;
-    } else if (resid != nullptr) {
-      const float* rr = resid + (r >> res_shift) * Fres;
-      o.x += lerp_feat(rr, Fres, F, f);
-      o.y += lerp_feat(rr, Fres, F, f + 1);
-      o.z += lerp_feat(rr, Fres, F, f + 2);
-      o.w += lerp_feat(rr, Fres, F, f + 3);
-    }
-    *reinterpret_cast<float4*>(x + r * F + f) = o;
   }
+  if (amax != nullptr) amax_commit(amax, vmax);
 }
 
 // one float4 per thread: any F % 4 == 0
 __global__ __launch_bounds__(256) void k_bn_act_fwd_v4(const float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
                                                         const float* __restrict__ resid, int Fres, int res_shift,
-                                                        float* __restrict__ x, long M, int F) {
+                                                        float* __restrict__ x, long M, int F,
+                                                        unsigned* __restrict__ amax) {
   const int F4 = F >> 2;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = M * F4;
-  if (idx >= tot) return;
+  const bool live = idx < tot;
+  if (!live) idx = tot - 1;                                  // clamped, not returned: every lane reaches amax_commit
   long r = idx / F4;
   int f = (int)(idx - r * F4) * 4;
   float4 v = *reinterpret_cast<const float4*>(y + r * F + f);
@@ -241,7 +252,8 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd_v4(const float* __restrict__
       v.w += lerp_feat(rr, Fres, F, f + 3);
     }
   }
-  *reinterpret_cast<float4*>(x + r * F + f) = v;
+  if (live) *reinterpret_cast<float4*>(x + r * F + f) = v;
+  if (amax != nullptr) amax_commit(amax, live ? amax4(0.f, &v.x) : 0.f);
 }
 
 // scalar version for F % 4 != 0
@@ -500,9 +512,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ coef, int relu,
-                                                               float* __restrict__ gy, long M, int F, RowMap m) {
+                                                               float* __restrict__ gy, long M, int F, RowMap m,
+                                                               unsigned* __restrict__ amax) {
   long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * F) return;
+  const bool live = idx < M * F;
+  if (!live) idx = M * F - 1;                                // clamped, not returned: every lane reaches amax_commit
   const int f = (int)(idx % F);
   float wr = 1.f;
   if (m.ids != nullptr) {
@@ -516,7 +530,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
   if (relu && fmaf(v, scale[f], shift[f]) <= 0.f) go = 0.f;
   const float k = gamma[f] * invstd[f];
   const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
-  gy[idx] = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
+  const float o = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
+  if (live) gy[idx] = o;
+  if (amax != nullptr) amax_commit(amax, live ? fabsf(o) : 0.f);
 }
 
 // Two stages like the forward finalize.  Stage 1: block = 32 adjacent columns of BOTH partial kinds (128-byte coalesced
@@ -580,11 +596,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ coef,
-                                                       int relu, float* __restrict__ gy, long M, RowMap m) {
+                                                       int relu, float* __restrict__ gy, long M, RowMap m,
+                                                       unsigned* __restrict__ amax) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
   const int rloc = t / LPR, f = (t % LPR) * 4;
+  float vmax = 0.f;                                          // max |gy stored| -> the tensor's amax word
   float sc[4], sh[4], k[4], a0[4], a1[4];
   *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + f);
   *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + f);
@@ -639,8 +657,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                       : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
       }
       *reinterpret_cast<float4*>(gy + row[u] * F + f) = *reinterpret_cast<float4*>(o);
+      vmax = amax4(vmax, o);
     }
   }
+  if (amax != nullptr) amax_commit(amax, vmax);
 }
 
 // The same pass with each thread owning PAIRS of adjacent rows (2q, 2q+1), so that the pair-sums the backward of an
@@ -652,11 +672,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ coef,
                                                              int relu, float* __restrict__ gy, float* __restrict__ pair_gx,
-                                                             float* __restrict__ pair_gy, long Mp, RowMap m) {
+                                                             float* __restrict__ pair_gy, long Mp, RowMap m,
+                                                             unsigned* __restrict__ amax) {
   constexpr int F = LPR * 4;
   constexpr int RP = 256 / LPR;
   const int t = threadIdx.x;
   const int rloc = t / LPR, f = (t % LPR) * 4;
+  float vmax = 0.f;                                          // max |gy stored| (the pair sums are <= twice that)
   float sc[4], sh[4], k[4], a0[4], a1[4], mu[4], is[4], ga[4];
   *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + f);
   *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + f);
@@ -719,7 +741,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
                            : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
           if (wr[c] == 0.f) o[c][i] = 0.f;                // a hole: no data (its g / v registers were zeroed above)
         }
-        if (wr[c] != 0.f) *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
+        if (wr[c] != 0.f) {
+          *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
+          vmax = amax4(vmax, o[c]);
+        }
       }
       // the pair-sums leave the holes out; a pair of two holes (a hole parent) is not written at all
       if (wr[0] != 0.f || wr[1] != 0.f) {
@@ -738,6 +763,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
       }
     }
   }
+  if (amax != nullptr) amax_commit(amax, vmax);
 }
 
 __global__ __launch_bounds__(256) void k_pair_sum(const float* __restrict__ in, float* __restrict__ out, long Mout, int F,
@@ -946,8 +972,9 @@ extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const f
 
 extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                               const float* resid, int32_t Fres, int32_t res_shift, float* x, int64_t M, int32_t F,
-                              p2m_graph_t classes, void* stream) {
+                              p2m_graph_t classes, void* amax_out, void* stream) {
   P2M_CHECK_ARG(y && x && F > 0, "null pointer or empty shape");
+  unsigned* amax = static_cast<unsigned*>(amax_out);
   P2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale/shift must both be given or both NULL");
   P2M_CHECK_ARG(resid == nullptr || Fres > 0, "Fres must be positive with a residual");
   P2M_CHECK_ARG(res_shift == 0 || res_shift == 1, "res_shift must be 0 or 1");
@@ -956,18 +983,20 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
   if (F % 4 == 0 && (resid == nullptr || Fres != F || Fres % 4 == 0)) {
     const int F4 = F / 4;
     if (F4 <= 256 && 256 % F4 == 0) {
-      const long rows_per_block = (long)(256 / F4) * ACT_UNROLL;
+      const long rows_per_block = (long)(256 / F4) * ACT_UNROLL * ACT_PASSES;
       RowMap m;
       long Mlog;
       P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
       hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(Mlog, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
-                         Fres, res_shift, x, Mlog, F, m);
+                         Fres, res_shift, x, Mlog, F, m, amax);
     } else {
+      P2M_CHECK_ARG(classes == nullptr || amax == nullptr, "amax_out with classes needs 256 % (F / 4) == 0");
       long tot = M * F4;
       hipLaunchKernelGGL(k_bn_act_fwd_v4, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
-                         res_shift, x, (long)M, F);
+                         res_shift, x, (long)M, F, amax);
     }
   } else {
+    P2M_CHECK_ARG(amax == nullptr, "amax_out needs F % 4 == 0");
     long tot = M * F;
     hipLaunchKernelGGL(k_bn_act_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid,
                        Fres, res_shift, x, (long)M, F);
@@ -1027,8 +1056,9 @@ extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, f
 extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* gamma, const float* coef,
                                 int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
-                                p2m_graph_t classes, void* stream) {
+                                p2m_graph_t classes, void* amax_out, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
+  unsigned* amax = static_cast<unsigned*>(amax_out);
   RowMap m;
   long Mlog;
   hipStream_t s = (hipStream_t)stream;
@@ -1039,22 +1069,22 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
     P2M_CHECK_ARG(row_map_of(classes, M, true, &m, &Mp), "M is not a multiple of the level's (even) vertex count");
     const int gridp = cdiv(Mp, APPLY_ROWS_PER_BLOCK / 2);
     switch (F) {
-      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
-      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
-      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
-      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m); break;
+      case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m, amax); break;
+      case 64:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<16>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m, amax); break;
+      case 128: hipLaunchKernelGGL(k_bn_bwd_apply_pairs<32>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m, amax); break;
+      default:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<64>, dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m, amax); break;
     }
     return check_launch("bn_bwd_apply(pairs)");
   }
   P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
   const int grid = cdiv(Mlog, APPLY_ROWS_PER_BLOCK);
   switch (F) {
-    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
-    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
-    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
-    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m); break;
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m, amax); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_apply<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m, amax); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_apply<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m, amax); break;
+    case 256: hipLaunchKernelGGL(k_bn_bwd_apply<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m, amax); break;
     default:
-      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv(Mlog * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, F, m);
+      hipLaunchKernelGGL(k_bn_bwd_apply_generic, dim3(cdiv(Mlog * F, 256)), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, F, m, amax);
   }
   return check_launch("bn_bwd_apply");
 }

@@ -1,5 +1,6 @@
 // Graph handles, error plumbing and the composite ChebConv entry point of libp2m_hip.so.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <map>
 #include <utility>
@@ -118,7 +119,7 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
 using namespace p2m;
 
 extern "C" const char* p2m_last_error_string(void) { return g_err; }
-extern "C" const char* p2m_version(void) { return "p2m-hip 0.3 (gfx950; fp32 contractions on the BF16 MFMA pipe as 3 exact slices, or on the f32 MFMA; paired operator, fake-row classes)"; }
+extern "C" const char* p2m_version(void) { return "p2m-hip 0.4 (gfx950; fp32 contractions as 2 scaled fp16 slices or 3 exact bf16 slices on the matrix pipe, or on the f32 MFMA; basis inside the contraction, paired operator, fake-row classes)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).
 extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val, int32_t V, int32_t nnz,
@@ -164,6 +165,15 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
     rp[i + 1] = (int)mc.size();
     max_row = std::max(max_row, rp[i + 1] - rp[i]);
   }
+  // |L x|, |L2 x| <= (max row sum of |L|, |L2|) max |x|: the headroom the two-fp16-slice contractions give the planes
+  double row_sum_max = 1.0;
+  for (int i = 0; i < V; i++) {
+    double sa = 0.0, sb = 0.0;
+    for (int j = rp[i]; j < rp[i + 1]; j++) { sa += std::fabs((double)ma[j]); sb += std::fabs((double)mb[j]); }
+    row_sum_max = std::max(row_sum_max, std::max(sa, sb));
+  }
+  int plane_bits = 0;
+  while (std::ldexp(1.0, plane_bits) < row_sum_max * (1.0 + 1e-6) && plane_bits < 30) plane_bits++;
   // fake (isolated) vertices: single-entry rows sharing the most common (a, b) pair
   std::vector<int> real_ids, fake_ids;
   float fa = 0.f, fb = 0.f;
@@ -241,6 +251,7 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   g->nnz = (int)mc.size();
   g->nnz_L = nnz;
   g->max_row = max_row;
+  g->plane_bits = plane_bits;
   int rc;
   if ((rc = upload(rp.data(), sizeof(int) * (V + 1), (void**)&g->rowptr)) != P2M_OK ||
       (rc = upload(mc.data(), sizeof(int) * mc.size(), (void**)&g->col)) != P2M_OK ||
@@ -292,6 +303,11 @@ extern "C" int p2m_graph_info(p2m_graph_t gh, int32_t info[4]) {
   info[2] = g->nnz;
   info[3] = g->max_row;
   return P2M_OK;
+}
+
+extern "C" int32_t p2m_graph_plane_bits(p2m_graph_t gh, int32_t plan) {
+  if (!gh || plan < 0 || plan > 2) return 0;
+  return reinterpret_cast<const Graph*>(gh)->plane_bits + (plan == 2 ? 1 : 0);
 }
 
 extern "C" int p2m_graph_split_info(p2m_graph_t gh, int32_t counts[2], float coef[2]) {
@@ -431,6 +447,6 @@ extern "C" int p2m_chebconv_fwd(p2m_graph_t gh, const float* X, const float* Wt,
   const Graph* g = reinterpret_cast<const Graph*>(gh);
   int rc = p2m_cheb_basis_fwd(gh, X, T1, T2, B, Fin, in_shift, stream);
   if (rc != P2M_OK) return rc;
-  return p2m_gemm_planes(X, T1, T2, 3, Fin, in_shift, Wt, nullptr, bias, nullptr, Y, nullptr, nullptr, 1, Fout, 0,
-                         (int64_t)B * g->V, stats, nullptr, nullptr, 0, stream);
+  return p2m_gemm_planes(X, T1, T2, 3, Fin, in_shift, Wt, nullptr, P2M_ARITH_F32, nullptr, 0, bias, nullptr, Y, nullptr,
+                         nullptr, 1, Fout, 0, (int64_t)B * g->V, stats, nullptr, nullptr, 0, nullptr, stream);
 }

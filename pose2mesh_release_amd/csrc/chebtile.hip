@@ -25,7 +25,12 @@
 // HBM traffic per real row: the union rows once per tile (re-use across neighbouring tiles through L2, as in
 // k_basis_tile), plane 0 once (L2-warm: the row is in its own union), C once; optionally the two gathered planes
 // (backward: the weight gradient X^T [g | Lg | L2g] reads them).
-// LDS: 80 640 (A image) + 61 440 (union rows) + 15 872 (entries, rows padded to 4) + tables = 158.5 KB -> one block per CU:
+// (Measured and removed: a double-buffered image in half chunks of 16 features - 2 x 43 KB, entries as {a, b} pairs +
+// offsets, one barrier per half and no hand-over stall: 1.821 vs 1.793 ms on the finest 128 -> 128 conv, i.e. the same;
+// what bounds the kernel is the VALU issue of the gather's fmafs and the slice split next to the MFMA stream, 11.4
+// instructions per MFMA against 5.5 in the plain contraction, whose basis fmafs run in a separate HBM-bound kernel.)
+// LDS: 80 640 (A image; 53 760 with two fp16 slices) + 61 440 (union rows) + 15 872 (entries, rows padded to 4) + tables
+// = 158.5 KB (132 KB) -> one block per CU:
 // 4 MFMA waves + 8 producer waves (two per SIMD: the gather is a chain of dependent LDS reads, a second wave fills its
 // latencies) for N <= 128, 4 + 4 for N = 256 (the 128-register accumulator needs the 256-register budget).
 #include "p2m_split.h"
@@ -42,13 +47,13 @@ constexpr int CT_SPAD = 32;                   // + 64 bytes per sample: the two 
 constexpr int CT_SLICE = CT_S * 32 * CT_LDA + CT_S * CT_SPAD;     // bf16 per slice image
 constexpr int CT_ECAP = TILE_ECAP + 3 * TILE_RMAX + 8;            // entries of a tile, every row padded to a multiple of 4,
                                                                   // + slack for the gather's read-ahead
-constexpr int CT_AS_BYTES = 3 * CT_SLICE * 2;
+constexpr int ct_as_bytes(int ns) { return ns * CT_SLICE * 2; }   // A image: ns slices (3 bf16 / 2 fp16, p2m_split.h)
 constexpr int CT_XS_BYTES = TILE_UCAP * CT_S * CT_CF * 4;
 constexpr int CT_ENT_BYTES = CT_ECAP * 16;
 constexpr int CT_TAB_BYTES = 1024;            // rowoff[40], rowvid[32], rowlen[32], rawoff[40]
-constexpr int CT_LDS_BYTES = CT_AS_BYTES + CT_XS_BYTES + CT_ENT_BYTES + CT_TAB_BYTES;
+constexpr int ct_lds_bytes(int ns) { return ct_as_bytes(ns) + CT_XS_BYTES + CT_ENT_BYTES + CT_TAB_BYTES; }
 static_assert(TILE_RMAX == 32, "one MFMA tile per (tile, sample)");
-static_assert(CT_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+static_assert(ct_lds_bytes(3) <= 160 * 1024, "LDS budget of one CU");
 
 struct TileGemmArgs {
   TilePlan pl;
@@ -56,6 +61,10 @@ struct TileGemmArgs {
   const float* X;              // gather source [B][x_rows][Ka]
   const float* A0;             // plane 0       [B][a0_rows][Ka], row = row_ids[i] >> a0_shift
   const unsigned short* Bx;    // pre-split weight Bx[k / 16][slice][n][k % 16], k = plane * Ka + feature (p2m_weight_split)
+  const unsigned* x_amax;      // two-fp16-slice mode: amax words of X / A0 (+ x_bits binades for the planes) and of the weight
+  const unsigned* b_amax;
+  unsigned* amax_out;          // optional: atomic max of |value stored|
+  int x_bits;
   const float* bias;           // [N] or null
   const float* addend;         // [B][c_rows][N] or null
   const float* act_scale;      // optional fused eval-mode BatchNorm (+ ReLU), the two roundings of p2m_bn_act_fwd
@@ -68,13 +77,123 @@ struct TileGemmArgs {
   int act_relu, a0_shift, B, Ka, N, Npad, nset, gpb;
 };
 
-// TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
-// the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
 // MODE: what the epilogue does besides bias + store - compiled in, because an epilogue that tests addend / activation /
 // statistics pointers per element is ~2 900 instructions with 250 branches, and nothing covers it (one block per CU)
 enum { CT_PLAIN = 0, CT_STATS = 1, CT_ADDEND = 2, CT_ACT = 3 };
-template <int TM, int TN, int NPW, int MODE>
+// Epilogue of one sample group in the MFMA waves: bias (+ activation / addend), store, BatchNorm partials; then a fresh
+// accumulator.  MODE is compiled in (see above).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) +
+// 8 (reg >> 2) + 4 (lane >> 5).
+template <int TM, int TN, int MODE>
+__device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TilePlan& pl, floatx16 (&acc)[TM][TN],
+                                              const int* rowvid, int grp, int tile, int R, int wm, int wn, int l31,
+                                              int lhi, int descale) {
+  int voff[16];                                   // element offset of this lane's 16 accumulator rows inside one
+#pragma unroll                                          // sample of C (-1: no such row); < 2^31: V * N <= 3 M elements
+  for (int r = 0; r < 16; r++) {
+    const int vid = rowvid[(r & 3) + 8 * (r >> 2) + 4 * lhi];
+    voff[r] = vid < 0 ? -1 : vid * g.N;
+  }
+  // pass 1: values, in registers (no branches)
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int n = wn * TN * 32 + j * 32 + l31;
+    const float bias_v = g.bias != nullptr ? g.bias[n] : 0.f;
+    float sc_v = 1.f, sh_v = 0.f;
+    if (MODE == CT_ACT) { sc_v = g.act_scale[n]; sh_v = g.act_shift[n]; }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = __builtin_ldexpf(acc[i][j][r], descale) + bias_v;     // descale: two-fp16-slice mode, else 0
+        if (MODE == CT_ACT) {
+          v = fmaf(v, sc_v, sh_v);
+          if (g.act_relu) v = fmaxf(v, 0.f);
+        }
+        acc[i][j][r] = v;
+      }
+  }
+  // pass 2: stores, accumulator row by accumulator row: the row-validity mask is the same for every tile, a
+  // sample's validity is wave-uniform
+  const int b0s = grp * CT_S + wm * TM;
+  float vmax = 0.f;
+  float* Cb[TM][TN];
+  const float* Ab[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const long sbase = (long)(b0s + i < g.B ? b0s + i : 0) * g.c_rows * g.N;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      Cb[i][j] = g.C + sbase + wn * TN * 32 + j * 32 + l31;
+      Ab[i][j] = MODE == CT_ADDEND ? g.addend + sbase + wn * TN * 32 + j * 32 + l31 : nullptr;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    if (voff[r] >= 0) {
+      if (MODE == CT_ADDEND) {
+        float ad[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) ad[i][j] = b0s + i < g.B ? Ab[i][j][voff[r]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j][r] += ad[i][j];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        if (b0s + i < g.B) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            Cb[i][j][voff[r]] = acc[i][j][r];
+            vmax = fmaxf(vmax, fabsf(acc[i][j][r]));
+          }
+        }
+      }
+    }
+  }
+  if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
+  if (MODE == CT_STATS) {
+    // column sums over the tile's rows of each sample: the other 16 rows sit in lane ^ 32
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        float csum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) csum += voff[r] >= 0 ? acc[i][j][r] : 0.f;
+        csum += __shfl_xor(csum, 32);
+        const float mean = csum / (float)R;
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float d = acc[i][j][r] - mean;
+          m2 += voff[r] >= 0 ? d * d : 0.f;
+        }
+        m2 += __shfl_xor(m2, 32);
+        if (lhi == 0 && b0s + i < g.B) {
+          float* st = g.stats + ((long)(b0s + i) * pl.ntiles + tile) * 2 * g.N;
+          const int n = wn * TN * 32 + j * 32 + l31;
+          st[n] = csum;
+          st[g.N + n] = m2;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+}
+
+// TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
+// the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
+template <int TM, int TN, int NPW, int MODE, int NS>
 __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gemm(TileGemmArgs g) {
+  typedef typename SliceFrag<NS>::type frag_t;
+  constexpr int CT_AS_BYTES = ct_as_bytes(NS);
   constexpr int NT = 256 + 64 * NPW;          // 4 consumer waves + NPW producer waves
   constexpr int WM = CT_S / TM;               // consumer waves along the samples
   constexpr int WN = 4 / WM;                  // ... along the columns
@@ -141,6 +260,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   __syncthreads();
 
   const bool producer = t >= 256;             // wave-uniform
+  float x_sc = 1.f;                           // two-fp16-slice mode: the planes are staged times 2^sx
+  int descale = 0;
+  if (NS == 2) {
+    const int sx = slice_scale_exp(*g.x_amax, g.x_bits);
+    x_sc = exp2_int(sx);
+    descale = -(sx + slice_scale_exp(*g.b_amax, 0));
+  }
 
   if (producer) {
     // ------------------------------------------------------------------------------------------------------------
@@ -200,7 +326,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     lds_block_barrier();                                // B1(-1): xs(0) visible
     int grp = grp0, fc = 0;
     for (int w = 0; w < nunits; w++) {
-      u32x2 sp[NRP][3][3];                              // [row][plane][slice]: the A operand of this unit, held until the
+      u32x2 sp[NRP][3][NS];                             // [row][plane][slice]: the A operand of this unit, held until the
                                                         // MFMA waves release the image
 #pragma unroll
       for (int ps = 0; ps < NRP; ps++) {
@@ -237,9 +363,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
             __builtin_nontemporal_store(t2, reinterpret_cast<f32x4*>(g.E2 + o));
           }
         }
-        split3_pack4(p0[ps][0], p0[ps][1], p0[ps][2], p0[ps][3], sp[ps][0][0], sp[ps][0][1], sp[ps][0][2]);
-        split3_pack4(t1[0], t1[1], t1[2], t1[3], sp[ps][1][0], sp[ps][1][1], sp[ps][1][2]);
-        split3_pack4(t2[0], t2[1], t2[2], t2[3], sp[ps][2][0], sp[ps][2][1], sp[ps][2][2]);
+        split_pack4<NS>(p0[ps][0], p0[ps][1], p0[ps][2], p0[ps][3], x_sc, sp[ps][0]);
+        split_pack4<NS>(t1[0], t1[1], t1[2], t1[3], x_sc, sp[ps][1]);
+        split_pack4<NS>(t2[0], t2[1], t2[2], t2[3], x_sc, sp[ps][2]);
       }
       lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
                                                         //        every producer is done reading xs(w)
@@ -249,7 +375,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-          for (int sl = 0; sl < 3; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[ps][p][sl];
+          for (int sl = 0; sl < NS; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[ps][p][sl];
       }
       lds_block_barrier();                              // B1(w): image of unit w visible - the MFMA waves go; everything
                                                         //        below runs under their MFMAs, not in front of them
@@ -274,26 +400,26 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    // B fragments: byte address = Bx + ((plane * Ka/16 + fc * 2 + half) * 3 + slice) * Npad * 32 + (n * 16 + lhi * 8) * 2
+    // B fragments: byte address = Bx + ((plane * Ka/16 + fc * 2 + half) * NS + slice) * Npad * 32 + (n * 16 + lhi * 8) * 2
     const long bx_slice = (long)g.Npad * 32;            // bytes per slice of one 16-wide k chunk
-    const long bx_plane = (long)(g.Ka / 16) * 3 * bx_slice;
+    const long bx_plane = (long)(g.Ka / 16) * NS * bx_slice;
     const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
     constexpr int NB = TN == 1 ? 3 : 2;                 // ring of B fragment sets: the fragments of step st + NB - 1 are loaded
-    bf16x8 fb[NB][3][TN];                               // during step st (N = 256: no registers for a third set)
-    auto load_b = [&](int fc, int st, bf16x8 (&b)[3][TN]) {   // step st of chunk fc: plane st / 2, half st & 1
-      const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * 3 * bx_slice;
+    frag_t fb[NB][NS][TN];                              // during step st (N = 256: no registers for a third set)
+    auto load_b = [&](int fc, int st, frag_t (&b)[NS][TN]) {  // step st of chunk fc: plane st / 2, half st & 1
+      const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * NS * bx_slice;
 #pragma unroll
-      for (int sl = 0; sl < 3; sl++)
+      for (int sl = 0; sl < NS; sl++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          b[sl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + sl * bx_slice + j * (32 * 16 * 2)));
+          b[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(src + sl * bx_slice + j * (32 * 16 * 2)));
     };
     const unsigned short* a_lane = As + ((wm * TM) * 32 + l31) * CT_LDA + (wm * TM) * CT_SPAD + lhi * 8;
-    auto read_a = [&](int sl, int st, bf16x8 (&a)[TM]) {
+    auto read_a = [&](int sl, int st, frag_t (&a)[TM]) {
 #pragma unroll
       for (int i = 0; i < TM; i++)
         a[i] = __builtin_bit_cast(
-            bf16x8, *reinterpret_cast<const u32x4*>(a_lane + sl * CT_SLICE + i * (32 * CT_LDA + CT_SPAD) + st * 16));
+            frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * CT_SLICE + i * (32 * CT_LDA + CT_SPAD) + st * 16));
     };
     load_b(0, 0, fb[0]);
     if (NB == 3) load_b(0, 1, fb[1]);
@@ -303,8 +429,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
       lds_block_barrier();                              // B2(w)
       lds_block_barrier();                              // B1(w): image of unit w is in LDS
-      bf16x8 fl[TM];                                    // the low-slice A fragments: what the first MFMAs of a step read
-      read_a(2, 0, fl);
+      frag_t fl[TM];                                    // the low-slice A fragments: what the first MFMAs of a step read
+      read_a(NS - 1, 0, fl);
 #pragma unroll
       for (int st = 0; st < 6; st++) {
         // B fragments NB - 1 steps ahead (they do not depend on the producers; the last steps fetch the next unit's first).
@@ -314,127 +440,39 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
         else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 fh[TM], fm[TM];
+        frag_t fh[TM], fm[TM];
         read_a(0, st, fh);
-        read_a(1, st, fm);
+        if constexpr (NS == 3) read_a(1, st, fm);
 #define P2M_PAIR(FA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], fb[st % NB][SB][j], acc[i][j], 0, 0, 0);
+      acc[i][j] = slice_mfma<NS>(FA[i], fb[st % NB][SB][j], acc[i][j]);
         P2M_PAIR(fl, 0)
         __builtin_amdgcn_sched_barrier(0);
-        if (st < 5) read_a(2, st + 1, fl);              // the next step's first operands, under this step's other 5/6
-        P2M_PAIR(fh, 2)
-        P2M_PAIR(fm, 1)
-        P2M_PAIR(fm, 0)
-        P2M_PAIR(fh, 1)
-        P2M_PAIR(fh, 0)
+        if (st < 5) read_a(NS - 1, st + 1, fl);         // the next step's first operands, under this step's other products
+        if constexpr (NS == 3) {
+          P2M_PAIR(fh, 2)
+          P2M_PAIR(fm, 1)
+          P2M_PAIR(fm, 0)
+          P2M_PAIR(fh, 1)
+          P2M_PAIR(fh, 0)
+        } else {
+          P2M_PAIR(fh, 1)
+          P2M_PAIR(fh, 0)
+        }
 #undef P2M_PAIR
         __builtin_amdgcn_sched_barrier(0);
         if (st == 1) lds_block_barrier();               // B3(w): the producers' xs stores for unit w + 1 (not ours to wait
                                                         //        for, but s_barrier is block-wide)
       }
       if (fc == nchunks - 1) {
-        // ---- epilogue of this sample group: bias (+ activation / addend), store, BatchNorm partials; then a fresh accumulator
-        int voff[16];                                   // element offset of this lane's 16 accumulator rows inside one
-#pragma unroll                                          // sample of C (-1: no such row); < 2^31: V * N <= 3 M elements
-        for (int r = 0; r < 16; r++) {
-          const int vid = rowvid[(r & 3) + 8 * (r >> 2) + 4 * lhi];
-          voff[r] = vid < 0 ? -1 : vid * g.N;
-        }
-        // pass 1: values, in registers (no branches)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int n = wn * TN * 32 + j * 32 + l31;
-          const float bias_v = g.bias != nullptr ? g.bias[n] : 0.f;
-          float sc_v = 1.f, sh_v = 0.f;
-          if (MODE == CT_ACT) { sc_v = g.act_scale[n]; sh_v = g.act_shift[n]; }
-#pragma unroll
-          for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-              float v = acc[i][j][r] + bias_v;
-              if (MODE == CT_ACT) {
-                v = fmaf(v, sc_v, sh_v);
-                if (g.act_relu) v = fmaxf(v, 0.f);
-              }
-              acc[i][j][r] = v;
-            }
-        }
-        // pass 2: stores, accumulator row by accumulator row: the row-validity mask is the same for every tile, a
-        // sample's validity is wave-uniform
-        const int b0s = grp * CT_S + wm * TM;
-        float* Cb[TM][TN];
-        const float* Ab[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-          const long sbase = (long)(b0s + i < g.B ? b0s + i : 0) * g.c_rows * g.N;
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            Cb[i][j] = g.C + sbase + wn * TN * 32 + j * 32 + l31;
-            Ab[i][j] = MODE == CT_ADDEND ? g.addend + sbase + wn * TN * 32 + j * 32 + l31 : nullptr;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (voff[r] >= 0) {
-            if (MODE == CT_ADDEND) {
-              float ad[TM][TN];
-#pragma unroll
-              for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) ad[i][j] = b0s + i < g.B ? Ab[i][j][voff[r]] : 0.f;
-#pragma unroll
-              for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j][r] += ad[i][j];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-              if (b0s + i < g.B) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) Cb[i][j][voff[r]] = acc[i][j][r];
-              }
-            }
-          }
-        }
-        if (MODE == CT_STATS) {
-          // column sums over the tile's rows of each sample: the other 16 rows sit in lane ^ 32
-#pragma unroll
-          for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-              float csum = 0.f;
-#pragma unroll
-              for (int r = 0; r < 16; r++) csum += voff[r] >= 0 ? acc[i][j][r] : 0.f;
-              csum += __shfl_xor(csum, 32);
-              const float mean = csum / (float)R;
-              float m2 = 0.f;
-#pragma unroll
-              for (int r = 0; r < 16; r++) {
-                const float d = acc[i][j][r] - mean;
-                m2 += voff[r] >= 0 ? d * d : 0.f;
-              }
-              m2 += __shfl_xor(m2, 32);
-              if (lhi == 0 && b0s + i < g.B) {
-                float* st = g.stats + ((long)(b0s + i) * pl.ntiles + tile) * 2 * g.N;
-                const int n = wn * TN * 32 + j * 32 + l31;
-                st[n] = csum;
-                st[g.N + n] = m2;
-              }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
         grp++;
       }
       fc = fcn;
     }
   }
 }
+
 
 }  // namespace p2m
 
@@ -449,31 +487,36 @@ static int pick_gpb(int ntiles, int ngroups) {
   return gpb;
 }
 
-template <int TM, int TN, int NPW, int MODE>
+template <int TM, int TN, int NPW, int MODE, int NS>
 static int launch_tile_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
+  constexpr int LDS_BYTES = ct_lds_bytes(NS);
   static bool attr_set = false;     // once per process and instantiation (never inside a stream capture: the first call
                                     // of every shape happens in the eager warm-up steps)
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, CT_LDS_BYTES);
+    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {
-      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", CT_LDS_BYTES, hipGetErrorString(e));
+      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e));
       return P2M_ERR_HIP;
     }
     attr_set = true;
   }
   const int ngroups = cdiv(a.B, CT_S);
   const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
-  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE>), dim3(nblocks), dim3(256 + 64 * NPW), CT_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>), dim3(nblocks), dim3(256 + 64 * NPW), LDS_BYTES, s, a);
   return check_launch("cheb_tile_gemm");
 }
 
+template <int TM, int TN, int NPW, int NS>
+static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
+  if (a.stats != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_STATS, NS>(a, s);
+  if (a.addend != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_ADDEND, NS>(a, s);
+  if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT, NS>(a, s);
+  return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN, NS>(a, s);
+}
 template <int TM, int TN, int NPW>
 static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
-  if (a.stats != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_STATS>(a, s);
-  if (a.addend != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_ADDEND>(a, s);
-  if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT>(a, s);
-  return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN>(a, s);
+  return a.x_amax != nullptr ? launch_tile_gemm_ns<TM, TN, NPW, 2>(a, s) : launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
 }
 
 extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, int32_t Ka, int32_t N) {
@@ -485,10 +528,13 @@ extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, in
 }
 
 extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, const float* A0, int32_t Ka,
-                                  const void* Bx, const float* bias, const float* addend, float* C, int32_t N,
-                                  float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,
-                                  int32_t act_relu, int32_t B, void* stream) {
+                                  const void* Bx, int32_t arith, const void* x_amax, const float* bias,
+                                  const float* addend, float* C, int32_t N, float* stats, float* E1, float* E2,
+                                  const float* act_scale, const float* act_shift, int32_t act_relu, void* amax_out,
+                                  int32_t B, void* stream) {
   P2M_CHECK_ARG(gh && X && A0 && Bx && C, "null pointer");
+  P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
+  P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || x_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of X / A0");
   P2M_CHECK_ARG(plan >= 0 && plan <= 2, "plan must be 0 (level), 1 (un-pooled input) or 2 (paired operator)");
   P2M_CHECK_ARG((E1 == nullptr) == (E2 == nullptr), "E1 / E2 must both be given or both NULL");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
@@ -527,6 +573,14 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   a.Ka = Ka;
   a.N = N;
   a.Npad = cdiv(N, 128) * 128;          // the layout p2m_weight_split writes
+  a.x_amax = a.b_amax = nullptr;
+  a.x_bits = 0;
+  if (arith == P2M_ARITH_F16X2) {
+    a.x_amax = static_cast<const unsigned*>(x_amax);
+    a.x_bits = g.plane_bits + (paired ? 1 : 0);
+    a.b_amax = reinterpret_cast<const unsigned*>(a.Bx + 2l * a.Npad * 3 * Ka);     // trails the slices (p2m_weight_split)
+  }
+  a.amax_out = static_cast<unsigned*>(amax_out);
   a.gpb = pick_gpb(a.pl.ntiles, cdiv(B, CT_S));
   hipStream_t s = (hipStream_t)stream;
   if (N == 256) return launch_tile_gemm<4, 2, 4>(a, s);

@@ -6,11 +6,13 @@
 //
 // Replaces nn.Linear inside graph_conv_cheby (lib/models/backbones/cheby_graph_conv.py:37), the
 // fc lift (lib/models/meshnet.py:105) and their autograd backward.  1e-4 vertex parity needs fp32 products; gfx950
-// has no TF32/xf32.  Two arithmetics compute the same fp32 contraction (include/p2m.h, P2M_ARITH_*):
+// has no TF32/xf32.  Three arithmetics compute the same fp32 contraction (include/p2m.h, P2M_ARITH_*):
 //   plain    native f32 MFMA v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, 157 TFLOP/s peak);
-//   _bx/_ws  every operand cut exactly into three bf16 slices, six slice products per fp32 product on
-//            v_mfma_f32_32x32x16_bf16 (2500 / 6 = 417 TFLOP/s peak), fp32 accumulation - the default.  _ws is the
-//            wave-specialised form (4 MFMA waves + 4 staging waves per block), _bx the 4-wave form.
+//   _ws<3>   every operand cut exactly into three bf16 slices, six slice products per fp32 product on
+//            v_mfma_f32_32x32x16_bf16 (2500 / 6 = 417 TFLOP/s peak), fp32 accumulation;
+//   _ws<2>   every operand scaled by a power of two (from its amax word) and cut into two fp16 slices, three slice
+//            products on v_mfma_f32_32x32x16_f16 (2500 / 3 = 833 TFLOP/s peak), 22-bit operands (p2m_split.h).
+//            _ws = wave-specialised (4 MFMA waves + 4 staging waves per block).
 //
 // Tiling (64-wide waves), all variants: the MFMA waves are arranged 2(M) x 2(N); block tile 128 x BN (BN = 128 or
 // 64); each wave owns 64 x BN/2 = (2 x BN/64) MFMA 32x32 tiles; K chunk 32 (f32) or 16 (bf16 slices) per barrier,
@@ -51,6 +53,11 @@ struct GemmArgs {
   // split-bf16 mode (k_gemm_planes_bx): Bx[k / 16][s][n][k % 16], s < 3, n < Npad, k < Ktot = nplanesA * Ka
   const unsigned short* Bx;
   int Npad, Ktot;
+  // two-fp16-slice mode: amax words (p2m_split.h) of the A planes (+ a_bits binades of headroom) and of the weight
+  const unsigned* a_amax;
+  const unsigned* b_amax;
+  int a_bits;
+  unsigned* amax_out;    // optional: receives max |value stored| (atomic max; the caller zeroes it)
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -69,7 +76,7 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
 template <int BN, bool EXTRA, bool ROWS>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][BN / 64], float* smem,
                                               const int* rowtab, int mt, long m0, int n0, int rs_i0, int wm, int wn,
-                                              int l31, int lhi) {
+                                              int l31, int lhi, int descale = 0) {
   constexpr int WTN = BN / 2;
   constexpr int TN = WTN / 32;
   constexpr int TM = 2;
@@ -84,6 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
     sh_v[j] = (g.act_scale != nullptr && ncol[j] < g.N) ? g.act_shift[ncol[j]] : 0.f;
   }
   float csum[TN];
+  float vmax = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; j++) csum[j] = 0.f;
 #pragma unroll
@@ -99,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         long row = ROWS ? (long)rowtab[ml] : m0 + ml;
         const bool rok = ROWS ? (row >= 0) : (row < g.M);
-        float v = acc[i][j][r] + bias_v[j];
+        float v = __builtin_ldexpf(acc[i][j][r], descale) + bias_v[j];     // descale: exact (two-fp16-slice mode), else 0
         if (g.act_scale != nullptr) v = fmaf(v, sc_v[j], sh_v[j]);
         if (g.act_relu) v = fmaxf(v, 0.f);
         if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
@@ -107,16 +115,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
           Cq[row * g.Nc + c] = v;
           csum[j] += v;
+          vmax = fmaxf(vmax, fabsf(v));
         }
       }
       if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < g.M) Cq[(row >> 1) * g.Nc + c] = acc[i][j][r] + acc[i][j][r + 1];
+          if (row < g.M) {
+            const float pv = acc[i][j][r] + acc[i][j][r + 1];
+            Cq[(row >> 1) * g.Nc + c] = pv;
+            vmax = fmaxf(vmax, fabsf(pv));
+          }
         }
       }
     }
+  if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
   if (g.stats == nullptr) return;
 
   // column sums over the 128-row tile: lane^32 holds the same column, the other wm wave the other 64 rows
@@ -332,9 +346,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
 //  (-1.4 % on the step), the BatchNorm-backward reduction in this kernel's epilogue (its 4-byte strided reads of the
 //  layer's raw input cost the contraction +4.5 ms, the pass they replace 3.3 ms).)
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool EXTRA, bool ROWS>
+template <int BN, bool EXTRA, bool ROWS, int NS>
 __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
-  constexpr int NS = 3, KB = 16;
+  constexpr int KB = 16;
+  typedef typename SliceFrag<NS>::type frag_t;
   constexpr int NBUF = 2, NST = 2;    // LDS ring of two chunks, two register stages of lead
   constexpr int AHEAD = NBUF - 1;     // the producers store chunk kc + AHEAD during iteration kc
   constexpr int WTN = BN / 2;
@@ -370,6 +385,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   const int cpp = g.Ka / KB;
   const int n = g.nplanesA * cpp;           // chunks
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // two-fp16-slice mode: the A planes are staged times 2^sa, the weight arrives times 2^sb (p2m_weight_split)
+  float a_sc = 1.f;
+  int descale = 0;
+  if (NS == 2) {
+    const int sa = slice_scale_exp(*g.a_amax, g.a_bits);
+    a_sc = exp2_int(sa);
+    descale = -(sa + slice_scale_exp(*g.b_amax, 0));
+  }
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -435,11 +458,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
       for (int ps = 0; ps < APASS; ps++)
         a[ps] = *reinterpret_cast<const f32x4*>(Ab + (p == 0 ? voff0[ps] : voff12[ps]));
       const char* src0 = reinterpret_cast<const char*>(g.Bx + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice));   // uniform
-      const char* src1 = src0 + 2 * bx_slice;
-      const char* src2 = src1 + 2 * bx_slice;
-      b[0] = *reinterpret_cast<const u32x4*>(src0 + bx_voff);
-      b[1] = *reinterpret_cast<const u32x4*>(src1 + bx_voff);
-      b[2] = *reinterpret_cast<const u32x4*>(src2 + bx_voff);
+#pragma unroll
+      for (int sl = 0; sl < NS; sl++) b[sl] = *reinterpret_cast<const u32x4*>(src0 + sl * 2 * bx_slice + bx_voff);
     };
     auto store_chunk = [&](int kc, f32x4 (&a)[APASS], const u32x4 (&b)[NS]) {
       const int buf = kc % NBUF;
@@ -448,17 +468,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
       for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(a[ps]));
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
-        u32x2 ph, pm, pl;
-        split3_pack4(a[ps][0], a[ps][1], a[ps][2], a[ps][3], ph, pm, pl);
+        u32x2 sl[NS];
+        split_pack4<NS>(a[ps][0], a[ps][1], a[ps][2], a[ps][3], a_sc, sl);
         unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
-        *reinterpret_cast<u32x2*>(d) = ph;
-        *reinterpret_cast<u32x2*>(d + BM * LDX) = pm;
-        *reinterpret_cast<u32x2*>(d + 2 * BM * LDX) = pl;
+#pragma unroll
+        for (int q = 0; q < NS; q++) *reinterpret_cast<u32x2*>(d + q * BM * LDX) = sl[q];
       }
       unsigned short* d = Bs + buf * B_BUF + b_n * LDX + b_half;
-      *reinterpret_cast<u32x4*>(d) = b[0];
-      *reinterpret_cast<u32x4*>(d + BN * LDX) = b[1];
-      *reinterpret_cast<u32x4*>(d + 2 * BN * LDX) = b[2];
+#pragma unroll
+      for (int q = 0; q < NS; q++) *reinterpret_cast<u32x4*>(d + q * BN * LDX) = b[q];
     };
     const int last = n - 1;
     // chunk c lives in register stage c % NST and LDS buffer c % NBUF.  Prologue: chunks 0..AHEAD-1 stored, the next NST
@@ -492,8 +510,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
       }
     }
   } else {
-    bf16x8 fa[NBUF - 1][NS][TM], fb[NBUF - 1][NS][TN];       // [register set][slice h,m,l][tile]
-    auto read_frags = [&](int kc, bf16x8 (&a)[NS][TM], bf16x8 (&b)[NS][TN]) {
+    frag_t fa[NBUF - 1][NS][TM], fb[NBUF - 1][NS][TN];       // [register set][slice, high first][tile]
+    auto read_frags = [&](int kc, frag_t (&a)[NS][TM], frag_t (&b)[NS][TN]) {
       const int buf = kc % NBUF;
       const unsigned short* as = As + buf * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
       const unsigned short* bs = Bs + buf * B_BUF + (wn * WTN + l31) * LDX + lhi * 8;
@@ -501,22 +519,28 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
       for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
-          a[sl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(as + (sl * BM + i * 32) * LDX));
+          a[sl][i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(as + (sl * BM + i * 32) * LDX));
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          b[sl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bs + (sl * BN + j * 32) * LDX));
+          b[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(bs + (sl * BN + j * 32) * LDX));
       }
     };
-    auto mfmas = [&](const bf16x8 (&a)[NS][TM], const bf16x8 (&b)[NS][TN]) {
+    auto mfmas = [&](const frag_t (&a)[NS][TM], const frag_t (&b)[NS][TN]) {
 #define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SA][i], b[SB][j], acc[i][j], 0, 0, 0);
-      P2M_PAIR(2, 0)
-      P2M_PAIR(0, 2)
-      P2M_PAIR(1, 1)
-      P2M_PAIR(1, 0)
-      P2M_PAIR(0, 1)
-      P2M_PAIR(0, 0)
+      acc[i][j] = slice_mfma<NS>(a[SA][i], b[SB][j], acc[i][j]);
+      if constexpr (NS == 3) {          // smallest products first
+        P2M_PAIR(2, 0)
+        P2M_PAIR(0, 2)
+        P2M_PAIR(1, 1)
+        P2M_PAIR(1, 0)
+        P2M_PAIR(0, 1)
+        P2M_PAIR(0, 0)
+      } else {
+        P2M_PAIR(1, 0)
+        P2M_PAIR(0, 1)
+        P2M_PAIR(0, 0)
+      }
 #undef P2M_PAIR
     };
     lds_barrier();                              // the first AHEAD chunks are in LDS
@@ -528,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   }
   __syncthreads();   // staging buffers are free: the epilogue reuses them
   if (!producer) {
-    gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi);
+    gemm_epilogue<BN, EXTRA, ROWS>(g, acc, smem, rowtab, mt, m0, n0, rs_i0, wm, wn, l31, lhi, descale);
   } else {
     if (g.stats != nullptr) {                   // the three block barriers of the statistics reduction
       __syncthreads();
@@ -540,17 +564,87 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
 
 // Bx[k / 16][s][n][k % 16] = s-th bf16 slice of Bm[k][n] (zero for N <= n < Npad): the pre-split weight operand,
 // chunk-major so that the [BN x 16] slice a block stages per chunk is one contiguous run
-__global__ void k_weight_split(const float* __restrict__ Bm, unsigned short* __restrict__ Bx, int K, int N, int Npad) {
+// NS = 2: fp16 slices of Bm 2^sb, sb from the bound 2^bits * (*amax_in) - the word trailing the image itself (bits = 0,
+// written by k_amax_one_block just before) or the word of the tensor Bm was derived from; the trailer then receives
+// that bound, so every consumer re-derives the same sb from the image alone
+template <int NS>
+__global__ void k_weight_split(const float* __restrict__ Bm, unsigned short* __restrict__ Bx, int K, int N, int Npad,
+                               const unsigned* __restrict__ amax_in, int bits) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Npad * K) return;
   const int k = (int)(i / Npad), n = (int)(i - (long)k * Npad);      // n fastest: coalesced reads of Bm
-  unsigned h = 0, m = 0, l = 0;
-  if (n < N) split3(Bm[(long)k * N + n], h, m, l);
   const long sl = (long)Npad * 16;
-  unsigned short* d = Bx + (long)(k >> 4) * 3 * sl + (long)n * 16 + (k & 15);
-  d[0] = (unsigned short)(h >> 16);
-  d[sl] = (unsigned short)(m >> 16);
-  d[2 * sl] = (unsigned short)(l >> 16);
+  unsigned short* d = Bx + (long)(k >> 4) * NS * sl + (long)n * 16 + (k & 15);
+  if constexpr (NS == 3) {
+    unsigned h = 0, m = 0, l = 0;
+    if (n < N) split3(Bm[(long)k * N + n], h, m, l);
+    d[0] = (unsigned short)(h >> 16);
+    d[sl] = (unsigned short)(m >> 16);
+    d[2 * sl] = (unsigned short)(l >> 16);
+  } else {
+    unsigned* trailer = reinterpret_cast<unsigned*>(Bx + (long)NS * Npad * K);
+    const unsigned word = *amax_in;
+    if (i == 0 && amax_in != trailer) *trailer = word == 0u ? 0u : __float_as_uint(__builtin_ldexpf(__uint_as_float(word), bits));
+    const float y = n < N ? Bm[(long)k * N + n] * exp2_int(slice_scale_exp(word, bits)) : 0.f;
+    const _Float16 h = (_Float16)y;
+    const _Float16 l = (_Float16)(y - (float)h);
+    d[0] = __builtin_bit_cast(unsigned short, h);
+    d[sl] = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
+// amax words (p2m_split.h).  One block, overwrites the word: for small tensors (weights) - no zeroing, no atomics.
+__global__ __launch_bounds__(1024) void k_amax_one_block(const float* __restrict__ x, long n, unsigned* __restrict__ word) {
+  __shared__ float red[16];
+  float m = 0.f;
+  const long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n >> 2 : 0;      // float4 body, 8 loads in flight per thread
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  long i = threadIdx.x;
+  for (; i + 7 * 1024 < n4; i += 8 * 1024) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = x4[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+  }
+  for (; i < n4; i += 1024) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (long j = n4 * 4 + threadIdx.x; j < n; j += 1024) m = fmaxf(m, fabsf(x[j]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) m = fmaxf(m, red[w]);
+    *word = __float_as_uint(m);
+  }
+}
+// Any size: atomic max into a word the caller has zeroed.  n4 = float4 count (n % 4 == 0, 16-byte aligned base).
+__global__ __launch_bounds__(256) void k_amax(const f32x4* __restrict__ x, long n4, unsigned* __restrict__ word) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = x[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  amax_commit(word, m);
+}
+// The rows of a row set only (the others may hold no data): row (b, i) -> b * V + ids[i], F % 4 == 0
+__global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, RowSet rs, int B, int F,
+                                                   unsigned* __restrict__ word) {
+  const int f4 = F >> 2;
+  const long tot = (long)B * rs.n * f4;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long row = i / f4;
+    const int c = (int)(i - row * f4);
+    const int b = (int)(row / rs.n), r = (int)(row - (long)b * rs.n);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * rs.V + (rs.ids ? rs.ids[r] : r)) * F + c * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  amax_commit(word, m);
 }
 
 // scalar fall-back (first conv Fin=5 -> K=15; last conv Fout=3): one thread per (row, n)
@@ -608,6 +702,10 @@ struct TnArgs {
   // b*V + ids[i], G planes 1,2 at the compact row b*nset + i when `compact`
   const int* ids;
   int nset, V, splits, compact;
+  // two-fp16-slice mode: amax words of the A planes and of the G planes (+ binades of headroom), p2m_split.h
+  const unsigned* a_amax;
+  const unsigned* g_amax;
+  int a_bits, g_bits;
 };
 
 template <int BN, bool ROWS = false>
@@ -782,9 +880,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Wave-specialised (4 MFMA waves + 4 staging waves, one LDS-only barrier per 16-row stage, two register stages of lead);
 // see k_gemm_planes_ws.
-template <int BN, bool ROWS = false>
+template <int BN, bool ROWS, int NS>
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
-  constexpr int NS = 3;
+  typedef typename SliceFrag<NS>::type frag_t;
   constexpr int RK = 16;                 // rows (reduction) per stage = one bf16 MFMA k-step
   constexpr int LDX = RK + 8;            // bf16 per LDS row: 48-byte stride, conflict-free ds_read_b128
   constexpr int WTN = BN / 2;
@@ -857,6 +955,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     }
   }
   const int buf_stride = is_a ? A_BUF : G_BUF;
+  float my_sc = 1.f;                     // two-fp16-slice mode: this staging wave's operand is staged times 2^s
+  int descale = 0;
+  if (NS == 2) {
+    const int sa = slice_scale_exp(*g.a_amax, g.a_bits), sg = slice_scale_exp(*g.g_amax, g.g_bits);
+    my_sc = exp2_int(is_a ? sa : sg);
+    descale = -(sa + sg);
+  }
   const int* idp = ROWS ? g.ids + r_begin + rq * 4 : nullptr;
   // Addresses: per-thread 64-bit base (plane + column + the first row of this block's sample / chunk), fixed for the
   // whole kernel, plus a 32-bit byte offset per load = (row relative to that base >> shift) * pitch * 4: three 32-bit
@@ -904,11 +1009,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     unsigned short* d = dst + buf * buf_stride;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      u32x2 ph, pm, pl;
-      split3_pack4(x[0][e], x[1][e], x[2][e], x[3][e], ph, pm, pl);
-      *reinterpret_cast<u32x2*>(d + e * LDX) = ph;
-      *reinterpret_cast<u32x2*>(d + e * LDX + slice_stride) = pm;
-      *reinterpret_cast<u32x2*>(d + e * LDX + 2 * slice_stride) = pl;
+      u32x2 sl[NS];
+      split_pack4<NS>(x[0][e], x[1][e], x[2][e], x[3][e], my_sc, sl);
+#pragma unroll
+      for (int q = 0; q < NS; q++) *reinterpret_cast<u32x2*>(d + e * LDX + q * slice_stride) = sl[q];
     }
   };
   using std::false_type;
@@ -916,30 +1020,31 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   auto compute = [&](int cur) {
     const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
     const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + l31) * LDX + lhi * 8;
-    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+    frag_t fa[NS][TM], fb[NS][TN];       // [slice, high first][tile]
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const unsigned short* q = as + i * 32 * LDX;
-      ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-      am[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BM * LDX));
-      al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BM * LDX));
-    }
+    for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const unsigned short* q = gs + j * 32 * LDX;
-      bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q));
-      bm[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + BN * LDX));
-      bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(q + 2 * BN * LDX));
+      for (int i = 0; i < TM; i++)
+        fa[sl][i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(as + (sl * BM + i * 32) * LDX));
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+        fb[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(gs + (sl * BN + j * 32) * LDX));
     }
-#define P2M_PAIR(XA, XB)                                                                       \
+#define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA[i], XB[j], acc[i][j], 0, 0, 0);
-    P2M_PAIR(al, bh)
-    P2M_PAIR(ah, bl)
-    P2M_PAIR(am, bm)
-    P2M_PAIR(am, bh)
-    P2M_PAIR(ah, bm)
-    P2M_PAIR(ah, bh)
+      acc[i][j] = slice_mfma<NS>(fa[SA][i], fb[SB][j], acc[i][j]);
+    if constexpr (NS == 3) {            // smallest products first
+      P2M_PAIR(2, 0)
+      P2M_PAIR(0, 2)
+      P2M_PAIR(1, 1)
+      P2M_PAIR(1, 0)
+      P2M_PAIR(0, 1)
+      P2M_PAIR(0, 0)
+    } else {
+      P2M_PAIR(1, 0)
+      P2M_PAIR(0, 1)
+      P2M_PAIR(0, 0)
+    }
 #undef P2M_PAIR
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -1007,7 +1112,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = acc[i][j][r];
+          if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = __builtin_ldexpf(acc[i][j][r], descale);
         }
       }
   }
@@ -1162,28 +1267,88 @@ using namespace p2m;
 extern "C" int32_t p2m_stats_tile_rows(void) { return BM; }
 
 
-extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N) {
-  if (K <= 0 || N <= 0 || K % 16 != 0) return 0;
-  return 3ll * (cdiv(N, 128) * 128ll) * K;
+static inline int slices_of(int arith) { return arith == P2M_ARITH_F16X2 ? 2 : 3; }
+// the amax word of a two-fp16-slice weight image trails its slices (8 elements = 16 bytes: keeps images 16-byte sized)
+static inline const unsigned* weight_amax_word(const void* Bx, int arith, long Npad, long K) {
+  return arith == P2M_ARITH_F16X2
+             ? reinterpret_cast<const unsigned*>(static_cast<const unsigned short*>(Bx) + 2 * Npad * K)
+             : nullptr;
 }
 
-extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, void* Bx, void* stream) {
+extern "C" int64_t p2m_weight_split_elems(int32_t K, int32_t N, int32_t arith) {
+  if (K <= 0 || N <= 0 || K % 16 != 0 || (arith != P2M_ARITH_BF16X3 && arith != P2M_ARITH_F16X2)) return 0;
+  return (long)slices_of(arith) * (cdiv(N, 128) * 128ll) * K + (arith == P2M_ARITH_F16X2 ? 8 : 0);
+}
+
+extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t arith, const void* amax_in,
+                                int32_t amax_bits, void* Bx, void* stream) {
   P2M_CHECK_ARG(Bm && Bx && K > 0 && N > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(K % 16 == 0, "K must be a multiple of 16");
+  P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
   const int Npad = cdiv(N, 128) * 128;
-  hipLaunchKernelGGL(k_weight_split, dim3(cdiv((long)Npad * K, 256)), dim3(256), 0, (hipStream_t)stream, Bm,
-                     static_cast<unsigned short*>(Bx), K, N, Npad);
+  const dim3 grid(cdiv((long)Npad * K, 256));
+  unsigned short* bx = static_cast<unsigned short*>(Bx);
+  if (arith == P2M_ARITH_F16X2) {
+    const unsigned* word = static_cast<const unsigned*>(amax_in);
+    P2M_CHECK_ARG(amax_bits >= 0 && amax_bits <= 30, "amax_bits out of range");
+    if (word == nullptr) {              // no bound from the caller: the weight's own maximum (one small extra launch)
+      unsigned* trailer = const_cast<unsigned*>(weight_amax_word(Bx, arith, Npad, K));
+      hipLaunchKernelGGL(k_amax_one_block, dim3(1), dim3(1024), 0, (hipStream_t)stream, Bm, (long)K * N, trailer);
+      word = trailer;
+      amax_bits = 0;
+    }
+    hipLaunchKernelGGL(k_weight_split<2>, grid, dim3(256), 0, (hipStream_t)stream, Bm, bx, K, N, Npad, word, amax_bits);
+  } else {
+    hipLaunchKernelGGL(k_weight_split<3>, grid, dim3(256), 0, (hipStream_t)stream, Bm, bx, K, N, Npad, nullptr, 0);
+  }
   return check_launch("weight_split");
 }
 
-// picks the instantiation: tile width from N, EXTRA epilogue, native f32 MFMA or split-bf16 (g.Bx != nullptr)
+extern "C" int p2m_amax(const float* x, int64_t n, void* word, void* stream) {
+  P2M_CHECK_ARG(x && word && n >= 0, "null pointer");
+  P2M_CHECK_ARG(n % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "n must be a multiple of 4, x 16-byte aligned");
+  if (n == 0) return P2M_OK;
+  const long n4 = n / 4;
+  const int grid = (int)(n4 < 256l * 2048 ? cdiv(n4, 256) : 2048);
+  hipLaunchKernelGGL(k_amax, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x), n4,
+                     static_cast<unsigned*>(word));
+  return check_launch("amax");
+}
+
+extern "C" int p2m_amax_rows(p2m_graph_t gh, int32_t row_set, const float* x, int32_t B, int32_t F, void* word,
+                             void* stream) {
+  P2M_CHECK_ARG(gh && x && word, "null pointer");
+  P2M_CHECK_ARG(row_set >= 0 && row_set <= 4, "row_set must be 0 (live rows) or 1..4");
+  P2M_CHECK_ARG(F > 0 && F % 4 == 0, "F must be a positive multiple of 4");
+  const Graph& gr = *reinterpret_cast<const Graph*>(gh);
+  RowSet rs;
+  if (row_set == 0) {                       // every row that holds data: all of them, or the live ones under classes
+    rs.V = gr.V;
+    rs.ids = gr.live_ids;
+    rs.n = gr.live_ids ? gr.n_live : gr.V;
+  } else {
+    rs = row_set_of(gr, row_set);
+  }
+  if (B <= 0 || rs.n == 0) return P2M_OK;
+  const long tot = (long)B * rs.n * (F / 4);
+  const int grid = (int)(tot < 256l * 2048 ? cdiv(tot, 256) : 2048);
+  hipLaunchKernelGGL(k_amax_rows, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rs, B, F, static_cast<unsigned*>(word));
+  return check_launch("amax_rows");
+}
+
+// picks the instantiation: tile width from N, EXTRA epilogue, native f32 MFMA or slices (g.Bx != nullptr; two fp16
+// slices when g.a_amax is set)
 template <bool ROWS>
 static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
   const bool wide = (g.N % 128 == 0);
   g.ntn = wide ? g.N / 128 : cdiv(g.N, 64);
   const dim3 grid(cdiv(g.ntm, 8) * 8 * g.ntn);
   if (g.Bx != nullptr) {
-#define P2M_LAUNCH_WS(BNv, EX) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS>), grid, dim3(512), 0, s, g)
+#define P2M_LAUNCH_WS(BNv, EX)                                                                              \
+  do {                                                                                                      \
+    if (g.a_amax != nullptr) hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 2>), grid, dim3(512), 0, s, g); \
+    else hipLaunchKernelGGL((k_gemm_planes_ws<BNv, EX, ROWS, 3>), grid, dim3(512), 0, s, g);                 \
+  } while (0)
     if (wide) { if (extra) P2M_LAUNCH_WS(128, true); else P2M_LAUNCH_WS(128, false); }
     else { if (extra) P2M_LAUNCH_WS(64, true); else P2M_LAUNCH_WS(64, false); }
 #undef P2M_LAUNCH_WS
@@ -1196,11 +1361,13 @@ static void launch_gemm_planes(GemmArgs& g, bool extra, hipStream_t s) {
 }
 
 extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
-                               int32_t a0_shift, const float* Bm, const void* Bsplit, const float* bias,
+                               int32_t a0_shift, const float* Bm, const void* Bsplit, int32_t arith,
+                               const void* a_amax, int32_t a_bits, const float* bias,
                                const float* addend, float* C0, float* C1, float* C2, int32_t nplanesC, int32_t Nc,
                                int32_t pair_out, int64_t M, float* stats, const float* act_scale,
-                               const float* act_shift, int32_t act_relu, void* stream) {
+                               const float* act_shift, int32_t act_relu, void* amax_out, void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesC >= 1 && nplanesC <= 3, "plane count must be 1..3");
+  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && (stats || pair_out)), "fused activation excludes stats and pair_out");
   P2M_CHECK_ARG(A0 && Bm && C0 && Ka > 0 && Nc > 0, "null pointer or empty shape");
@@ -1219,10 +1386,13 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.N = nplanesC * Nc; g.Nc = Nc;
   g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0;
   g.Bx = nullptr; g.Npad = 0; g.Ktot = 0;
+  g.a_amax = g.b_amax = nullptr; g.a_bits = 0;
+  g.amax_out = static_cast<unsigned*>(amax_out);
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
   if (!mfma_ok) {
     P2M_CHECK_ARG(!pair_out, "pair_out needs the MFMA path (Ka % 32 == 0, N % 32 == 0)");
+    P2M_CHECK_ARG(!amax_out, "amax_out needs the MFMA path (Ka % 32 == 0, N % 32 == 0)");
     long tot = M * g.N;
     g.ntm = g.ntn = 0;
     hipLaunchKernelGGL(k_naive_gemm_planes, dim3(cdiv(tot, 256)), dim3(256), 0, s, g);
@@ -1232,10 +1402,17 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
     }
     return check_launch("gemm_planes(naive)");
   }
-  if (Bsplit != nullptr) {
+  if (arith != P2M_ARITH_F32) {
+    P2M_CHECK_ARG(Bsplit != nullptr, "the slice arithmetics need the pre-split weight (p2m_weight_split)");
+    P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || a_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of the A planes");
     g.Bx = static_cast<const unsigned short*>(Bsplit);
     g.Npad = cdiv(g.N, 128) * 128;
     g.Ktot = nplanesA * Ka;
+    if (arith == P2M_ARITH_F16X2) {
+      g.a_amax = static_cast<const unsigned*>(a_amax);
+      g.a_bits = a_bits;
+      g.b_amax = weight_amax_word(Bsplit, arith, g.Npad, g.Ktot);
+    }
   }
   g.ntm = cdiv(M, BM);
   launch_gemm_planes<false>(g, addend != nullptr || pair_out, s);
@@ -1244,10 +1421,14 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
 
 extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A0, const float* A1,
                                     const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift,
-                                    int32_t planes_compact, const float* Bm, const void* Bsplit, const float* bias,
+                                    int32_t planes_compact, const float* Bm, const void* Bsplit, int32_t arith,
+                                    const void* a_amax, int32_t a_bits, const float* bias,
                                     const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
-                                    const float* act_shift, int32_t act_relu, void* stream) {
+                                    const float* act_shift, int32_t act_relu, void* amax_out, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
+  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
+  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || Bsplit != nullptr, "the slice arithmetics need the pre-split weight (p2m_weight_split)");
+  P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || a_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of the A planes");
   P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   P2M_CHECK_ARG(!((act_scale || act_relu) && stats), "fused activation excludes stats");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
@@ -1265,9 +1446,16 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.N = N; g.Nc = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.tps = cdiv(rs.n, BM); g.compact = planes_compact;
-  g.Bx = static_cast<const unsigned short*>(Bsplit);
+  g.Bx = arith == P2M_ARITH_F32 ? nullptr : static_cast<const unsigned short*>(Bsplit);
   g.Npad = cdiv(N, 128) * 128;
   g.Ktot = nplanesA * Ka;
+  g.a_amax = g.b_amax = nullptr; g.a_bits = 0;
+  if (arith == P2M_ARITH_F16X2) {
+    g.a_amax = static_cast<const unsigned*>(a_amax);
+    g.a_bits = a_bits;
+    g.b_amax = weight_amax_word(Bsplit, arith, g.Npad, g.Ktot);
+  }
+  g.amax_out = static_cast<unsigned*>(amax_out);
   g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
   g.ntm = B * g.tps;
   launch_gemm_planes<true>(g, addend != nullptr, (hipStream_t)stream);
@@ -1284,9 +1472,10 @@ extern "C" int32_t p2m_rows_tiles_per_sample(p2m_graph_t gh, int32_t row_set) {
 extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                            int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
                            int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith,
-                           void* stream) {
+                           const void* a_amax, int32_t a_bits, const void* g_amax, int32_t g_bits, void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesG >= 1 && nplanesG <= 3, "plane count must be 1..3");
-  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3, "unknown arithmetic");
+  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
+  P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || (a_amax && g_amax), "P2M_ARITH_F16X2 needs the amax words of both operands");
   const int N = nplanesG * Gc;
   P2M_CHECK_ARG(A0 && G0 && P && Ka > 0 && Gc > 0 && chunk_rows > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
@@ -1299,6 +1488,8 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   g.P = P; g.Pdb = Pdb; g.M = M; g.chunk_rows = chunk_rows;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = nplanesA * Ka; g.N = N;
   g.ids = nullptr; g.nset = 0; g.V = 0; g.splits = 1; g.compact = 0;
+  g.a_amax = static_cast<const unsigned*>(a_amax); g.g_amax = static_cast<const unsigned*>(g_amax);
+  g.a_bits = a_bits; g.g_bits = g_bits;
   const int nchunks = cdiv(M, chunk_rows);
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (Gc % 4 == 0) && (g.Ktot >= 32);
@@ -1310,17 +1501,19 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
     return check_launch("gemm_tn(naive)");
   }
   g.nkt = cdiv(g.Ktot, BM);
-  const bool bx = arith == P2M_ARITH_BF16X3;
+  const bool bx = arith != P2M_ARITH_F32;
   // N = 192 (three planes of 64): two 128-wide tiles (the second half empty) stage A twice, three 64-wide tiles thrice
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, false>), grid, dim3(512), 0, s, g);
+    if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<128, false, 2>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, false, 3>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, false>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, false>), grid, dim3(512), 0, s, g);
+    if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<64, false, 2>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, false, 3>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, false>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn");
@@ -1329,9 +1522,10 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
 extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A, int32_t Ka,
                                 int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
                                 int32_t Gc, int32_t planes_compact, int32_t splits, float* P, float* Pdb,
-                                int32_t arith, void* stream) {
+                                int32_t arith, const void* a_amax, const void* g_amax, int32_t g_bits, void* stream) {
   P2M_CHECK_ARG(gh && A && G0 && P, "null pointer");
-  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3, "unknown arithmetic");
+  P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
+  P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || (a_amax && g_amax), "P2M_ARITH_F16X2 needs the amax words of both operands");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
   P2M_CHECK_ARG(nplanesG >= 1 && nplanesG <= 3 && splits >= 1, "plane count must be 1..3, splits >= 1");
   P2M_CHECK_ARG(Ka % 32 == 0 && Gc % 32 == 0, "Ka and Gc must be multiples of 32");
@@ -1348,20 +1542,24 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   g.chunk_rows = cdiv(rs.n, splits);
   g.nplanesA = 1; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = Ka; g.N = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.splits = splits; g.compact = planes_compact;
+  g.a_amax = static_cast<const unsigned*>(a_amax); g.g_amax = static_cast<const unsigned*>(g_amax);
+  g.a_bits = 0; g.g_bits = g_bits;
   const int nchunks = B * splits;
   hipStream_t s = (hipStream_t)stream;
   g.nkt = cdiv(g.Ktot, BM);
-  const bool bx = arith == P2M_ARITH_BF16X3;
+  const bool bx = arith != P2M_ARITH_F32;
   if (bx) g.chunk_rows = cdiv(g.chunk_rows, 16) * 16;    // 16-byte aligned id loads; trailing splits may be empty
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, true>), grid, dim3(512), 0, s, g);
+    if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<128, true, 2>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, true, 3>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, true>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
     const dim3 grid(g.nkt * g.ntn, nchunks);
-    if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, true>), grid, dim3(512), 0, s, g);
+    if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<64, true, 2>), grid, dim3(512), 0, s, g);
+    else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, true, 3>), grid, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, true>), grid, dim3(256), 0, s, g);
   }
   return check_launch("gemm_tn_rows");

@@ -38,6 +38,7 @@ struct Graph {
   int nnz = 0;       // merged pattern
   int nnz_L = 0;     // pattern of L alone (for reporting)
   int max_row = 0;
+  int plane_bits = 0;      // ceil(log2(max row sum of |a|, |b|)) >= 0: |L x|, |L2 x| <= 2^plane_bits max |x|
   int* rowptr = nullptr;   // [V+1]
   int* col = nullptr;      // [nnz]
   float* a = nullptr;      // [nnz]  coefficients of L
@@ -97,6 +98,25 @@ static inline RowSet row_set_of(const Graph& g, int which) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// amax words (include/p2m.h, P2M_ARITH_F16X2): max |v| over a wave -> one atomic max on the word (the bits of non-negative
+// floats order as unsigned integers; NaNs are skipped by fmaxf).  Every lane of the wave must get here.
+// The word is read first (device-scope load: past the CU's vector cache, which atomics do not update) and the atomic only
+// issued by a wave that raises it: a few per launch instead of one per wave - 220 000 same-address atomics made
+// k_bn_act_fwd 6.5x slower.
+__device__ __forceinline__ void amax_commit(unsigned* word, float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+  }
+}
+__device__ __forceinline__ float amax4(float m, const float* o) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+}
+#endif
 
 #define P2M_CHECK_ARG(cond, msg)                       \
   do {                                                 \

@@ -70,21 +70,22 @@ def _narrow(L):
     return (not L.has_bn) and K_CHEB * L.Fout <= 32 and L.Fin % 32 == 0 and not L.first_in_block and L.Fout <= 4
 
 
-def _narrow_operands(W, L):
-    """[Fin, 32] operand of the project-then-combine path: columns k*Fout + fo = W[fo][fin*3 + k], zero padded."""
+def _narrow_operands(W, L, wa):
+    """[Fin, 32] operand of the project-then-combine path: columns k*Fout + fo = W[fo][fin*3 + k], zero padded.
+    wa: the parameter's amax word (f16x2; every derived operand here is a permutation of the parameter)."""
     Wp = torch.nn.functional.pad(W.detach().view(L.Fout, L.Fin, K_CHEB).permute(1, 2, 0).reshape(L.Fin, -1),
                                  (0, 32 - K_CHEB * L.Fout)).contiguous()
-    return Wp, ops.weight_split(Wp)
+    return Wp, ops.weight_split(Wp, wa)
 
 
-def _transposed_operands(Wp):
+def _transposed_operands(Wp, wa):
     Wpt = Wp.t().contiguous()
-    return Wpt, ops.weight_split(Wpt)
+    return Wpt, ops.weight_split(Wpt, wa)
 
 
-def _fc_operands(fw):
+def _fc_operands(fw, wa):
     fwt, _, _ = ops.weight_pack(fw, fw.shape[1], 1, need_w2=False)
-    return fwt, (ops.weight_split(fwt) if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
+    return fwt, (ops.weight_split(fwt, wa) if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
 
 
 def _forward_inference(net, graphs, x, params):
@@ -103,6 +104,7 @@ def _forward_inference(net, graphs, x, params):
     nblk = len(net.CL_F)
     block_in, block_in_shift, block_in_F = None, 0, 0
     dev = x.device
+    f16 = ops.f16x2()       # every contraction output is the next one's operand here: each comes back with its amax word
     for L in net._layers:
         g = graphs[L.graph]
         M = B * g.V
@@ -110,7 +112,7 @@ def _forward_inference(net, graphs, x, params):
             block_in, block_in_shift, block_in_F = cur, cur_shift, L.Fin
         W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
         if _narrow(L):
-            Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
+            Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
             oi = net._out_index_on(dev)
             if g.split:
                 Pm = torch.empty((M, 32), device=dev, dtype=torch.float32)
@@ -136,29 +138,32 @@ def _forward_inference(net, graphs, x, params):
         mfma = L.Fin % 32 == 0 and L.Fout % 32 == 0
         if g.split and mfma:
             y = torch.empty((M, L.Fout), device=dev, dtype=torch.float32)
-            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt))
+            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
             T1 = T2 = None
+            ya = ops.tag_amax(y, ops.new_amax(dev))._p2m_amax if f16 else None
             if ops.tile_gemm_ok(g, cur_shift, L.Fin, L.Fout, B=B):
-                ops.cheb_tile_gemm(g, cur_shift, cur, cur, L.Fin, Wtx, bvec, None, y, L.Fout, B, act=act)
+                ops.cheb_tile_gemm(g, cur_shift, cur, cur, L.Fin, Wtx, bvec, None, y, L.Fout, B, act=act, amax_out=ya)
             else:
                 T1, T2 = ops.cheb_basis_fwd_real(g, cur, B, L.Fin, cur_shift)
                 ops.gemm_planes_rows(g, 1, B, [cur, T1, T2], L.Fin, cur_shift, True, Wt, bvec, None, y, L.Fout, Bx=Wtx,
-                                     act=act)
+                                     act=act, amax=ops.amax_of(cur), amax_bits=g.plane_bits, amax_out=ya)
         else:
             T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
-            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) if mfma else None
-            (y,), _ = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, False, Bx=Wtx, act=act)
+            Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W)))) if mfma else None
+            (y,), _ = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, False, Bx=Wtx, act=act,
+                                      amax=ops.amax_of(cur), amax_bits=g.plane_bits, want_amax=True)
         del T1, T2
         if L.has_bn and L.last_in_block and 1 <= L.block <= nblk - 2:        # residual (meshnet.py:108-115)
-            y = ops.bn_act_fwd(y, None, False, block_in, block_in_F, block_in_shift, M, L.Fout)
+            y = ops.bn_act_fwd(y, None, False, block_in, block_in_F, block_in_shift, M, L.Fout,
+                               amax_rows=(g, B, 1) if g.split else None)
         cur, cur_shift = y, 0
         if L.last_in_block:
             if L.block == 0:                                                  # fc lift (:104-106)
-                h = cur.view(B, J * L.Fout)
+                h = ops.view_tagged(cur, B, J * L.Fout)
                 fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
-                fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw))
-                (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx)
-                cur = u.view(B * net._Vc, net.CL_F[1][0])
+                fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw))))
+                (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx, want_amax=True)
+                cur = ops.view_tagged(u, B * net._Vc, net.CL_F[1][0])
             elif L.block < nblk - 2:
                 cur_shift = 1
     return cur.view(B, graphs[0].V, net.num_mesh_output_chan)
@@ -185,6 +190,7 @@ class _MeshNetFn(torch.autograd.Function):
         graphs = net._graph_cache.on(x.device)
         training = net.training
         wc = net._weight_cache
+        ops.amax_begin_step(x.device)
         J, cin = net.num_joint, net.num_joint_input_chan
         if training:
             ops.bump_weight_epoch()       # running statistics change behind torch's back: cached eval coefficients are stale
@@ -208,7 +214,7 @@ class _MeshNetFn(torch.autograd.Function):
             W, bvec = params[P[f"cl.{L.ci}.weight"]], params[P[f"cl.{L.ci}.bias"]]
             if _narrow(L):
                 # final 64 -> 3 conv by linearity: project to 9 columns on the MFMA first, then combine sparsely
-                Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L))
+                Wp, Wpx = wc.get((L.ci, "narrow"), W, lambda: _narrow_operands(W, L, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
                 if g.classes:       # holes of `cur` hold no data: project the live rows only; the combine fills the holes
                     Pm = torch.empty((M, 32), device=cur.device, dtype=torch.float32)
                     for rs in (1, 2):
@@ -233,15 +239,17 @@ class _MeshNetFn(torch.autograd.Function):
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
                 opf = wc.get((L.ci, "split_fwd"), W,
-                             lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b))
+                             lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b,
+                                                        wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
                                                         g.fake_b, need_stats, operands=opf, want_planes=False)
                 tile_rows = ("tiles", cur_shift) if tiled else "rows"
             else:
                 T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
-                Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt)) \
+                Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W)))) \
                     if (L.Fin % 32 == 0 and L.Fout % 32 == 0) else None
-                (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats, Bx=Wtx)
+                (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats, Bx=Wtx,
+                                           amax=ops.amax_of(cur), amax_bits=g.plane_bits)
                 tile_rows = None
             co = None
             if L.has_bn:
@@ -281,13 +289,14 @@ class _MeshNetFn(torch.autograd.Function):
             cur, cur_shift = out, 0
             if L.last_in_block:
                 if L.block == 0:                                      # fc lift (:104-106)
-                    h = cur.view(B, J * L.Fout)
+                    h = ops.view_tagged(cur, B, J * L.Fout)
                     fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
-                    fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw))
-                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx)
+                    fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw))))
+                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx,
+                                              want_amax=True)
                     if keep:
                         fc_saved = h
-                    cur = u.view(B * net._Vc, net.CL_F[1][0])
+                    cur = ops.view_tagged(u, B * net._Vc, net.CL_F[1][0])
                 elif L.block < nblk - 2:                              # virtual x2 un-pool (:111)
                     cur_shift = 1
         V0 = graphs[0].V
@@ -369,7 +378,7 @@ class _MeshNetFn(torch.autograd.Function):
                 if L.block == 0:
                     # fc backward (meshnet.py:105-106): G is d(fc out) as [B*Vc, 64]
                     fw = params[P["fc.weight"]]
-                    dU = G.view(B, fw.shape[0])
+                    dU = ops.view_tagged(G, B, fw.shape[0])
                     h = ctx.fc_saved
                     Pw, Pb, nch = ops.gemm_tn([h], fw.shape[1], 0, dU, B, fw.shape[0])
                     tg = tgt("fc.weight", "fc.bias")
@@ -379,7 +388,8 @@ class _MeshNetFn(torch.autograd.Function):
                     else:
                         grads[P["fc.weight"]], grads[P["fc.bias"]] = \
                             ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
-                    fwx = wc.get("fc_bwd", fw, lambda: ops.weight_split(fw)
+                    fwx = wc.get("fc_bwd", fw,
+                                 lambda: ops.weight_split(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw)))
                                  if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
                     (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False, Bx=fwx)
                     G = dh.view(B * J, L.Fout)
@@ -406,7 +416,8 @@ class _MeshNetFn(torch.autograd.Function):
                     grads[P[f"cl.{L.ci}.weight"]] = dWn.contiguous()
                     grads[P[f"cl.{L.ci}.bias"]] = db32[:L.Fout].contiguous()
                 Wl = params[P[f"cl.{L.ci}.weight"]]
-                Wpt, Wptx = wc.get((L.ci, "narrow_bwd"), Wl, lambda: _transposed_operands(Wp))
+                Wpt, Wptx = wc.get((L.ci, "narrow_bwd"), Wl, lambda: _transposed_operands(
+                    Wp, wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 if gph.classes:
                     dX = torch.empty((M, L.Fin), device=E.device, dtype=torch.float32)
                     for rs in (1, 2):
@@ -462,11 +473,14 @@ class _MeshNetFn(torch.autograd.Function):
                 add = (Gs_block if Gs_block is not None else ops.pair_sum(G, Mc, Fblk, classes=gph)) if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
-                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
+                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
+                                                        wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0)
+                ga = ops.amax_of(gy, gph, B)       # bounds S g (x 2) and the paired planes (x 2^(plane_bits + 1))
                 with side_ctx(keep, X, P0, E1, E2):
-                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True)
-                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False)
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 3, B, X, L.Fin, 0, [P0, E1, E2], L.Fout, True, g_amax=ga,
+                                                   g_bits=gph.plane_bits + 1)
+                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 4, B, X, L.Fin, 0, [P0], L.Fout, False, g_amax=ga, g_bits=1)
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
                                                      L.Fin, *(tg or ()))
@@ -482,14 +496,16 @@ class _MeshNetFn(torch.autograd.Function):
                 add = G if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
                 opb = wc.get((L.ci, "split_bwd"), Wl,
-                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b))
+                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
+                                                        wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 E1, E2, _, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
                                                  gph.fake_b, operands=opb)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
                 with side_ctx(keep, X, gy, E1, E2):
-                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True)
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True,
+                                                   g_amax=ops.amax_of(gy, gph, B), g_bits=gph.plane_bits)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
@@ -506,11 +522,14 @@ class _MeshNetFn(torch.autograd.Function):
                 # gather (12.5 rows/row) replaces the two-source gather of p2m_cheb_basis_bwd (25 rows/row).
                 E1, E2 = ops.cheb_basis_fwd(gph, gy, B, L.Fout, 0)
                 Wl = params[P[f"cl.{L.ci}.weight"]]
-                W3x = wc.get((L.ci, "w3x"), Wl, lambda: ops.weight_split(W2))
+                W3x = wc.get((L.ci, "w3x"), Wl, lambda: ops.weight_split(
+                    W2, wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 (dX,), _ = ops.gemm_planes([gy, E1, E2], L.Fout, 0, W2, None, M, L.Fin, 1, False,
-                                           addend=G if fuse_res else None, pair_out=bool(x_shift), Bx=W3x)
+                                           addend=G if fuse_res else None, pair_out=bool(x_shift), Bx=W3x,
+                                           amax=ops.amax_of(gy), amax_bits=gph.plane_bits)
                 with side_ctx(keep, X, gy, E1, E2):
-                    Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout)
+                    Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, [gy, E1, E2], M, K_CHEB * L.Fout,
+                                              g_amax=ops.amax_of(gy), g_bits=gph.plane_bits)
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     if tg is not None:
                         ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, dW=tg[0], db=tg[1], layout=1)
@@ -522,7 +541,8 @@ class _MeshNetFn(torch.autograd.Function):
                     grads[P[f"cl.{L.ci}.weight"]], grads[P[f"cl.{L.ci}.bias"]] = dW, db
                 del Pw, Pb, E1, E2
             else:
-                Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout)
+                Pw, Pb, nch = ops.gemm_tn([X, T1, T2], L.Fin, x_shift, gy, M, L.Fout, a_amax=ops.amax_of(X),
+                                          a_bits=gph.plane_bits)
                 tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                 if tg is not None:
                     ops.weight_grad_unpack(Pw, Pb, nch, L.Fout, L.Fin, K_CHEB, dW=tg[0], db=tg[1])

@@ -161,6 +161,8 @@ class DeviceGraph:
         nt = (ctypes.c_int32 * 3)()
         check(_lib.hip().p2m_graph_plan_info(self.handle, ctypes.byref(nt)), "p2m_graph_plan_info")
         self.plan_tiles = tuple(int(v) for v in nt)
+        # binades of headroom the two-fp16-slice contractions give the Chebyshev planes of this level (include/p2m.h)
+        self.plane_bits = int(_lib.hip().p2m_graph_plane_bits(self.handle, 0))
 
         self.classes = False
         self.n_fake_all = self.n_fake
@@ -316,13 +318,75 @@ def cheb_basis_fwd_real(g, X, B, F, in_shift):
     return T1, T2
 
 
-# Arithmetic of the dense contractions: "bf16x3" (default) = the fp32 contraction on the BF16 matrix pipe (operands cut
-# exactly into 3 bf16 slices, 6 slice products, fp32 accumulate; error vs float64 <= the native kernel's, see
-# include/p2m.h and tests/test_gpu_ops.py::test_bf16x3_error_is_fp32_class); "f32" = native f32 MFMA.
-# Measured: 3860-3970 vs 3400-3440 meshes/s.
+# Arithmetic of the dense contractions (include/p2m.h P2M_ARITH_*), all of them the fp32 contraction with fp32
+# accumulation: "f16x2" = operands scaled by a power of two from their amax word and cut into 2 fp16 slices, 3 slice
+# products on the fp16 matrix pipe (22-bit operands); "bf16x3" = operands cut exactly into 3 bf16 slices, 6 slice products
+# (error vs float64 <= the native kernel's, tests/test_gpu_ops.py::test_bf16x3_error_is_fp32_class); "f32" = native f32
+# MFMA (the independent kernel set of the parity tests).
 GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "bf16x3")
-if GEMM_ARITH not in ("f32", "bf16x3"):
-    raise ValueError(f"P2M_GEMM_ARITH must be f32 or bf16x3, not {GEMM_ARITH!r}")
+if GEMM_ARITH not in ("f32", "bf16x3", "f16x2"):
+    raise ValueError(f"P2M_GEMM_ARITH must be f32, bf16x3 or f16x2, not {GEMM_ARITH!r}")
+
+
+# ---- amax words (include/p2m.h, P2M_ARITH_F16X2) ----------------------------------------------------------------
+# A uint32 in device memory bounding max |x| of one tensor.  The producer of a tensor attaches the word to the tensor
+# OBJECT (`t._p2m_amax`); a consumer that finds none computes it with one extra pass (amax_of).  Words come zeroed from
+# a per-device chunk that is renewed at the start of every forward (inside a stream capture the zeroing is then part of
+# the graph, and a forward never zeroes words a pending backward still reads).
+_amax_chunks = {}
+
+
+def f16x2():
+    return GEMM_ARITH == "f16x2"
+
+
+def amax_begin_step(device):
+    _amax_chunks.pop(torch.device(device).index, None)
+
+
+def new_amax(device):
+    key = torch.device(device).index
+    ent = _amax_chunks.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = [torch.zeros(256, dtype=torch.int32, device=device), 0]
+        _amax_chunks[key] = ent
+    w = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    return w
+
+
+def tag_amax(t, word):
+    t._p2m_amax = word
+    return t
+
+
+def view_tagged(t, *shape):
+    """t.view(*shape) that keeps t's amax word (a view is a new tensor object)."""
+    v = t.view(*shape)
+    w = getattr(t, "_p2m_amax", None)
+    if w is not None:
+        v._p2m_amax = w
+    return v
+
+
+def amax_of(t, g=None, B=None, row_set=0):
+    """The amax word of t (None unless GEMM_ARITH is f16x2): the one its producer attached, else computed now - over the
+    rows of `row_set` of level g when given (0: every row that holds data), else over the whole tensor."""
+    if not f16x2() or t is None or t.numel() % 4 != 0:      # (widths that are not MFMA shapes take the scalar kernels)
+        return None
+    w = getattr(t, "_p2m_amax", None)
+    if w is None:
+        w = new_amax(t.device)
+        if g is not None:
+            F = t.shape[-1]
+            if t.numel() != B * g.V * F:
+                raise P2MError("amax_of: the tensor is not a [B, V, F] tensor of this level (un-pooled operands must come "
+                               "tagged from their producer)")
+            check(_lib.hip().p2m_amax_rows(g.handle, row_set, _p(_req(t, "x")), B, F, _p(w), _stream()), "p2m_amax_rows")
+        else:
+            check(_lib.hip().p2m_amax(_p(_req(t, "x")), t.numel(), _p(w), _stream()), "p2m_amax")
+        t._p2m_amax = w
+    return w
 
 
 # ---- per-step cache of derived weight operands ---------------------------------------------------------------
@@ -360,31 +424,68 @@ class WeightCache:
         self._d.clear()
 
 
+def _amax_planes(planes, g=None, B=None):
+    """One word bounding SEVERAL operand planes that are not known to derive from one tagged tensor (op-level callers;
+    the network passes the source tensor's word plus headroom bits instead): planes[0] over the data rows of level g when
+    given, the others (compact planes) whole."""
+    if len(planes) == 1:
+        return amax_of(planes[0], g, B)
+    w = new_amax(planes[0].device)
+    for i, t in enumerate(planes):
+        if i == 0 and g is not None:
+            check(_lib.hip().p2m_amax_rows(g.handle, 0, _p(_req(t, "x")), B, t.shape[-1], _p(w), _stream()), "p2m_amax_rows")
+        else:
+            check(_lib.hip().p2m_amax(_p(_req(t, "x")), t.numel(), _p(w), _stream()), "p2m_amax")
+    return w
+
+
 def gemm_kernel_name():
     """Name prefix of the plane-contraction kernel the current arithmetic selects (rocprof kernel names start with it)."""
-    return "k_gemm_planes_ws" if GEMM_ARITH == "bf16x3" else "k_gemm_planes<"
+    return "k_gemm_planes<" if GEMM_ARITH == "f32" else "k_gemm_planes_ws"
 
 
 def arith_code():
     """P2M_ARITH_* value of include/p2m.h for the current GEMM_ARITH."""
-    return 1 if GEMM_ARITH == "bf16x3" else 0
+    return {"f32": 0, "bf16x3": 1, "f16x2": 2}[GEMM_ARITH]
 
 
-def weight_split(Bm):
-    """Pre-split, k-contiguous copy of a [K, N] weight operand for the bf16x3 contraction (None in f32 mode)."""
-    if GEMM_ARITH != "bf16x3":
+def weight_split(Bm, amax=None, bits=0):
+    """Pre-split, k-contiguous copy of a [K, N] weight operand for the slice contractions (None in f32 mode).
+    f16x2: amax = the amax word of the tensor Bm derives from, which bounds Bm after `bits` binades (param_amax,
+    eff_bits); default: Bm's own maximum, computed by one more small launch."""
+    if GEMM_ARITH == "f32":
         return None
     K, N = Bm.shape
     lib = _lib.hip()
-    Bx = torch.empty((int(lib.p2m_weight_split_elems(K, N)),), device=Bm.device, dtype=torch.int16)
-    check(lib.p2m_weight_split(_p(_req(Bm, "B")), K, N, _p(Bx), _stream()), "p2m_weight_split")
+    Bx = torch.empty((int(lib.p2m_weight_split_elems(K, N, arith_code())),), device=Bm.device, dtype=torch.int16)
+    check(lib.p2m_weight_split(_p(_req(Bm, "B")), K, N, arith_code(), _p(amax), int(bits), _p(Bx), _stream()),
+          "p2m_weight_split")
     return Bx
 
 
-def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None):
+def param_amax(W):
+    """f16x2: one amax word per parameter tensor - its packed / transposed / effective copies are bounded by it."""
+    if not f16x2() or W.numel() % 4 != 0:
+        return None
+    w = new_amax(W.device)
+    check(_lib.hip().p2m_amax(_p(_req(W, "weight")), W.numel(), _p(w), _stream()), "p2m_amax")
+    return w
+
+
+def eff_bits(a, b):
+    """binades by which W0 + a W1 + b W2 (weight_eff) can exceed max |W|"""
+    return int(np.ceil(np.log2(1.0 + abs(a) + abs(b)) - 1e-12))
+
+
+def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None,
+                     amax=None, amax_bits=0, amax_out=None):
     """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake, 3 / 4 the paired sets).  Returns stats
-    or None.  Bx: the pre-split copy of Bm (weight_split) when the caller has it cached."""
+    or None.  Bx: the pre-split copy of Bm (weight_split) when the caller has it cached.  f16x2: amax = the word
+    bounding the A planes after amax_bits binades (default: A[0]'s own); amax_out: a zeroed word that receives the
+    bound of what is stored."""
     n = g.set_size(row_set)
+    if f16x2() and amax is None:
+        amax = _amax_planes(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
     st = None
     weighted = stats and row_set == 2 and g.classes     # representatives count once per class member: separate pass
     if stats:
@@ -396,12 +497,13 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     with _timed("gemm_planes_mfma", (fl, fl, 4.0 * B * n * (len(A) * Ka + N))):
         check(_lib.hip().p2m_gemm_planes_rows(g.handle, row_set, B, a[0], a[1], a[2], len(A), Ka, a0_shift,
                                               int(compact), _p(_req(Bm, "B")),
-                                              _p(Bx if Bx is not None else weight_split(Bm)),
+                                              _p(Bx if Bx is not None else weight_split(Bm)), arith_code(), _p(amax),
+                                              int(amax_bits),
                                               _p(bias if bias is None else _req(bias, "bias")),
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
                                               _p(None if weighted else st), _p(None if act is None else act[0]),
                                               _p(None if act is None else act[1]), int(bool(act and act[2])),
-                                              _stream()), "p2m_gemm_planes_rows")
+                                              _p(amax_out), _stream()), "p2m_gemm_planes_rows")
     if weighted and n > 0:
         check(_lib.hip().p2m_stats_rows_w(g.handle, _p(C), B, N, _p(st), _stream()), "p2m_stats_rows_w")
     return st
@@ -425,11 +527,11 @@ def side_stream(device, which=0):
     return st
 
 
-def split_operands(Bm, Ka, N, fake_a, fake_b):
+def split_operands(Bm, Ka, N, fake_a, fake_b, amax=None):
     """Derived operands of one split contraction: (Bx, We, Wex) = pre-split Bm, the fake-vertex effective weight
-    W0 + a*W1 + b*W2 and its pre-split copy."""
+    W0 + a*W1 + b*W2 and its pre-split copy.  amax: the amax word of the parameter Bm is a permutation of (f16x2)."""
     We = weight_eff(Bm, Ka, N, fake_a, fake_b)
-    return weight_split(Bm), We, weight_split(We)
+    return weight_split(Bm, amax), We, weight_split(We, amax, eff_bits(fake_a, fake_b) if amax is not None else 0)
 
 
 def cheb_basis_pair(g, G, B, F):
@@ -444,7 +546,7 @@ def cheb_basis_pair(g, G, B, F):
 
 def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
     """True when the real rows of this conv take the basis-inside-the-contraction kernel (see TILE_GEMM)."""
-    if TILE_GEMM in ("0", False) or GEMM_ARITH != "bf16x3":
+    if TILE_GEMM in ("0", False) or GEMM_ARITH == "f32":
         return False
     if not _lib.hip().p2m_cheb_tile_gemm_supported(g.handle, plan, Ka, N):
         return False
@@ -453,10 +555,14 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
     return plan != 2 and not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
 
 
-def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None):
+def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None,
+                   amax=None, amax_out=None):
     """C[rows of the plan] = [A0 | L X | L2 X] W (+bias)(+addend) in one kernel (include/p2m.h).  Returns
-    (stats [B*ntiles, 2, N] or None, (E1, E2) compact planes or None)."""
+    (stats [B*ntiles, 2, N] or None, (E1, E2) compact planes or None).  f16x2: amax = the word bounding X and A0 (default:
+    X's own); amax_out: a zeroed word that receives the bound of what is stored."""
     nset = g.n_pair_real if plan == 2 else g.n_real
+    if f16x2() and amax is None:
+        amax = amax_of(X, g if plan != 1 else None, B)
     st = torch.empty((B * g.plan_tiles[plan], 2, N), device=C.device, dtype=torch.float32) if stats else None
     E1 = torch.empty((B * nset, Ka), device=C.device, dtype=torch.float32) if want_planes else None
     E2 = torch.empty((B * nset, Ka), device=C.device, dtype=torch.float32) if want_planes else None
@@ -465,11 +571,12 @@ def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, w
     nbytes = 4.0 * B * nset * (Ka + N + (2 * Ka if want_planes else 0) + (N if addend is not None else 0))
     with _timed("cheb_tile_gemm", (fl, fl, nbytes)):
         check(_lib.hip().p2m_cheb_tile_gemm(g.handle, plan, _p(_req(X, "X")), _p(_req(A0, "A0")), Ka, _p(Bx),
+                                            arith_code(), _p(amax),
                                             _p(bias if bias is None else _req(bias, "bias")),
                                             _p(addend if addend is None else _req(addend, "addend")), _p(C), N, _p(st),
                                             _p(E1), _p(E2), _p(None if act is None else act[0]),
-                                            _p(None if act is None else act[1]), int(bool(act and act[2])), B,
-                                            _stream()), "p2m_cheb_tile_gemm")
+                                            _p(None if act is None else act[1]), int(bool(act and act[2])),
+                                            _p(amax_out), B, _stream()), "p2m_cheb_tile_gemm")
     return st, ((E1, E2) if want_planes else None)
 
 
@@ -483,24 +590,29 @@ def bn_finalize_tiles(g, plan, B, st_real, st_fake, gamma, beta, running_mean, r
     return co
 
 
-def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None):
+def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, amax_out=None):
     """Backward contraction of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"):
     C[B*V/2, N] = [S g | S L g | S L2 g] Bm (+ addend).  Returns the planes (P0 full, P1c, P2c).
     P0: S g when the caller already has it (by-product of the BatchNorm backward)."""
     if P0 is None:
         P0 = pair_sum(Gy, B * (g.V // 2), Ka, classes=g)
     Bx, We, Wex = operands
+    ga = amax_of(Gy, g, B)            # |S g| <= 2 max |g|, |S L g|, |S L2 g| <= 2^(plane_bits + 1) max |g|
     if tile_gemm_ok(g, 2, Ka, N, want_planes=True, B=B):
         # planes S L g, S L2 g formed inside the contraction; written out (compact) only for the weight gradient
-        _, (P1c, P2c) = cheb_tile_gemm(g, 2, Gy, P0, Ka, Bx, None, addend, C, N, B, want_planes=True)
+        _, (P1c, P2c) = cheb_tile_gemm(g, 2, Gy, P0, Ka, Bx, None, addend, C, N, B, want_planes=True, amax=ga,
+                                       amax_out=amax_out)
     else:
         P1c, P2c = cheb_basis_pair(g, Gy, B, Ka)
-        gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx)
-    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex)
+        gemm_planes_rows(g, 3, B, [P0, P1c, P2c], Ka, 0, True, Bm, None, addend, C, N, False, Bx=Bx, amax=ga,
+                         amax_bits=g.plane_bits + 1, amax_out=amax_out)
+    gemm_planes_rows(g, 4, B, [P0], Ka, 0, False, We, None, addend, C, N, False, Bx=Wex, amax=ga, amax_bits=1,
+                     amax_out=amax_out)
     return P0, P1c, P2c
 
 
-def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, want_planes=True):
+def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, want_planes=True,
+               amax_out=None):
     """One split contraction: the real-vertex rows [X | L X | L2 X] Bm (K = 3*Ka), then the fake-vertex GEMM (K = Ka,
     W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's basis on a side
     stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
@@ -508,15 +620,19 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
     (p2m_bn_finalize_split)."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
+    xa = amax_of(X, g if a0_shift == 0 else None, B)
     if tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
-                                     want_planes=want_planes)
-        st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
+                                     want_planes=want_planes, amax=xa, amax_out=amax_out)
+        st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
+                               amax_out=amax_out)
         T1c, T2c = planes if planes is not None else (None, None)
         return T1c, T2c, st1, st2, True
     T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, a0_shift)
-    st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx)
-    st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex)
+    st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, a0_shift, True, Bm, bias, addend, C, N, stats, Bx=Bx, amax=xa,
+                           amax_bits=g.plane_bits, amax_out=amax_out)
+    st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
+                           amax_out=amax_out)
     return T1c, T2c, st1, st2, False
 
 
@@ -525,9 +641,15 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 TN_TARGET_BLOCKS = 768
 
 
-def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
-    """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks)."""
+def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_amax=None, g_bits=0):
+    """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks).  f16x2: the amax
+    words of A and of the G planes (after g_bits binades); default: the tensors' own."""
     n = g.set_size(row_set)
+    if f16x2():
+        if a_amax is None:
+            a_amax = amax_of(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
+        if g_amax is None:
+            g_amax = _amax_planes(G, g if row_set <= 2 else None, B)
     N = len(G) * Gc
     ntiles = ((Ka + 127) // 128) * ((N + 127) // 128)
     splits = max(1, -(-TN_TARGET_BLOCKS // (B * ntiles)))
@@ -538,7 +660,7 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact):
     with _timed("gemm_tn_mfma", 2.0 * B * n * Ka * N):
         check(_lib.hip().p2m_gemm_tn_rows(g.handle, row_set, B, _p(_req(A, "A")), Ka, a0_shift, gp[0], gp[1], gp[2],
                                           len(G), Gc, int(compact), splits, _p(P), _p(Pdb), arith_code(),
-                                          _stream()),
+                                          _p(a_amax), _p(g_amax), int(g_bits), _stream()),
               "p2m_gemm_tn_rows")
     return P, Pdb, nch
 
@@ -582,11 +704,13 @@ def weight_pack(W, Fin, K, need_w2=True, need_w3=False):
 
 
 def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend=None, pair_out=False, Bx=None,
-                act=None):
+                act=None, amax=None, amax_bits=0, want_amax=False):
     """A: list of 1..3 plane tensors.  Returns (list of C planes, stats or None).
     addend: [M, N] added in the epilogue; pair_out: the (single) output has M/2 rows = sums of row pairs.
     Bx: cached weight_split(Bm), if the caller has one.  act = (scale[N], shift[N], relu): fused eval-mode
-    BatchNorm + ReLU in the epilogue (bitwise the separate bn_act_fwd pass)."""
+    BatchNorm + ReLU in the epilogue (bitwise the separate bn_act_fwd pass).  f16x2: amax = the word bounding the A
+    planes after amax_bits binades (default: A[0]'s own, over the whole tensor); want_amax: the (single) output comes
+    back tagged with its bound."""
     dev = A[0].device
     Nc = N // nplanesC
     C = [torch.empty((M >> 1 if pair_out else M, Nc), device=dev, dtype=torch.float32) for _ in range(nplanesC)]
@@ -601,16 +725,24 @@ def gemm_planes(A, Ka, a0_shift, Bm, bias, M, N, nplanesC=1, stats=False, addend
         Bx = None
     elif Bx is None:
         Bx = weight_split(Bm)
+    amax_out = None
+    if mfma and f16x2():
+        if amax is None:
+            amax = _amax_planes(A)
+        if want_amax and nplanesC == 1:
+            amax_out = new_amax(dev)
+            tag_amax(C[0], amax_out)
     fl = 2.0 * M * len(A) * Ka * N                                                                  # algorithmic FLOPs
     nbytes = 4.0 * M * ((len(A) - 1 + 1.0 / (1 << a0_shift)) * Ka + (0.5 if pair_out else 1.0) * N
                         + (N if addend is not None else 0))
     with _timed("gemm_planes_mfma" if mfma else "gemm_planes_valu", (fl, fl, nbytes)):
         check(_lib.hip().p2m_gemm_planes(a[0], a[1], a[2], len(A), Ka, a0_shift, _p(_req(Bm, "B")), _p(Bx),
+                                         arith_code() if mfma else 0, _p(amax), int(amax_bits),
                                          _p(bias if bias is None else _req(bias, "bias")),
                                          _p(addend if addend is None else _req(addend, "addend")), c[0], c[1], c[2],
                                          nplanesC, Nc, int(pair_out), M, _p(st),
                                          _p(None if act is None else act[0]), _p(None if act is None else act[1]),
-                                         int(bool(act and act[2])), _stream()), "p2m_gemm_planes")
+                                         int(bool(act and act[2])), _p(amax_out), _stream()), "p2m_gemm_planes")
     return C, st
 
 
@@ -624,9 +756,10 @@ def pick_chunk_rows(M, ntiles_out, target_blocks=None, quantum=32):
     return rows
 
 
-def gemm_tn(A, Ka, a0_shift, G, M, N):
+def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits=0):
     """G: one [M, N] tensor or a list of column planes [M, N/len(G)].
-    Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks)."""
+    Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks).  f16x2: the amax words of the A / G planes (after
+    a_bits / g_bits binades); default: the first planes' own, over the whole tensors."""
     Gl = list(G) if isinstance(G, (list, tuple)) else [G]
     G = Gl[0]
     Gc = N // len(Gl)
@@ -639,9 +772,15 @@ def gemm_tn(A, Ka, a0_shift, G, M, N):
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
     mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32 and Gc % 4 == 0
     gp = [_p(_req(t, "G plane")) for t in Gl] + [None] * (3 - len(Gl))
+    if mfma and f16x2():
+        if a_amax is None:
+            a_amax = _amax_planes(A)
+        if g_amax is None:
+            g_amax = _amax_planes(Gl)
     with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", 2.0 * M * Ktot * N):
         check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, gp[0], gp[1], gp[2], len(Gl), Gc, M,
-                                     chunk_rows, _p(P), _p(Pdb), arith_code(), _stream()), "p2m_gemm_tn")
+                                     chunk_rows, _p(P), _p(Pdb), arith_code() if mfma else 0, _p(a_amax), int(a_bits),
+                                     _p(g_amax), int(g_bits), _stream()), "p2m_gemm_tn")
     return P, Pdb, nchunks
 
 
@@ -680,15 +819,23 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None):
-    """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped)."""
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, amax_rows=None):
+    """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped).  f16x2: the output comes
+    back tagged with its amax word - over the live rows (classes), over amax_rows = (DeviceGraph, B, row_set) when only
+    those rows of y hold data (inference on the real rows), else over all rows."""
     x = torch.empty((M, F), device=y.device, dtype=torch.float32)
     sc = None if co is None else co[2]
     sh = None if co is None else co[3]
     cls = classes.handle if (classes is not None and classes.classes) else None
+    # the pass itself bounds what it writes, unless it also walks rows that hold no data (amax_rows)
+    word = new_amax(y.device) if (f16x2() and F % 4 == 0 and amax_rows is None) else None
     check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
                                     _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),
-                                    _p(x), M, F, cls, _stream()), "p2m_bn_act_fwd")
+                                    _p(x), M, F, cls, _p(word), _stream()), "p2m_bn_act_fwd")
+    if word is not None:
+        tag_amax(x, word)
+    elif f16x2() and F % 4 == 0:
+        amax_of(x, amax_rows[0], amax_rows[1], amax_rows[2])
     return x
 
 
@@ -714,11 +861,14 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None,
           "p2m_bn_bwd_finalize")
     alloc = torch.zeros if (zero_holes and cls is not None) else torch.empty
     gy = alloc((M, F), device=y.device, dtype=torch.float32)
+    word = new_amax(y.device) if f16x2() else None
     pgx = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
     pgy = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
                                _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, cls,
-                               _stream()), "p2m_bn_bwd_apply")
+                               _p(word), _stream()), "p2m_bn_bwd_apply")
+    if word is not None:
+        tag_amax(gy, word)
     if pair_in or pair_out:
         return gy, dgamma, dbeta, pgx, pgy
     return gy, dgamma, dbeta

@@ -49,9 +49,9 @@ def ops(hip_libs):
     return o
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f16x2"])
 def arith(request, ops, monkeypatch):
-    """Both arithmetics of the dense contraction: native f32 MFMA and the 3-slice bf16 split on the BF16 pipe."""
+    """The arithmetics of the dense contraction: native f32 MFMA, 3 bf16 slices, 2 scaled fp16 slices (include/p2m.h)."""
     monkeypatch.setattr(ops, "GEMM_ARITH", request.param)
     return request.param
 
@@ -320,6 +320,80 @@ def test_bf16x3_error_is_fp32_class(ops, monkeypatch, M, Ka, N):
     assert errs["bf16x3"] <= 4.0 * errs["f32"] + 2.4e-7, errs              # 2.4e-7 = 2 fp32 ulps of the scale
 
 
+@pytest.mark.parametrize("M,Ka,N", [(2048, 256, 256), (1000, 128, 64)])
+def test_f16x2_error_is_fp32_class(ops, monkeypatch, M, Ka, N):
+    """Two scaled fp16 slices, three slice products: against float64 the error stays within 4x of the native f32 MFMA's
+    (+ 2^-20 of sum |a||b|: 22-bit operands and the dropped low x low product) on inputs with a wide dynamic range, for
+    the plane contraction and for the weight-gradient contraction; a plain fp16 product would be ~1e3 times worse."""
+    gen = torch.Generator().manual_seed(M)
+    A = [(torch.randn(M, Ka, generator=gen) * torch.exp(2 * torch.randn(M, Ka, generator=gen))).cuda()
+         for _ in range(3)]
+    Bm = (torch.randn(3 * Ka, N, generator=gen) * torch.exp(2 * torch.randn(3 * Ka, N, generator=gen))).cuda()
+    G = (torch.randn(M, N, generator=gen) * torch.exp(2 * torch.randn(M, N, generator=gen))).cuda()
+    Z = torch.cat(A, 1).double()
+    ref, scale = Z @ Bm.double(), Z.abs() @ Bm.abs().double()
+    ref_t, scale_t = Z.t() @ G.double(), Z.abs().t() @ G.abs().double()
+    errs, errs_t = {}, {}
+    for mode in ("f32", "f16x2"):
+        monkeypatch.setattr(ops, "GEMM_ARITH", mode)
+        (C,), _ = ops.gemm_planes(A, Ka, 0, Bm, None, M, N, 1, False)
+        errs[mode] = ((C.double() - ref).abs() / scale).max().item()
+        P, _, nch = ops.gemm_tn(A, Ka, 0, G, M, N)
+        errs_t[mode] = ((P.double().sum(0) - ref_t).abs() / scale_t).max().item()
+    print("max |err| / sum|a||b|:", errs, "weight gradient:", errs_t)
+    for e in (errs, errs_t):
+        assert e["f32"] < 5e-6 and e["f16x2"] < 5e-6, e
+        assert e["f16x2"] <= 4.0 * e["f32"] + 2.0 ** -20, e
+
+
+@pytest.mark.parametrize("magnitude", [1e-30, 1e-7, 1.0, 1e30])
+def test_f16x2_is_scale_free_and_zero_safe(ops, monkeypatch, magnitude):
+    """The power-of-two scaling makes the result independent of the operands' magnitudes (fp16 alone spans 2^-24..2^16):
+    gradients of 1e-7, activations of 1e30 - the same relative error; an all-zero operand gives exact zeros; the amax
+    word a contraction hands on (want_amax) is the maximum of what it stored."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
+    M, Ka, N = 640, 64, 128
+    gen = torch.Generator().manual_seed(11)
+    A = torch.randn(M, Ka, generator=gen).cuda()
+    Bm = (torch.randn(Ka, N, generator=gen) / 8).cuda()
+    ref = A.double() @ Bm.double()
+    (C,), _ = ops.gemm_planes([A * magnitude], Ka, 0, Bm, None, M, N, 1, False, want_amax=True)
+    assert ((C.double() / magnitude - ref).abs().max() < 2e-6 * ref.abs().max()).item()
+    word = C._p2m_amax.view(torch.float32).item()
+    assert word == C.abs().max().item()
+    (Cw,), _ = ops.gemm_planes([A], Ka, 0, Bm * magnitude, None, M, N, 1, False)
+    assert ((Cw.double() / magnitude - ref).abs().max() < 2e-6 * ref.abs().max()).item()
+    (Z,), _ = ops.gemm_planes([torch.zeros_like(A)], Ka, 0, Bm, None, M, N, 1, False)
+    assert (Z == 0).all()
+    # one huge outlier: everything within 2^-18 of it keeps 22 bits, the rest an ABSOLUTE error of 2^-40 of the outlier
+    A2 = A.clone()
+    A2[3, 5] = 3.0e4
+    (C2,), _ = ops.gemm_planes([A2], Ka, 0, Bm, None, M, N, 1, False)
+    ref2 = A2.double() @ Bm.double()
+    assert ((C2.double() - ref2).abs().max() < 2e-6 * ref2.abs().max()).item()
+    rows = torch.arange(M, device="cuda") != 3
+    assert ((C2.double() - ref2)[rows].abs().max() < 4e-6 * ref[rows.cpu()].abs().max()).item()
+
+
+def test_f16x2_weight_image(ops, monkeypatch):
+    """p2m_weight_split, P2M_ARITH_F16X2: [K/16][2][Npad][16] fp16 slices of Bm 2^sb followed by the weight's amax word;
+    slice 0 + slice 1 reproduces Bm 2^sb to 2^-22 of each value that is within 2^-18 of the maximum."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
+    K, N = 96, 160
+    gen = torch.Generator().manual_seed(5)
+    Bm = (torch.randn(K, N, generator=gen) / 7).cuda()
+    Bx = ops.weight_split(Bm)
+    Npad = 256
+    assert Bx.numel() == 2 * Npad * K + 8
+    amax = Bx[2 * Npad * K:2 * Npad * K + 2].view(torch.float32).item()
+    assert amax == Bm.abs().max().item()
+    sb = 14 - int(np.floor(np.log2(amax)))                    # amax 2^sb in [2^14, 2^15)
+    sl = Bx[:2 * Npad * K].view(torch.float16).view(K // 16, 2, Npad, 16).permute(1, 2, 0, 3).reshape(2, Npad, K)
+    assert (sl[:, N:, :] == 0).all()
+    rec = (sl[0, :N].double() + sl[1, :N].double()).t() * 2.0 ** -sb
+    assert ((rec - Bm.double()).abs() <= 2.0 ** -22 * Bm.double().abs() + 2.0 ** -40 * amax).all()
+
+
 @pytest.mark.parametrize("V,Fdim,shift,B", [(736, 128, 0, 5), (736, 128, 1, 3), (1472, 64, 1, 9), (2944, 32, 0, 4),
                                             (736, 256, 0, 2), (1472, 256, 1, 6)])
 def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
@@ -526,13 +600,14 @@ def test_row_kernel_basis_variant_in_a_subprocess(hip_libs):
 @pytest.mark.parametrize("V,Fin,Fout,shift,B", [(736, 128, 128, 0, 5), (736, 128, 128, 1, 3), (1472, 256, 128, 0, 4),
                                                 (1472, 128, 256, 1, 9), (2944, 128, 64, 0, 2), (736, 64, 128, 0, 7),
                                                 (736, 256, 256, 1, 6)])
-def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkeypatch, V, Fin, Fout, shift, B):
+@pytest.mark.parametrize("slices", ["bf16x3", "f16x2"])
+def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkeypatch, slices, V, Fin, Fout, shift, B):
     """p2m_cheb_tile_gemm (the Chebyshev planes formed per tile in LDS and contracted without touching HBM) against the
     two-kernel form it replaces, p2m_cheb_basis_fwd_real + p2m_gemm_planes_rows: same real rows of C (fp32 round-off:
     the k order of the accumulation differs), untouched fake rows, the optional planes BITWISE those of the basis kernel
     (same entry order, same fmaf chain), BatchNorm statistics through their own finalize, addend, fused activation.
     B is deliberately not a multiple of the 4 samples a block tile holds."""
-    monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
+    monkeypatch.setattr(ops, "GEMM_ARITH", slices)
     monkeypatch.setattr(ops, "TILE_GEMM", True)          # opt-in path (P2M_TILE_GEMM=1)
     L = _band_graph(V, 7 + V + shift)
     g = ops.DeviceGraph(L, "cuda:0")

@@ -161,6 +161,16 @@ def test_basis_inside_the_contraction_network_vs_oracle_train(hip_libs, tmp_path
     _kink_resolved_check_child("a_tile_gemm_human36_B3", tmp_path, {"P2M_TILE_GEMM": "1"}, "human36", 3, 21, 99, 5)
 
 
+@pytest.mark.parametrize("env,tag", [({"P2M_GEMM_ARITH": "f16x2"}, "a_f16x2_human36_B3"),
+                                     ({"P2M_GEMM_ARITH": "f16x2", "P2M_TILE_GEMM": "1"}, "a_f16x2_tile_human36_B3"),
+                                     ({"P2M_GEMM_ARITH": "bf16x3"}, "a_bf16x3_human36_B3")])
+def test_slice_arithmetics_network_vs_oracle_train(hip_libs, tmp_path, env, tag):
+    """The whole network in each slice arithmetic of the contractions (include/p2m.h P2M_ARITH_*: two scaled fp16 slices with
+    the amax words travelling with the tensors, three exact bf16 slices), with and without the basis inside the
+    contraction, against the float64 oracle: vertices, and every gradient with the ReLU kinks resolved."""
+    _kink_resolved_check_child(tag, tmp_path, env, "human36", 3, 21, 99, 5)
+
+
 @pytest.mark.parametrize("joint_set,B", [("mano", 5), ("human36", 3), ("coco", 2)])
 def test_full_gradients_vs_oracle_train(hip_libs, joint_set, B):
     """(a) every parameter gradient and the input gradient, FULL tensors, train mode, fresh inputs, against float64

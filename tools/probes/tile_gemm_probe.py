@@ -39,7 +39,7 @@ def bench(fn, n=6):
 
 
 graphs = {}
-tot = [0.0, 0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0, 0.0]
 for lvl, Ka, N, plan in CASES:
     g = graphs.setdefault(lvl, ops.DeviceGraph(gL[lvl], "cuda:0"))
     if not g.split or not ops.tile_gemm_ok(g, plan, Ka, N):
@@ -56,14 +56,30 @@ for lvl, Ka, N, plan in CASES:
     if plan == 2:
         def two():
             P1, P2 = ops.cheb_basis_pair(g, X, B, Ka)
-            ops.gemm_planes_rows(g, 3, B, [A0, P1, P2], Ka, 0, True, W, None, None, C, N, False, Bx=Bx)
+            ops.gemm_planes_rows(g, 3, B, [A0, P1, P2], Ka, 0, True, W, None, None, C, N, False, Bx=Bx,
+                                 amax=ops.amax_of(X), amax_bits=g.plane_bits + 1)
     else:
         def two():
             T1, T2 = ops.cheb_basis_fwd_real(g, X, B, Ka, shift)
-            ops.gemm_planes_rows(g, 1, B, [X, T1, T2], Ka, shift, True, W, None, None, C, N, True, Bx=Bx)
+            ops.gemm_planes_rows(g, 1, B, [X, T1, T2], Ka, shift, True, W, None, None, C, N, True, Bx=Bx,
+                                 amax=ops.amax_of(X), amax_bits=g.plane_bits)
     ms2 = 0.0 if ONLY_TILE else bench(two)
-    ms_f = bench(lambda: ops.cheb_tile_gemm(g, plan, X, A0, Ka, Bx, None, None, C, N, B, stats=(plan != 2)))
-    ms_b = bench(lambda: ops.cheb_tile_gemm(g, plan, X, A0, Ka, Bx, None, None, C, N, B, want_planes=True))
+    if plan != 2 and not ONLY_TILE:       # the contraction alone (planes already in HBM) and the weight gradient of the same conv
+        T1, T2 = ops.cheb_basis_fwd_real(g, X, B, Ka, shift)
+        ms_g = bench(lambda: ops.gemm_planes_rows(g, 1, B, [X, T1, T2], Ka, shift, True, W, None, None, C, N, True, Bx=Bx,
+                                                  amax=ops.amax_of(X), amax_bits=g.plane_bits))
+        Gy = torch.randn(B * g.V, N, device="cuda")
+        E1, E2 = ops.cheb_basis_fwd_real(g, Gy, B, N, 0)
+        ms_t = bench(lambda: ops.gemm_tn_rows(g, 1, B, X, Ka, shift, [Gy, E1, E2], N, True, a_amax=ops.amax_of(X),
+                                              g_amax=ops.amax_of(Gy), g_bits=g.plane_bits))
+        tot[3] += ms_g
+        tot[4] += ms_t
+        print(f"   contraction alone {ms_g:7.3f} ms ({2.0 * B * nset * 3 * Ka * N / ms_g / 1e9:6.1f} TF) | weight gradient "
+              f"{ms_t:7.3f} ms ({2.0 * B * nset * 3 * Ka * N / ms_t / 1e9:6.1f} TF)", flush=True)
+        del T1, T2, Gy, E1, E2
+    xa = ops.amax_of(X)          # (f16x2) the operand's amax word, computed once outside the timed calls
+    ms_f = bench(lambda: ops.cheb_tile_gemm(g, plan, X, A0, Ka, Bx, None, None, C, N, B, stats=(plan != 2), amax=xa))
+    ms_b = bench(lambda: ops.cheb_tile_gemm(g, plan, X, A0, Ka, Bx, None, None, C, N, B, want_planes=True, amax=xa))
     fl = 2.0 * B * nset * 3 * Ka * N
     tot[0] += ms2
     tot[1] += ms_f
@@ -71,4 +87,5 @@ for lvl, Ka, N, plan in CASES:
     print(f"V={g.V:6d} rows={nset:5d} Ka={Ka:3d} N={N:3d} plan={plan}: basis+gemm {ms2:7.3f} ms | tile_gemm {ms_f:7.3f} ms "
           f"({fl / ms_f / 1e9:6.1f} TF) | with planes out {ms_b:7.3f} ms ({fl / ms_b / 1e9:6.1f} TF)", flush=True)
     del X, C, A0
-print(f"TOTAL basis+gemm {tot[0]:.3f} ms | tile_gemm {tot[1]:.3f} ms | with planes {tot[2]:.3f} ms")
+print(f"TOTAL basis+gemm {tot[0]:.3f} ms | tile_gemm {tot[1]:.3f} ms | with planes {tot[2]:.3f} ms | contraction alone "
+      f"{tot[3]:.3f} ms | weight gradient {tot[4]:.3f} ms   [P2M_GEMM_ARITH={ops.GEMM_ARITH}]")
