@@ -165,7 +165,7 @@ int64_t p2m_weight_split_elems(int32_t K, int32_t N, int32_t arith);
 int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t arith, const void* amax_in, int32_t amax_bits,
                      void* Bx, void* stream);
 /* amax words: atomic max of |x| into *word (uint32, device; the caller zeroes it before the first contribution).
- * p2m_amax: n contiguous floats (n % 4 == 0, 16-byte aligned).  p2m_amax_rows: rows of a [B, V, F] tensor of a level -
+ * p2m_amax: n contiguous floats.  p2m_amax_rows: rows of a [B, V, F] tensor of a level -
  * row_set 0 = every row that holds data (all rows; the live rows once classes are declared), 1..4 = that row set.   */
 int p2m_amax(const float* x, int64_t n, void* word, void* stream);
 int p2m_amax_rows(p2m_graph_t g, int32_t row_set, const float* x, int32_t B, int32_t F, void* word, void* stream);
@@ -305,8 +305,10 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * Bx = p2m_weight_split of the [3 Ka, N] operand (rows k * Ka + fin).  N in {64, 128, 256}, Ka % 32 == 0
  * (p2m_cheb_tile_gemm_supported).  Rows of C outside the row set are not touched (fake vertices: p2m_gemm_planes_rows,
  * row set 2 / 4, with p2m_weight_eff).  Optional: stats[B * ntiles(plan)][2][N] BatchNorm partials per (sample, tile)
- * for p2m_bn_finalize_tiles; E1 / E2 [B * nset, Ka]: the two gathered planes, compact (bitwise those of
- * p2m_cheb_basis_fwd_real / p2m_cheb_basis_pair), for the weight gradient p2m_gemm_tn_rows; act_*: fused eval-mode
+ * for p2m_bn_finalize_tiles; E1 / E2 [B * nset, Ka]: the two gathered planes, compact, for the weight gradient
+ * p2m_gemm_tn_rows - bitwise those of p2m_cheb_basis_fwd_real / p2m_cheb_basis_pair where the kernel gathers with the
+ * same fmaf chain (P2M_ARITH_BF16X3; N = 256), equal to fp32 round-off where the gather itself runs on the matrix cores
+ * (P2M_ARITH_F16X2 with N <= 128: the tile's operator as a dense fp16-sliced block, baked with the plan); act_*: fused eval-mode
  * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  arith: P2M_ARITH_BF16X3 or P2M_ARITH_F16X2 (Bx split with
  * the same arith; x_amax = amax word bounding X and A0, the kernel adds the level's p2m_graph_plane_bits for the planes
  * it forms).  amax_out as in p2m_gemm_planes.                                                                          */

@@ -56,9 +56,21 @@ struct FlatRows {
 // Greedy tiles of consecutive rows (<= TILE_RMAX rows, <= TILE_UCAP distinct source rows, <= TILE_ECAP entries) for
 // k_basis_tile.  A row that does not fit a tile on its own leaves the plan empty (ntiles == 0: the row kernel stays in
 // charge).  Entry order = the order of `fr` (the merged-CSR order): the tile kernel's fmaf chain is the row kernel's.
-static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
+static inline unsigned short f16_bits(float v) {
+  const _Float16 h = (_Float16)v;                    // round to nearest even
+  unsigned short b;
+  memcpy(&b, &h, sizeof(b));
+  return b;
+}
+
+// entry_bits: binades that bound the entries' magnitudes (|a|, |b| <= 2^entry_bits): the dense blocks are stored times
+// 2^(14 - entry_bits)
+static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl, int entry_bits) {
   std::vector<int> tile_row{0}, tile_u{0}, ucol, erow{0};
   std::vector<float4> ent;
+  std::vector<unsigned short> ltx;
+  std::vector<double> dense((size_t)64 * TILE_UPAD);
+  const int lt_exp = 14 - entry_bits;
   std::vector<int> local(nsrc, -1), uni;
   const int n = fr.n();
   int i = 0;
@@ -84,6 +96,9 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
     if ((int)uni.size() > TILE_UCAP || entries > TILE_ECAP) return P2M_OK;   // a single row too large: no plan
     std::sort(uni.begin(), uni.end());
     for (size_t q = 0; q < uni.size(); q++) local[uni[q]] = (int)q;
+    const size_t lt0 = ltx.size();
+    ltx.resize(lt0 + TILE_LTX_ELEMS, 0);
+    std::fill(dense.begin(), dense.end(), 0.0);
     for (int r = i; r < i + rows; r++) {
       for (int j = fr.rp[r]; j < fr.rp[r + 1]; j++) {
         float4 e4;
@@ -91,9 +106,20 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
         const int lc = local[fr.src[j]];
         memcpy(&e4.z, &lc, sizeof(int));
         ent.push_back(e4);
+        // dense block: entries of one row that share a source column (the two children of an un-pooled input row) add up
+        dense[(size_t)(r - i) * TILE_UPAD + lc] += (double)fr.a[j];
+        dense[(size_t)(32 + r - i) * TILE_UPAD + lc] += (double)fr.b[j];
       }
       erow.push_back((int)ent.size());
     }
+    for (int pi = 0; pi < 64; pi++)
+      for (int u = 0; u < (int)uni.size(); u++) {
+        const float y = (float)std::ldexp(dense[(size_t)pi * TILE_UPAD + u], lt_exp);
+        const _Float16 h = (_Float16)y;
+        const size_t at = lt0 + (((size_t)(u >> 4) * 2 * 2 + (size_t)((u >> 3) & 1)) * 64 + (size_t)pi) * 8 + (u & 7);
+        ltx[at] = f16_bits((float)h);
+        ltx[at + 2 * 64 * 8] = f16_bits(y - (float)h);
+      }
     for (int c : uni) { ucol.push_back(c); local[c] = -1; }
     i += rows;
     tile_row.push_back(i);
@@ -108,8 +134,10 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl) {
       (rc = upload(tile_u.data(), sizeof(int) * tile_u.size(), (void**)&pl.tile_u)) != P2M_OK ||
       (rc = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
       (rc = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
-      (rc = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK)
+      (rc = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK ||
+      (rc = upload(ltx.data(), sizeof(unsigned short) * ltx.size(), (void**)&pl.ltx)) != P2M_OK)
     return rc;
+  pl.lt_exp = lt_exp;
   pl.ntiles = (int)tile_row.size() - 1;
   return P2M_OK;
 }
@@ -203,7 +231,7 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
         for (int j = rp[v]; j < rp[v + 1]; j++) fr.push(mc[j] >> sh, ma[j], mb[j]);
         fr.end_row();
       }
-      rc2 = build_tile_plan(fr, V >> sh, g->plan[sh]);
+      rc2 = build_tile_plan(fr, V >> sh, g->plan[sh], plane_bits);
     }
     // PAIRED operator (plan[2]): row c = (merged row 2c) + (merged row 2c+1), over the coarse vertices with at least one
     // real child.  S L g and S L2 g (S = the x2 un-pool's transpose, the pair-sum) in ONE pass over g: the backward
@@ -227,7 +255,7 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
         fr.end_row();
       }
       if (preal.size() >= 128) {
-        rc2 = build_tile_plan(fr, V, g->plan[2]);
+        rc2 = build_tile_plan(fr, V, g->plan[2], plane_bits + 1);
         if (rc2 == P2M_OK && g->plan[2].ntiles > 0) {
           g->n_pair_real = (int)preal.size();
           g->n_pair_fake = (int)pfake.size();
@@ -290,6 +318,7 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
     if (pl.erow) (void)hipFree(pl.erow);
     if (pl.ent) (void)hipFree(pl.ent);
     if (pl.tile_cnt) (void)hipFree(pl.tile_cnt);
+    if (pl.ltx) (void)hipFree(pl.ltx);
   }
   delete g;
   return P2M_OK;

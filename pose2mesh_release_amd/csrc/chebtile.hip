@@ -473,6 +473,289 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same contraction with the GATHER ON THE MATRIX CORES (two-fp16-slice arithmetic only).
+//
+// k_cheb_tile_gemm above forms L X and L2 X with v_fma chains in its producer waves: 16 fmafs per merged-CSR entry and
+// lane, 11 VALU instructions per MFMA - the kernel is bound by VALU issue, not by the matrix pipe or HBM.  Here the tile's
+// operator is a DENSE block (TilePlan::ltx: the coefficients of the <= 32 output rows of both planes over the <= 128
+// union columns, pre-cut into two fp16 slices at bake time) and the planes are a small matrix product per unit:
+//
+//   stage 1   E^T[(sample, feature), (plane, row)] = Xu^T[(sample, feature), u] * Lt^T[u, (plane, row)]
+//             M = 128, N = 64, K = 128: 8 k-steps, each MFMA wave owns (two samples) x (one plane), three slice products
+//             per step -> 48 MFMAs per wave and unit.  A operand: the union rows of the 4 samples, cut into fp16
+//             slices and TRANSPOSED by the producer waves on the way into LDS (a lane owns 4 union rows x 4 features:
+//             the 4 rows of one feature are one 8-byte store, as in k_gemm_tn_ws); B operand: the wave's 32 rows of the
+//             dense block, in registers for the whole block (they do not depend on the unit).
+//   convert   the accumulators (fp32: E 2^(sx + lt_exp)) hold, per lane, 4 consecutive features of one (plane, row):
+//             rescale, cut into fp16 slices, 8-byte stores into the A image of stage 2 - no cross-lane traffic.
+//   stage 2   C = [A0 | E1 | E2] W: exactly the k loop of k_cheb_tile_gemm (72 MFMAs per wave and unit).
+// The producers only move data: union rows and plane 0 from global (prefetched one unit ahead), split, store.  Two
+// LDS-only block barriers per unit.  LDS: 69 632 (transposed union image) + 53 248 (A image) = 120 KB.  120 MFMAs per
+// wave and unit instead of 72, ~150 VALU instructions per lane instead of ~550.
+// E1 / E2 differ from the fmaf chain of k_basis_tile by fp32 round-off (22-bit operands, fp32 accumulation).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MG_LDU = TILE_UPAD + 8;                  // fp16 per row of the transposed union image: 272 B = 17 x 16 B
+constexpr int MG_LDK = 3 * CT_CF + 8;                  // fp16 per row of the A image: 208 B = 13 x 16 B
+constexpr int MG_XU_SLICE = CT_S * CT_CF * MG_LDU;     // rows (sample, feature as e * 8 + q for feature 4 q + e)
+constexpr int MG_A_SLICE = CT_S * 32 * MG_LDK;         // rows (sample, tile row)
+constexpr int MG_XU_BYTES = 2 * MG_XU_SLICE * 2;
+constexpr int MG_A_BYTES = 2 * MG_A_SLICE * 2;
+constexpr int MG_LDS_BYTES = MG_XU_BYTES + MG_A_BYTES + 256;
+static_assert(TILE_UCAP <= TILE_UPAD && TILE_UPAD == 128, "stage 1 walks 8 k-steps of 16 union rows");
+static_assert(MG_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+
+template <int TM, int TN, int NPW, int MODE>
+__global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(TileGemmArgs g) {
+  constexpr int NS = 2;
+  typedef f16x8 frag_t;
+  constexpr int NP = 64 * NPW;
+  constexpr int WM = CT_S / TM;
+  constexpr int WN = 4 / WM;
+  constexpr int NXI = 16 / NPW;               // union items (4 rows x 4 features) per producer lane
+  constexpr int NPI = 1024 / NP;              // plane-0 items (1 row x 4 features) per producer lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
+  unsigned short* Xu = reinterpret_cast<unsigned short*>(ct_smem);
+  unsigned short* Ai = Xu + 2 * MG_XU_SLICE;
+  int* rowvid = reinterpret_cast<int*>(ct_smem + MG_XU_BYTES + MG_A_BYTES);
+
+  const TilePlan& pl = g.pl;
+  const int ngroups = (g.B + CT_S - 1) / CT_S;
+  const int nbg = (ngroups + g.gpb - 1) / g.gpb;
+  const int lid = xcd_contiguous(blockIdx.x, gridDim.x);
+  if (lid >= pl.ntiles * nbg) return;
+  const int tile = lid % pl.ntiles;
+  const int bg = lid / pl.ntiles;
+  const int grp0 = bg * g.gpb;
+  int grp1 = grp0 + g.gpb;
+  if (grp1 > ngroups) grp1 = ngroups;
+  const int nchunks = g.Ka / CT_CF;
+  const int nunits = (grp1 - grp0) * nchunks;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  if (t < 32) rowvid[t] = t < R ? g.row_ids[r0 + t] : -1;
+  __syncthreads();
+  const int sx = slice_scale_exp(*g.x_amax, g.x_bits);
+  const float x_sc = exp2_int(sx);
+  const int descale = -(sx + slice_scale_exp(*g.b_amax, 0));
+
+  if (t >= 256) {
+    // ------------------------------------------------------------------------------------------------ producers
+    const int pt = t - 256;
+    const int q = pt & 7;                               // this lane's 4 features (16 bytes) of a 128-byte line
+    // union image items: (u-quad, sample, q).  The 16 lanes of a store group are 8 q x 2 u-quads: rows e * 8 + q are
+    // 4 dwords apart mod 32, the two u-quads 2 dwords -> every 8-byte store of a group has its own bank pair
+    const int ulo = (pt >> 3) & 1, s = (pt >> 4) & 3, uhi = pt >> 6;
+    unsigned uoff[NXI][4];
+#pragma unroll
+    for (int k = 0; k < NXI; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int u = ((((uhi + k * NPW) << 1) | ulo) << 2) + j;
+        uoff[k][j] = (unsigned)pl.ucol[u0 + (u < U ? u : U - 1)] * (unsigned)(g.Ka * 4);   // clamped: their Lt columns are 0
+      }
+    // plane-0 items: (tile row, sample, q)
+    const int s0 = (pt >> 3) & 3, i0 = pt >> 5;
+    unsigned a0off[NPI];
+#pragma unroll
+    for (int k = 0; k < NPI; k++) {
+      const int vid = rowvid[i0 + k * (NP / 32)];
+      a0off[k] = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
+    }
+    f32x4 xr[NXI][4], p0[NPI];
+    auto sample_of = [&](int grp, int ss) {             // clamped: a group's missing samples recompute the last one
+      const int b = grp * CT_S + ss;
+      return b < g.B ? b : g.B - 1;
+    };
+    int lg = grp0, lfc = 0;                             // next unit of the loaders
+    auto load_unit = [&]() {
+      const char* bx = reinterpret_cast<const char*>(g.X + ((long)sample_of(lg, s) * g.x_rows) * g.Ka + lfc * CT_CF + q * 4);
+#pragma unroll
+      for (int k = 0; k < NXI; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xr[k][j] = *reinterpret_cast<const f32x4*>(bx + uoff[k][j]);
+      const char* ba = reinterpret_cast<const char*>(g.A0 + ((long)sample_of(lg, s0) * g.a0_rows) * g.Ka + lfc * CT_CF + q * 4);
+#pragma unroll
+      for (int k = 0; k < NPI; k++) p0[k] = *reinterpret_cast<const f32x4*>(ba + a0off[k]);
+      if (++lfc == nchunks) { lfc = 0; lg++; }
+    };
+    auto store_xu = [&]() {
+#pragma unroll
+      for (int k = 0; k < NXI; k++) {
+        const int uq = ((uhi + k * NPW) << 1) | ulo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          u32x2 ph, pl2;
+          split2_pack4(xr[k][0][e], xr[k][1][e], xr[k][2][e], xr[k][3][e], x_sc, ph, pl2);
+          unsigned short* d = Xu + (s * 32 + e * 8 + q) * MG_LDU + uq * 4;
+          *reinterpret_cast<u32x2*>(d) = ph;
+          *reinterpret_cast<u32x2*>(d + MG_XU_SLICE) = pl2;
+        }
+      }
+    };
+    auto store_p0 = [&]() {
+#pragma unroll
+      for (int k = 0; k < NPI; k++) {
+        u32x2 ph, pl2;
+        split2_pack4(p0[k][0], p0[k][1], p0[k][2], p0[k][3], x_sc, ph, pl2);
+        unsigned short* d = Ai + (s0 * 32 + i0 + k * (NP / 32)) * MG_LDK + q * 4;
+        *reinterpret_cast<u32x2*>(d) = ph;
+        *reinterpret_cast<u32x2*>(d + MG_A_SLICE) = pl2;
+      }
+    };
+    load_unit();
+    store_p0();
+    store_xu();
+    if (nunits > 1) load_unit();
+    lds_block_barrier();                                // X2(-1): unit 0 is staged
+    for (int w = 0; w < nunits; w++) {
+      lds_block_barrier();                              // X1(w): the MFMA waves are done with the union image of unit w
+      if (w + 1 < nunits) store_xu();                   // ... under their stage 2
+      lds_block_barrier();                              // X2(w): ... and with the A image of unit w
+      if (w + 1 < nunits) {
+        store_p0();                                     // plane 0 of unit w + 1, under its stage 1 (visible at X1(w + 1))
+        if (w + 2 < nunits) load_unit();
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ MFMA waves
+    // 2 x 2 over (sample pair, plane) in stage 1 and over (sample pair, column half) in stage 2
+    static_assert(WM == 2 && WN == 2 && TM == 2, "wave pair (2 wm, 2 wm + 1) owns samples 2 wm, 2 wm + 1");
+    const int wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // stage 2: the pre-split weight, as in k_cheb_tile_gemm
+    const long bx_slice = (long)g.Npad * 32;
+    const long bx_plane = (long)(g.Ka / 16) * NS * bx_slice;
+    const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
+    constexpr int NB = TN == 1 ? 3 : 2;
+    frag_t fb[NB][NS][TN];
+    auto load_b = [&](int fc, int st, frag_t (&b)[NS][TN]) {
+      const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * NS * bx_slice;
+#pragma unroll
+      for (int sl = 0; sl < NS; sl++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          b[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(src + sl * bx_slice + j * (32 * 16 * 2)));
+    };
+    const unsigned short* a_lane = Ai + ((wm * TM) * 32 + l31) * MG_LDK + lhi * 8;
+    auto read_a = [&](int sl, int koff, frag_t (&a)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+        a[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * MG_A_SLICE + i * 32 * MG_LDK + koff));
+    };
+    // stage 1: this wave forms plane wn + 1 of samples 2 wm, 2 wm + 1.  A fragments = rows (sample, feature) of the union
+    // image; B fragments = rows (plane wn, tile row) of the dense block - the same for every unit of the block, so all
+    // 8 k-steps stay in registers (64 VGPRs) and stage 1 reads nothing but the union image from LDS: the LDS pipe is
+    // shared by the four SIMDs and was as busy as each of their matrix pipes
+    const unsigned short* xu_lane = Xu + ((wm * 2) * 32 + l31) * MG_LDU + lhi * 8;
+    frag_t lt[TILE_UPAD / 16][NS];
+    {
+      const unsigned short* src = pl.ltx + (size_t)tile * TILE_LTX_ELEMS + (lhi * 64 + wn * 32 + l31) * 8;
+#pragma unroll
+      for (int ks = 0; ks < TILE_UPAD / 16; ks++)
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++)
+          lt[ks][sl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(src + (ks * 2 + sl) * 128 * 8));
+    }
+    const float e_sc = exp2_int(-pl.lt_exp);             // stage-1 accumulator = E 2^(sx + lt_exp)
+    unsigned short* c_lane = Ai + ((wm * 2) * 32 + l31) * MG_LDK + (wn + 1) * CT_CF + 16 * lhi;
+    float* Eout = wn == 0 ? g.E1 : g.E2;
+    load_b(0, 0, fb[0]);
+    if (NB == 3) load_b(0, 1, fb[1]);
+    lds_block_barrier();                                // X2(-1)
+    int grp = grp0, fc = 0;
+    for (int w = 0; w < nunits; w++) {
+      const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
+      // ---- stage 1.  Fragments of step ks + 1 are read in front of the MFMAs of step ks: issued behind them, their
+      // latency would be a bubble of the matrix pipe at every step
+      floatx16 e[2];                                    // (the first product of a unit takes the literal 0 as its addend)
+      frag_t xa[2][2][NS];                              // [ring][sample][slice]
+      auto read_x = [&](int ks, frag_t (&x)[2][NS]) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int sl = 0; sl < NS; sl++)
+            x[i][sl] = __builtin_bit_cast(
+                frag_t, *reinterpret_cast<const u32x4*>(xu_lane + i * 32 * MG_LDU + sl * MG_XU_SLICE + ks * 16));
+      };
+      read_x(0, xa[0]);
+#pragma unroll
+      for (int ks = 0; ks < TILE_UPAD / 16; ks++) {
+        if (ks + 1 < TILE_UPAD / 16) read_x(ks + 1, xa[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const frag_t (&x)[2][NS] = xa[ks & 1];
+#pragma unroll
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][1], lt[ks][0], ks == 0 ? floatx16{} : e[i]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], lt[ks][1], e[i]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], lt[ks][0], e[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- the plane leaves the accumulators: lane = tile row l31, registers j + 4 q4 = features 16 lhi + 4 j + q4
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int bsm = grp * CT_S + wm * 2 + i;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (Eout != nullptr && l31 < R && bsm < g.B) {
+            f32x4 o;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) o[q4] = __builtin_ldexpf(e[i][j + 4 * q4], -(sx + pl.lt_exp));
+            const long at = ((long)bsm * g.nset + r0 + l31) * g.Ka + fc * CT_CF + 16 * lhi + 4 * j;
+            *reinterpret_cast<f32x4*>(Eout + at) = o;    // (cached: L2 merges the 16-byte pieces of a line)
+          }
+          u32x2 ph, pl2;
+          split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, ph, pl2);
+          unsigned short* d = c_lane + i * 32 * MG_LDK + 4 * j;
+          *reinterpret_cast<u32x2*>(d) = ph;
+          *reinterpret_cast<u32x2*>(d + MG_A_SLICE) = pl2;
+        }
+      }
+      lds_block_barrier();                              // X1(w): planes 1, 2 of unit w visible; union image released
+      // ---- stage 2
+      frag_t fa[2][NS][TM];                             // A fragments, one step ahead
+      read_a(0, 0, fa[0][0]);
+      read_a(1, 0, fa[0][1]);
+#pragma unroll
+      for (int st = 0; st < 6; st++) {
+        constexpr int AH = NB - 1;
+        if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
+        else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
+        if (st + 1 < 6) {
+          read_a(0, (st + 1) * 16, fa[(st + 1) & 1][0]);
+          read_a(1, (st + 1) * 16, fa[(st + 1) & 1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#define P2M_PAIR(SA, SB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = slice_mfma<NS>(fa[st & 1][SA][i], fb[st % NB][SB][j], acc[i][j]);
+        P2M_PAIR(1, 0)
+        P2M_PAIR(0, 1)
+        P2M_PAIR(0, 0)
+#undef P2M_PAIR
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (fc == nchunks - 1) {
+        tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
+        grp++;
+      }
+      fc = fcn;
+      lds_block_barrier();                              // X2(w): stage 2 is done with the A image
+    }
+  }
+}
 
 }  // namespace p2m
 
@@ -514,9 +797,39 @@ static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
   if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT, NS>(a, s);
   return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN, NS>(a, s);
 }
+template <int TM, int TN, int NPW, int MODE>
+static int launch_mg_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_mg_gemm<TM, TN, NPW, MODE>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", MG_LDS_BYTES, hipGetErrorString(e));
+      return P2M_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int ngroups = cdiv(a.B, CT_S);
+  const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
+  hipLaunchKernelGGL((k_cheb_mg_gemm<TM, TN, NPW, MODE>), dim3(nblocks), dim3(256 + 64 * NPW), MG_LDS_BYTES, s, a);
+  return check_launch("cheb_tile_gemm(matrix gather)");
+}
+template <int TM, int TN, int NPW>
+static int launch_mg_gemm(const TileGemmArgs& a, hipStream_t s) {
+  if (a.stats != nullptr) return launch_mg_gemm_mode<TM, TN, NPW, CT_STATS>(a, s);
+  if (a.addend != nullptr) return launch_mg_gemm_mode<TM, TN, NPW, CT_ADDEND>(a, s);
+  if (a.act_scale != nullptr || a.act_relu) return launch_mg_gemm_mode<TM, TN, NPW, CT_ACT>(a, s);
+  return launch_mg_gemm_mode<TM, TN, NPW, CT_PLAIN>(a, s);
+}
+
 template <int TM, int TN, int NPW>
 static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
-  return a.x_amax != nullptr ? launch_tile_gemm_ns<TM, TN, NPW, 2>(a, s) : launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
+  if (a.x_amax == nullptr) return launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
+  // two fp16 slices: N <= 128 takes the gather on the matrix cores (4 producer waves: they only move data, and the MFMA
+  // waves need the 256-register budget for the dense-block rows and two accumulator sets); N = 256 (a 128-register
+  // accumulator) stays with the VALU gather
+  if constexpr (TN == 1) return a.N == 128 ? launch_mg_gemm<2, 2, 4>(a, s) : launch_mg_gemm<2, 1, 4>(a, s);
+  else return launch_tile_gemm_ns<TM, TN, NPW, 2>(a, s);
 }
 
 extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, int32_t Ka, int32_t N) {

@@ -622,12 +622,19 @@ __global__ __launch_bounds__(1024) void k_amax_one_block(const float* __restrict
     *word = __float_as_uint(m);
   }
 }
-// Any size: atomic max into a word the caller has zeroed.  n4 = float4 count (n % 4 == 0, 16-byte aligned base).
-__global__ __launch_bounds__(256) void k_amax(const f32x4* __restrict__ x, long n4, unsigned* __restrict__ word) {
+// Any size and alignment: atomic max into a word the caller has zeroed.  `head` scalars up to the first 16-byte boundary,
+// n4 float4, `tail` scalars (block 0 takes the scalars).
+__global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, int head, long n4, int tail,
+                                              unsigned* __restrict__ word) {
   float m = 0.f;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + head);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const f32x4 v = x[i];
+    const f32x4 v = x4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < head) m = fmaxf(m, fabsf(x[threadIdx.x]));
+    if ((int)threadIdx.x < tail) m = fmaxf(m, fabsf(x[head + n4 * 4 + threadIdx.x]));
   }
   amax_commit(word, m);
 }
@@ -1306,11 +1313,14 @@ extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t a
 
 extern "C" int p2m_amax(const float* x, int64_t n, void* word, void* stream) {
   P2M_CHECK_ARG(x && word && n >= 0, "null pointer");
-  P2M_CHECK_ARG(n % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "n must be a multiple of 4, x 16-byte aligned");
+  P2M_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 3) == 0, "x must be 4-byte aligned");
   if (n == 0) return P2M_OK;
-  const long n4 = n / 4;
-  const int grid = (int)(n4 < 256l * 2048 ? cdiv(n4, 256) : 2048);
-  hipLaunchKernelGGL(k_amax, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x), n4,
+  long head = (long)((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4;
+  if (head > n) head = n;
+  const long n4 = (n - head) / 4;
+  const int tail = (int)(n - head - 4 * n4);
+  const int grid = (int)(n4 < 256l * 2048 ? (n4 > 0 ? cdiv(n4, 256) : 1) : 2048);
+  hipLaunchKernelGGL(k_amax, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (int)head, n4, tail,
                      static_cast<unsigned*>(word));
   return check_launch("amax");
 }

@@ -24,7 +24,15 @@ struct TilePlan {
   int* erow = nullptr;        // [n_real+1]  entry range of each compact row
   float4* ent = nullptr;      // per entry {a, b, bits(local index into the tile's union), 0}, merged-CSR order
   float* tile_cnt = nullptr;  // [ntiles]    rows of each tile (as float: the weight of a tile's BatchNorm partials)
+  // The same operator as a DENSE block per tile, for the gather on the matrix cores (k_cheb_mg_gemm): row (p, i) =
+  // coefficients of output row i of plane p (0: a, 1: b) over the tile's union columns, zero padded to TILE_UPAD, times
+  // 2^lt_exp, cut into two fp16 slices and laid out as MFMA B fragments in 16-byte units:
+  // ltx[tile][u / 16][slice][(u / 8) % 2][p * 32 + i][u % 8].
+  unsigned short* ltx = nullptr;
+  int lt_exp = 0;
 };
+constexpr int TILE_UPAD = 128;                       // union columns of the dense block (>= TILE_UCAP, a multiple of 16)
+constexpr int TILE_LTX_ELEMS = (TILE_UPAD / 16) * 2 * 64 * 16;     // uint16 per tile: 32 KB
 // (measured and rejected: 64-row tiles / 240 union rows - halving the resident blocks costs more than the 22 % fewer L2-side
 //  reads bring; 80 / 512 and 100 / 768 at three resident blocks: DESIGN.md section 6)
 constexpr int TILE_RMAX = 32;      // rows per tile

@@ -115,7 +115,8 @@ CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
 if TILE_GEMM not in ("auto", "0", "1"):
     raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
-TILE_GEMM_MIN_ROWS = 3000      # "auto": real rows of the level (the two finest SMPL-like levels: 6890, 3638) ...
+TILE_GEMM_MG_MIN_ROWS = 1500   # "auto", f16x2 and N <= 128: the three finest SMPL-like levels (6890, 3638, 1923 real rows)
+TILE_GEMM_MIN_ROWS = 3000      # "auto", otherwise: the two finest levels, forward-form launches only ...
 TILE_GEMM_MIN_BATCH = 128      # ... and enough sample groups per tile to amortise a block's tables (B = 64 inference: 4.14 vs
                                # 3.83 ms per batch with the kernel on, measured)
 
@@ -323,7 +324,9 @@ def cheb_basis_fwd_real(g, X, B, F, in_shift):
 # products on the fp16 matrix pipe (22-bit operands); "bf16x3" = operands cut exactly into 3 bf16 slices, 6 slice products
 # (error vs float64 <= the native kernel's, tests/test_gpu_ops.py::test_bf16x3_error_is_fp32_class); "f32" = native f32
 # MFMA (the independent kernel set of the parity tests).
-GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "bf16x3")
+# Default f16x2: same parity maxima against the float64 oracle as bf16x3 (tests/test_gpu_parity_full.py) at half the
+# matrix-core work and two thirds of the LDS traffic - train step 40.1 vs 44.1 ms on the same MI355X.
+GEMM_ARITH = _os.environ.get("P2M_GEMM_ARITH", "f16x2")
 if GEMM_ARITH not in ("f32", "bf16x3", "f16x2"):
     raise ValueError(f"P2M_GEMM_ARITH must be f32, bf16x3 or f16x2, not {GEMM_ARITH!r}")
 
@@ -372,7 +375,7 @@ def view_tagged(t, *shape):
 def amax_of(t, g=None, B=None, row_set=0):
     """The amax word of t (None unless GEMM_ARITH is f16x2): the one its producer attached, else computed now - over the
     rows of `row_set` of level g when given (0: every row that holds data), else over the whole tensor."""
-    if not f16x2() or t is None or t.numel() % 4 != 0:      # (widths that are not MFMA shapes take the scalar kernels)
+    if not f16x2() or t is None or t.shape[-1] % 4 != 0:    # (widths that are not MFMA shapes take the scalar kernels)
         return None
     w = getattr(t, "_p2m_amax", None)
     if w is None:
@@ -465,7 +468,7 @@ def weight_split(Bm, amax=None, bits=0):
 
 def param_amax(W):
     """f16x2: one amax word per parameter tensor - its packed / transposed / effective copies are bounded by it."""
-    if not f16x2() or W.numel() % 4 != 0:
+    if not f16x2():
         return None
     w = new_amax(W.device)
     check(_lib.hip().p2m_amax(_p(_req(W, "weight")), W.numel(), _p(w), _stream()), "p2m_amax")
@@ -552,7 +555,11 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
         return False
     if TILE_GEMM in ("1", True):
         return True
-    return plan != 2 and not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
+    if plan == 2 or (B is not None and B < TILE_GEMM_MIN_BATCH):
+        return False
+    if f16x2() and N <= 128:        # the gather runs on the matrix cores (k_cheb_mg_gemm): also with the planes written out
+        return g.n_real >= TILE_GEMM_MG_MIN_ROWS
+    return not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS
 
 
 def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None,

@@ -637,7 +637,11 @@ def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkey
         err = (y - yref).abs().max().item()
         assert err < 2e-5 * max(1.0, yref.abs().max().item()), err
         if stats:
-            assert torch.equal(planes[0], T1c) and torch.equal(planes[1], T2c)
+            if slices == "bf16x3":      # the fmaf chain of the basis kernel, bit for bit
+                assert torch.equal(planes[0], T1c) and torch.equal(planes[1], T2c)
+            else:                       # f16x2, N <= 128: the planes come off the matrix cores (22-bit operands, fp32 sums)
+                for got, ref in ((planes[0], T1c), (planes[1], T2c)):
+                    assert (got - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
             gamma, beta = (torch.rand(Fout) + 0.5).cuda(), torch.randn(Fout).cuda()
             We = ops.weight_eff(Wt, Fin, Fout, g.fake_a, g.fake_b)
             st2 = ops.gemm_planes_rows(g, 2, B, [X], Fin, shift, False, We, bias, None, yref, Fout, True)

@@ -7,7 +7,7 @@
       plus eval slices of the same batch against the oracle;
   (d) three optimizer steps of the bench's TrainStep against oracle + torch.optim.Adam;
   (e) train-mode bitwise repeatability.
-All through the C ABI on the default (bf16x3) arithmetic.  Achieved maxima are written to
+All through the C ABI on the default (f16x2) arithmetic.  Achieved maxima are written to
 gpurun_out/parity_maxima.json (DESIGN.md section 5 quotes them)."""
 import json
 import os
@@ -201,8 +201,8 @@ def test_bench_scale_vs_oracle_train(hip_libs, joint_set, B):
 @pytest.mark.parametrize("joint_set,B,seeds", [("coco", 256, (41, 55, 9)), ("mano", 512, (42, 56, 10))])
 def test_baseline_sizes_default_vs_independent_kernel_set(hip_libs, tmp_path, joint_set, B, seeds):
     """(c) BASELINE configs[2] (SMPL-like coco graph, B=256, train) and configs[4] (MANO-like, B=512, train).  No CPU
-    oracle can run these sizes (float64 needs ~140 GB for configs[2]), so the default kernel set (bf16x3 contraction on
-    the BF16 pipe, fake-vertex split, LDS-tiled basis, wave-specialised GEMM) is compared with an INDEPENDENT one (native
+    oracle can run these sizes (float64 needs ~140 GB for configs[2]), so the default kernel set (f16x2 contraction on
+    the FP16 pipe, fake-vertex split, LDS-tiled basis, wave-specialised GEMM) is compared with an INDEPENDENT one (native
     f32 MFMA, unsplit rows, row-per-wave gather, 4-wave GEMM) that test_independent_kernel_set_vs_oracle_train pins to the
     float64 oracle at network level.  Forward: per-vertex L2.  Backward: the two runs' ReLU masks are compared bit by
     bit -- the handful of differing elements (fp32 kinks) is counted, and the gradient tolerance is the one that count

@@ -1,4 +1,4 @@
-"""Throughput and error of p2m_gemm_planes in both arithmetics (native f32 MFMA / bf16x3 split) on the layer shapes
+"""Throughput and error of p2m_gemm_planes in its arithmetics (native f32 MFMA / 3 bf16 slices / 2 fp16 slices) on the layer shapes
 of the SMPL network at batch 256.   python tools/probes/gemm_probe.py [B]"""
 import os
 import sys
@@ -12,9 +12,9 @@ from pose2mesh_release_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(96, 256, 256), (184, 256, 256), (368, 256, 128), (736, 128, 128), (1472, 128, 64), (2944, 64, 64),
           (5888, 64, 64), (11776, 64, 32)]           # (V, Ka, N)
-if os.environ.get("PROBE_SHAPE"):                     # e.g. PROBE_SHAPE=736,128,128 PROBE_MODES=bf16x3 for a PMC pass
+if os.environ.get("PROBE_SHAPE"):                     # e.g. PROBE_SHAPE=736,128,128 PROBE_MODES=f16x2 for a PMC pass
     SHAPES = [tuple(int(x) for x in os.environ["PROBE_SHAPE"].split(","))]
-MODES = os.environ.get("PROBE_MODES", "f32,bf16x3").split(",")
+MODES = os.environ.get("PROBE_MODES", "f32,bf16x3,f16x2").split(",")
 PLANES = int(os.environ.get("PROBE_PLANES", "3"))      # 1..3 A planes: time vs K gives the per-tile overhead
 
 

@@ -20,8 +20,8 @@ bash tools/rocprof_stats.sh ${T}_train --steps 4 --warmup 2 --no-kernel-timing -
 bash tools/rocprof_stats.sh ${T}_infer --mode infer --steps 20 --warmup 5 --no-kernel-timing --no-cpu-baseline > /dev/null 2>&1
 bash tools/rocprof_traffic.sh ${T} > gpurun_out/${T}_traffic.out 2>&1
 tail -12 gpurun_out/${T}_traffic.out
-PROBE_SHAPE=5888,128,128 PROBE_MODES=bf16x3 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_a "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
-PROBE_SHAPE=5888,128,128 PROBE_MODES=bf16x3 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
+PROBE_SHAPE=5888,128,128 PROBE_MODES=f16x2 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_a "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
+PROBE_SHAPE=5888,128,128 PROBE_MODES=f16x2 bash tools/rocprof_pmc.sh ${T}_pmc_gemm_b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" python $R/tools/probes/gemm_probe.py > /dev/null 2>&1
 # the basis-inside-the-contraction kernel (finest level, 128 -> 128, forward form): MFMA busy / VALU / waits, LDS conflicts,
 # HBM bytes
 for spec in "a:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
