@@ -486,13 +486,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 //             per step -> 48 MFMAs per wave and unit.  A operand: the union rows of the 4 samples, cut into fp16
 //             slices and TRANSPOSED by the producer waves on the way into LDS (a lane owns 4 union rows x 4 features:
 //             the 4 rows of one feature are one 8-byte store, as in k_gemm_tn_ws); B operand: the wave's 32 rows of the
-//             dense block, in registers for the whole block (they do not depend on the unit).
+//             dense block, copied to LDS once per block.
 //   convert   the accumulators (fp32: E 2^(sx + lt_exp)) hold, per lane, 4 consecutive features of one (plane, row):
 //             rescale, cut into fp16 slices, 8-byte stores into the A image of stage 2 - no cross-lane traffic.
 //   stage 2   C = [A0 | E1 | E2] W: exactly the k loop of k_cheb_tile_gemm (72 MFMAs per wave and unit).
 // The producers only move data: union rows and plane 0 from global (prefetched one unit ahead), split, store.  Two
-// LDS-only block barriers per unit.  LDS: 69 632 (transposed union image) + 53 248 (A image) = 120 KB.  120 MFMAs per
-// wave and unit instead of 72, ~150 VALU instructions per lane instead of ~550.
+// LDS-only block barriers per unit.  LDS: 69 632 (transposed union image) + 53 248 (A image) + 32 768 (dense block)
+// = 152 KB.  120 MFMAs per wave and unit instead of 72, ~150 VALU instructions per lane instead of ~550.
 // E1 / E2 differ from the fmaf chain of k_basis_tile by fp32 round-off (22-bit operands, fp32 accumulation).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MG_LDU = TILE_UPAD + 8;                  // fp16 per row of the transposed union image: 272 B = 17 x 16 B
@@ -501,7 +501,8 @@ constexpr int MG_XU_SLICE = CT_S * CT_CF * MG_LDU;     // rows (sample, feature 
 constexpr int MG_A_SLICE = CT_S * 32 * MG_LDK;         // rows (sample, tile row)
 constexpr int MG_XU_BYTES = 2 * MG_XU_SLICE * 2;
 constexpr int MG_A_BYTES = 2 * MG_A_SLICE * 2;
-constexpr int MG_LDS_BYTES = MG_XU_BYTES + MG_A_BYTES + 256;
+constexpr int MG_LT_BYTES = TILE_LTX_ELEMS * 2;
+constexpr int MG_LDS_BYTES = MG_XU_BYTES + MG_A_BYTES + MG_LT_BYTES + 256;
 static_assert(TILE_UCAP <= TILE_UPAD && TILE_UPAD == 128, "stage 1 walks 8 k-steps of 16 union rows");
 static_assert(MG_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
 
@@ -517,7 +518,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* Xu = reinterpret_cast<unsigned short*>(ct_smem);
   unsigned short* Ai = Xu + 2 * MG_XU_SLICE;
-  int* rowvid = reinterpret_cast<int*>(ct_smem + MG_XU_BYTES + MG_A_BYTES);
+  unsigned short* Lt = Ai + 2 * MG_A_SLICE;
+  int* rowvid = reinterpret_cast<int*>(ct_smem + MG_XU_BYTES + MG_A_BYTES + MG_LT_BYTES);
 
   const TilePlan& pl = g.pl;
   const int ngroups = (g.B + CT_S - 1) / CT_S;
@@ -537,6 +539,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
   const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
   const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
   if (t < 32) rowvid[t] = t < R ? g.row_ids[r0 + t] : -1;
+  {                                           // the tile's dense block: global -> LDS, once per block
+    const u32x4* src = reinterpret_cast<const u32x4*>(pl.ltx + (size_t)tile * TILE_LTX_ELEMS);
+    u32x4* dst = reinterpret_cast<u32x4*>(Lt);
+    for (int k = t; k < MG_LT_BYTES / 16; k += 256 + 64 * NPW) dst[k] = src[k];
+  }
   __syncthreads();
   const int sx = slice_scale_exp(*g.x_amax, g.x_bits);
   const float x_sc = exp2_int(sx);
@@ -638,7 +645,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
     const long bx_slice = (long)g.Npad * 32;
     const long bx_plane = (long)(g.Ka / 16) * NS * bx_slice;
     const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
-    constexpr int NB = TN == 1 ? 3 : 2;
+    // ring of NB fragment sets: the set of step st is refilled, for step st + NB (of this unit or the next), as soon as
+    // step st has used it.  N = 64: one set per k-step, a whole unit of lead; N = 128: three sets (six would spill)
+    constexpr int NB = TN == 1 ? 6 : 3;
     frag_t fb[NB][NS][TN];
     auto load_b = [&](int fc, int st, frag_t (&b)[NS][TN]) {
       const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * NS * bx_slice;
@@ -655,24 +664,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
         a[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * MG_A_SLICE + i * 32 * MG_LDK + koff));
     };
     // stage 1: this wave forms plane wn + 1 of samples 2 wm, 2 wm + 1.  A fragments = rows (sample, feature) of the union
-    // image; B fragments = rows (plane wn, tile row) of the dense block - the same for every unit of the block, so all
-    // 8 k-steps stay in registers (64 VGPRs) and stage 1 reads nothing but the union image from LDS: the LDS pipe is
-    // shared by the four SIMDs and was as busy as each of their matrix pipes
+    // image; B fragments = rows (plane wn, tile row) of the dense block (LDS, 16-byte units [k-step][slice][half][row])
     const unsigned short* xu_lane = Xu + ((wm * 2) * 32 + l31) * MG_LDU + lhi * 8;
-    frag_t lt[TILE_UPAD / 16][NS];
-    {
-      const unsigned short* src = pl.ltx + (size_t)tile * TILE_LTX_ELEMS + (lhi * 64 + wn * 32 + l31) * 8;
-#pragma unroll
-      for (int ks = 0; ks < TILE_UPAD / 16; ks++)
-#pragma unroll
-        for (int sl = 0; sl < NS; sl++)
-          lt[ks][sl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(src + (ks * 2 + sl) * 128 * 8));
-    }
+    const unsigned short* lt_lane = Lt + (lhi * 64 + wn * 32 + l31) * 8;
     const float e_sc = exp2_int(-pl.lt_exp);             // stage-1 accumulator = E 2^(sx + lt_exp)
     unsigned short* c_lane = Ai + ((wm * 2) * 32 + l31) * MG_LDK + (wn + 1) * CT_CF + 16 * lhi;
     float* Eout = wn == 0 ? g.E1 : g.E2;
-    load_b(0, 0, fb[0]);
-    if (NB == 3) load_b(0, 1, fb[1]);
+#pragma unroll
+    for (int st = 0; st < NB; st++) load_b(0, st, fb[st]);
     lds_block_barrier();                                // X2(-1)
     int grp = grp0, fc = 0;
     for (int w = 0; w < nunits; w++) {
@@ -680,42 +679,37 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       // ---- stage 1.  Fragments of step ks + 1 are read in front of the MFMAs of step ks: issued behind them, their
       // latency would be a bubble of the matrix pipe at every step
       floatx16 e[2];                                    // (the first product of a unit takes the literal 0 as its addend)
-      frag_t xa[2][2][NS];                              // [ring][sample][slice]
-      auto read_x = [&](int ks, frag_t (&x)[2][NS]) {
+      frag_t xa[2][2][NS], lt[2][NS];                   // [ring][sample][slice], [ring][slice]
+      auto read_x = [&](int ks, frag_t (&x)[2][NS], frag_t (&l)[NS]) {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
-          for (int sl = 0; sl < NS; sl++)
+          for (int i = 0; i < 2; i++)
             x[i][sl] = __builtin_bit_cast(
                 frag_t, *reinterpret_cast<const u32x4*>(xu_lane + i * 32 * MG_LDU + sl * MG_XU_SLICE + ks * 16));
+          l[sl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lt_lane + (ks * 2 + sl) * 128 * 8));
+        }
       };
-      read_x(0, xa[0]);
+      read_x(0, xa[0], lt[0]);
 #pragma unroll
       for (int ks = 0; ks < TILE_UPAD / 16; ks++) {
-        if (ks + 1 < TILE_UPAD / 16) read_x(ks + 1, xa[(ks + 1) & 1]);
+        if (ks + 1 < TILE_UPAD / 16) read_x(ks + 1, xa[(ks + 1) & 1], lt[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         const frag_t (&x)[2][NS] = xa[ks & 1];
+        const frag_t (&l)[NS] = lt[ks & 1];
 #pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][1], lt[ks][0], ks == 0 ? floatx16{} : e[i]);
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][1], l[0], ks == 0 ? floatx16{} : e[i]);
 #pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], lt[ks][1], e[i]);
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], l[1], e[i]);
 #pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], lt[ks][0], e[i]);
+        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], l[0], e[i]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the plane leaves the accumulators: lane = tile row l31, registers j + 4 q4 = features 16 lhi + 4 j + q4
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        const int bsm = grp * CT_S + wm * 2 + i;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          if (Eout != nullptr && l31 < R && bsm < g.B) {
-            f32x4 o;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) o[q4] = __builtin_ldexpf(e[i][j + 4 * q4], -(sx + pl.lt_exp));
-            const long at = ((long)bsm * g.nset + r0 + l31) * g.Ka + fc * CT_CF + 16 * lhi + 4 * j;
-            *reinterpret_cast<f32x4*>(Eout + at) = o;    // (cached: L2 merges the 16-byte pieces of a line)
-          }
           u32x2 ph, pl2;
           split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, ph, pl2);
           unsigned short* d = c_lane + i * 32 * MG_LDK + 4 * j;
@@ -730,9 +724,6 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       read_a(1, 0, fa[0][1]);
 #pragma unroll
       for (int st = 0; st < 6; st++) {
-        constexpr int AH = NB - 1;
-        if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
-        else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
         if (st + 1 < 6) {
           read_a(0, (st + 1) * 16, fa[(st + 1) & 1][0]);
           read_a(1, (st + 1) * 16, fa[(st + 1) & 1][1]);
@@ -746,6 +737,27 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
         P2M_PAIR(0, 0)
 #undef P2M_PAIR
         __builtin_amdgcn_sched_barrier(0);
+        if (st + NB < 6) load_b(fc, st + NB, fb[st % NB]);       // step st + NB of this unit, or of the next one (the last
+        else load_b(fcn, st + NB - 6, fb[st % NB]);              // unit refetches chunk 0: unused)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the plane as fp32, for the weight gradient.  AFTER stage 2: vmcnt counts loads and stores in order, so a store in
+      // front of stage 2 makes each of its waits for weight fragments a wait for the store's HBM acknowledgement as well
+      if (Eout != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int bsm = grp * CT_S + wm * 2 + i;
+          if (l31 < R && bsm < g.B) {
+            float* dst = Eout + ((long)bsm * g.nset + r0 + l31) * g.Ka + fc * CT_CF + 16 * lhi;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              f32x4 o;
+#pragma unroll
+              for (int q4 = 0; q4 < 4; q4++) o[q4] = __builtin_ldexpf(e[i][j + 4 * q4], -(sx + pl.lt_exp));
+              *reinterpret_cast<f32x4*>(dst + 4 * j) = o;          // (cached: L2 merges the 16-byte pieces of a line)
+            }
+          }
+        }
       }
       if (fc == nchunks - 1) {
         tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
