@@ -425,65 +425,70 @@ def main():
                                             "work": sum(k["work"] for k in ks),
                                             "work_alg": sum(k["work_alg"] for k in ks),
                                             "bytes": sum(k.get("bytes", 0.0) for k in ks)}
-            g = merged("gemm_planes_mfma", "gemm_planes_mfma_bwd")
-            if g:
-                if ops.GEMM_ARITH == "bf16x3":
-                    kprefix = ops.gemm_kernel_name()
-                    kname = kprefix + " (fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product)"
-                    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-                elif ops.GEMM_ARITH == "f16x2":
-                    kprefix = ops.gemm_kernel_name()
-                    kname = kprefix + " (fp32 as 2 scaled fp16 slices, 3 x v_mfma_f32_32x32x16_f16 per product)"
-                    peak = PEAK_BF16_MFMA_TFLOPS / 3.0       # the FP16 dense peak equals the BF16 one
-                else:
-                    kprefix = "k_gemm_planes<"
-                    kname, peak = "k_gemm_planes (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
-                ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-                tr, tr_src = _traffic_for(kprefix)
-                line["roofline"] = {"bound": "mfma", "kernel": kname,
-                                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                    "frac": round(ach / peak, 4),
-                                    "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                                    "algorithmic_bytes_per_launch": round(g["bytes"] / g["launches"]),
-                                    "launches": g["launches"], "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                                    "note": "achieved = algorithmic fp32 FLOPs / HIP-event time; peak = pipe peak "
-                                            "in algorithmic fp32 FLOPs (16-bit dense 2500 / 3 fp16 or 6 bf16 slice "
-                                            "products, or the f32 MFMA 157.3)",
-                                    "hbm_achieved_GBps": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
-                                    "hbm_frac_of_8000": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                                    "frac_of_f32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
+            # One roofline object per contraction family.  Each is bounded by the LARGER of (algorithmic fp32 FLOPs / matrix
+            # pipe peak in those FLOPs) and (algorithmic HBM bytes / 8 TB/s) - SURVEY 8(d)'s rule; `bound` names the binding
+            # resource, achieved / peak / frac refer to it, and both fractions are always listed.  `roofline` is the family
+            # with the largest measured time in the step; the others follow as roofline_<family>.
+            slices = {"f16x2": 3.0, "bf16x3": 6.0}.get(ops.GEMM_ARITH)
+            pipe_peak = PEAK_BF16_MFMA_TFLOPS / slices if slices else PEAK_FP32_MFMA_TFLOPS
+            arith_note = {"f16x2": "fp32 as 2 scaled fp16 slices, 3 x v_mfma_f32_32x32x16_f16 per product",
+                          "bf16x3": "fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product",
+                          "f32": "v_mfma_f32_32x32x2_f32"}[ops.GEMM_ARITH]
+
+            def family(rec, kernel, prefixes, fwd=None):
+                if not rec or rec["ms"] <= 0:
+                    return None
+                sec = rec["ms"] * 1e-3
+                tf, gbs = rec["work"] / sec / 1e12, rec["bytes"] / sec / 1e9
+                f_m, f_h = tf / pipe_peak, gbs / PEAK_HBM_GBPS
+                tr, tr_src = _traffic_for(*prefixes)
+                alg = rec["bytes"] / rec["launches"]
+                o = {"bound": "hbm" if f_h >= f_m else "mfma", "kernel": f"{kernel} ({arith_note})",
+                     "achieved": round(gbs, 1) if f_h >= f_m else round(tf, 2),
+                     "peak": PEAK_HBM_GBPS if f_h >= f_m else round(pipe_peak, 1),
+                     "unit": "GB/s" if f_h >= f_m else "TFLOP/s", "frac": round(max(f_h, f_m), 4),
+                     "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                     "algorithmic_bytes_per_launch": round(alg),
+                     "traffic_over_algorithmic": None if tr is None else round(tr["hbm_bytes_per_launch"] / alg, 3),
+                     "mfma": {"achieved_TFLOPs": round(tf, 2), "peak": round(pipe_peak, 1), "frac": round(f_m, 4),
+                              "frac_of_f32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)},
+                     "hbm": {"achieved_GBps": round(gbs, 1), "peak": PEAK_HBM_GBPS, "frac": round(f_h, 4),
+                             "frac_of_copy_ceiling_6300": round(gbs / 6300.0, 4)},
+                     "launches": rec["launches"], "avg_launch_ms": round(rec["ms"] / rec["launches"], 4),
+                     "ms_per_step": round(rec["ms"] / args.steps, 3),
+                     "note": "achieved = algorithmic work / HIP-event time over ALL launches of the family in the timed "
+                             "steps (backward launches share the GPU with the side-stream weight gradient); matrix-pipe peak "
+                             "in algorithmic fp32 FLOPs = 2500 / slice products (or the f32 MFMA's 157.3); algorithmic "
+                             "bytes = every operand row and every output row once"}
                 if tr is not None:
-                    line["roofline"]["traffic_note"] = (
-                        f"HBM bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE) averaged over the "
-                        f"{tr['launches']} launches of this kernel in the rocprofv3 --pmc passes of {tr_src}")
-                f = summ.get("gemm_planes_mfma")       # forward launches: no other kernel shares the GPU with them
-                if f and not infer:
-                    achf = f["work"] / (f["ms"] * 1e-3) / 1e12
-                    line["roofline"]["exclusive"] = {
-                        "note": "forward launches only; backward launches overlap the side-stream k_gemm_tn",
-                        "achieved": round(achf, 2), "frac": round(achf / peak, 4),
-                        "frac_of_f32_mfma_peak": round(achf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "launches": f["launches"], "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
-            tg = merged("cheb_tile_gemm", "cheb_tile_gemm_bwd")
-            if tg and tg["ms"] > 0:
-                # basis inside the contraction (k_cheb_tile_gemm): SURVEY 8(d)'s rule for a fused kernel -- the larger of
-                # dense FLOPs / MFMA peak and 4 V (Fin + Fout) bytes / 8 TB/s bounds it; both fractions are reported
-                peak_t = PEAK_BF16_MFMA_TFLOPS / (3.0 if ops.GEMM_ARITH == "f16x2" else 6.0)
-                ach = tg["work"] / (tg["ms"] * 1e-3) / 1e12
-                gbs = tg["bytes"] / (tg["ms"] * 1e-3) / 1e9
-                tr, tr_src = _traffic_for("k_cheb_tile_gemm")
-                line["roofline_fused"] = {
-                    "bound": "mfma", "kernel": f"k_cheb_tile_gemm (Chebyshev planes formed per tile in LDS, {ops.GEMM_ARITH} "
-                                               "MFMA; no T1/T2 planes in HBM)",
-                    "achieved": round(ach, 2), "peak": round(peak_t, 1), "unit": "TFLOP/s", "frac": round(ach / peak_t, 4),
-                    "hbm_achieved_GBps": round(gbs, 1), "hbm_frac_of_8000": round(gbs / PEAK_HBM_GBPS, 4),
-                    "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                    "algorithmic_bytes_per_launch": round(tg["bytes"] / tg["launches"]),
-                    "traffic_over_algorithmic": None if tr is None else round(
-                        tr["hbm_bytes_per_launch"] / (tg["bytes"] / tg["launches"]), 3),
-                    "launches": tg["launches"], "avg_launch_ms": round(tg["ms"] / tg["launches"], 4),
-                    "note": "algorithmic bytes = 4 rows (Fin + Fout): the input rows once, the output once (SURVEY 8(d), "
-                            "fused rule); which launches take this kernel: ops.TILE_GEMM (P2M_TILE_GEMM, default auto)"}
+                    o["traffic_note"] = (f"HBM bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE) averaged "
+                                         f"over the {tr['launches']} launches of this family in the rocprofv3 --pmc passes of "
+                                         f"{tr_src}")
+                if fwd and fwd["ms"] > 0 and not infer:
+                    fs = fwd["ms"] * 1e-3
+                    o["exclusive"] = {"note": "forward launches only (nothing else on the GPU)",
+                                      "mfma_frac": round(fwd["work"] / fs / 1e12 / pipe_peak, 4),
+                                      "hbm_frac": round(fwd["bytes"] / fs / 1e9 / PEAK_HBM_GBPS, 4),
+                                      "launches": fwd["launches"], "avg_launch_ms": round(fwd["ms"] / fwd["launches"], 4)}
+                return o
+            fams = {
+                "planes": family(merged("gemm_planes_mfma", "gemm_planes_mfma_bwd"),
+                                 "k_gemm_planes_ws: C = [A0|A1|A2] W, planes from HBM" if slices else "k_gemm_planes",
+                                 (ops.gemm_kernel_name(),), summ.get("gemm_planes_mfma")),
+                "weight_gradient": family(merged("gemm_tn_mfma", "gemm_tn_mfma_bwd"),
+                                          "k_gemm_tn_ws: P = X^T [g|Lg|L2g] over row chunks" if slices else "k_gemm_tn",
+                                          ("k_gemm_tn_ws",) if slices else ("k_gemm_tn<",)),
+                "fused": family(merged("cheb_tile_gemm", "cheb_tile_gemm_bwd"),
+                                "k_cheb_mg_gemm / k_cheb_tile_gemm: Chebyshev planes formed per tile on chip, no T1/T2 in HBM "
+                                "on the way in", ("k_cheb_mg_gemm", "k_cheb_tile_gemm"), summ.get("cheb_tile_gemm")),
+            }
+            fams = {k: v for k, v in fams.items() if v is not None}
+            if fams:
+                top = max(fams, key=lambda k: fams[k]["ms_per_step"])
+                line["roofline"] = dict(fams[top], family=top)
+                for k, v in fams.items():
+                    if k != top:
+                        line["roofline_" + k] = v
             sp = merged("cheb_basis_fwd", "cheb_basis_fwd_bwd", "cheb_basis_bwd", "cheb_basis_bwd_bwd")
             if sp and sp["ms"] > 0:
                 # achieved = the bytes the launches have to move (real-vertex rows only: read X once at the stored

@@ -664,7 +664,8 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_
     P = torch.empty((nch, Ka, N), device=A.device, dtype=torch.float32)
     Pdb = torch.empty((nch, N), device=A.device, dtype=torch.float32)
     gp = [_p(_req(t, "G plane")) for t in G] + [None] * (3 - len(G))
-    with _timed("gemm_tn_mfma", 2.0 * B * n * Ka * N):
+    # algorithmic HBM bytes: every row of A and of the G planes once (the partials are small)
+    with _timed("gemm_tn_mfma", (2.0 * B * n * Ka * N, 2.0 * B * n * Ka * N, 4.0 * B * n * (Ka + N))):
         check(_lib.hip().p2m_gemm_tn_rows(g.handle, row_set, B, _p(_req(A, "A")), Ka, a0_shift, gp[0], gp[1], gp[2],
                                           len(G), Gc, int(compact), splits, _p(P), _p(Pdb), arith_code(),
                                           _p(a_amax), _p(g_amax), int(g_bits), _stream()),
@@ -784,7 +785,7 @@ def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits
             a_amax = _amax_planes(A)
         if g_amax is None:
             g_amax = _amax_planes(Gl)
-    with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", 2.0 * M * Ktot * N):
+    with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", (2.0 * M * Ktot * N, 2.0 * M * Ktot * N, 4.0 * M * (Ktot + N))):
         check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, gp[0], gp[1], gp[2], len(Gl), Gc, M,
                                      chunk_rows, _p(P), _p(Pdb), arith_code() if mfma else 0, _p(a_amax), int(a_bits),
                                      _p(g_amax), int(g_bits), _stream()), "p2m_gemm_tn")
