@@ -117,8 +117,8 @@ if TILE_GEMM not in ("auto", "0", "1"):
     raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
 TILE_GEMM_MG_MIN_ROWS = 1500   # "auto", f16x2 and N <= 128: the three finest SMPL-like levels (6890, 3638, 1923 real rows)
 TILE_GEMM_MIN_ROWS = 3000      # "auto", otherwise: the two finest levels, forward-form launches only ...
-TILE_GEMM_MIN_BATCH = 128      # ... and enough sample groups per tile to amortise a block's tables (B = 64 inference: 4.14 vs
-                               # 3.83 ms per batch with the kernel on, measured)
+TILE_GEMM_MIN_BATCH = 128      # ... and, for the VALU-gather kernel, enough sample groups per tile to amortise a block's tables
+                               # (B = 64 inference: 4.14 vs 3.83 ms per batch with that kernel on, measured)
 
 
 class DeviceGraph:
@@ -555,11 +555,11 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
         return False
     if TILE_GEMM in ("1", True):
         return True
-    if plan == 2 or (B is not None and B < TILE_GEMM_MIN_BATCH):
+    if plan == 2:
         return False
-    if f16x2() and N <= 128:        # the gather runs on the matrix cores (k_cheb_mg_gemm): also with the planes written out
-        return g.n_real >= TILE_GEMM_MG_MIN_ROWS
-    return not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS
+    if f16x2() and N <= 128:        # the gather runs on the matrix cores (k_cheb_mg_gemm): also with the planes written out,
+        return g.n_real >= TILE_GEMM_MG_MIN_ROWS        # at any batch (B = 64 inference 3.51 vs 3.96 ms, B = 8 1.63 vs 1.76)
+    return not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
 
 
 def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None,
