@@ -7,9 +7,11 @@ but every device op is a hand-written gfx950 kernel reached through the C ABI (i
 
   reference op (file:line)                              here
   ---------------------------------------------------  ------------------------------------------
-  permute/view, 2x torch.sparse.mm, 2x cat, permute     p2m_cheb_basis_fwd  (one gather pass, CSR of L|2LL-I)
-    (backbones/cheby_graph_conv.py:16-34)
-  cl(x) nn.Linear (cheby_graph_conv.py:37)              p2m_gemm_planes     (fp32 product on the BF16 MFMA pipe, BN partials in epilogue)
+  permute/view, 2x torch.sparse.mm, 2x cat, permute     p2m_cheb_basis_fwd  (one gather pass, CSR of L|2LL-I), or, on the
+    (backbones/cheby_graph_conv.py:16-34)                 big levels, inside the contraction: p2m_cheb_tile_gemm
+  cl(x) nn.Linear (cheby_graph_conv.py:37)              p2m_gemm_planes     (fp32 product as 2 scaled fp16 slices on the
+                                                          matrix pipe - the amax words travel with the tensors -, BN
+                                                          partials in the epilogue)
   bn(x) BatchNorm1d over B*V rows (:39) + F.relu        p2m_bn_finalize + p2m_bn_act_fwd
     (meshnet.py:100) + F.interpolate residual (:109)
   nn.Upsample x2 (meshnet.py:71-78)                     not materialised: consumers index r>>1
