@@ -361,6 +361,20 @@ def main():
             for _ in range(args.steps):
                 step()
         torch.cuda.synchronize()
+    timer_serial = None
+    if not args.no_kernel_timing and not infer and world == 1:
+        # ... and twice more with the weight-gradient launches on the MAIN stream (ops.DW_SIDE_STREAM off): in the step they
+        # overlap the main stream's kernels, so their bracketed times above measure a shared GPU; here every launch has
+        # the GPU to itself (`exclusive_serial` in the roofline objects)
+        timer_overlap, ops.TIMER = ops.TIMER, ops.KernelTimer()
+        side, ops.DW_SIDE_STREAM = ops.DW_SIDE_STREAM, False
+        try:
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+        finally:
+            ops.DW_SIDE_STREAM = side
+        timer_serial, ops.TIMER = ops.TIMER, timer_overlap
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -418,6 +432,7 @@ def main():
                                       "speed-up-equivalent, NOT a utilisation -- `roofline` counts executed FLOPs"}
         if timer is not None:
             summ = timer.summary()
+            summ_serial = timer_serial.summary() if timer_serial is not None else None
 
             def merged(*names):
                 ks = [summ[n] for n in names if n in summ]
@@ -435,7 +450,14 @@ def main():
                           "bf16x3": "fp32 as 3 bf16 slices, 6 x v_mfma_f32_32x32x16_bf16 per product",
                           "f32": "v_mfma_f32_32x32x2_f32"}[ops.GEMM_ARITH]
 
-            def family(rec, kernel, prefixes, fwd=None):
+            def merged_serial(*names):
+                if summ_serial is None:
+                    return None
+                ks = [summ_serial[n] for n in names if n in summ_serial]
+                return None if not ks else {"launches": sum(k["launches"] for k in ks), "ms": sum(k["ms"] for k in ks),
+                                            "work": sum(k["work"] for k in ks), "bytes": sum(k.get("bytes", 0.0) for k in ks)}
+
+            def family(rec, kernel, prefixes, fwd=None, serial=None):
                 if not rec or rec["ms"] <= 0:
                     return None
                 sec = rec["ms"] * 1e-3
@@ -470,17 +492,29 @@ def main():
                                       "mfma_frac": round(fwd["work"] / fs / 1e12 / pipe_peak, 4),
                                       "hbm_frac": round(fwd["bytes"] / fs / 1e9 / PEAK_HBM_GBPS, 4),
                                       "launches": fwd["launches"], "avg_launch_ms": round(fwd["ms"] / fwd["launches"], 4)}
+                if serial and serial["ms"] > 0:
+                    ss = serial["ms"] * 1e-3
+                    o["exclusive_serial"] = {
+                        "note": "the same launches in two extra steps with the weight gradient on the main stream: every "
+                                "launch has the GPU to itself",
+                        "mfma_frac": round(serial["work"] / ss / 1e12 / pipe_peak, 4),
+                        "hbm_frac": round(serial["bytes"] / ss / 1e9 / PEAK_HBM_GBPS, 4),
+                        "hbm_GBps": round(serial["bytes"] / ss / 1e9, 1),
+                        "launches": serial["launches"], "avg_launch_ms": round(serial["ms"] / serial["launches"], 4)}
                 return o
             fams = {
                 "planes": family(merged("gemm_planes_mfma", "gemm_planes_mfma_bwd"),
                                  "k_gemm_planes_ws: C = [A0|A1|A2] W, planes from HBM" if slices else "k_gemm_planes",
-                                 (ops.gemm_kernel_name(),), summ.get("gemm_planes_mfma")),
+                                 (ops.gemm_kernel_name(),), summ.get("gemm_planes_mfma"),
+                                 merged_serial("gemm_planes_mfma", "gemm_planes_mfma_bwd")),
                 "weight_gradient": family(merged("gemm_tn_mfma", "gemm_tn_mfma_bwd"),
                                           "k_gemm_tn_ws: P = X^T [g|Lg|L2g] over row chunks" if slices else "k_gemm_tn",
-                                          ("k_gemm_tn_ws",) if slices else ("k_gemm_tn<",)),
+                                          ("k_gemm_tn_ws",) if slices else ("k_gemm_tn<",), None,
+                                          merged_serial("gemm_tn_mfma", "gemm_tn_mfma_bwd")),
                 "fused": family(merged("cheb_tile_gemm", "cheb_tile_gemm_bwd"),
                                 "k_cheb_mg_gemm / k_cheb_tile_gemm: Chebyshev planes formed per tile on chip, no T1/T2 in HBM "
-                                "on the way in", ("k_cheb_mg_gemm", "k_cheb_tile_gemm"), summ.get("cheb_tile_gemm")),
+                                "on the way in", ("k_cheb_mg_gemm", "k_cheb_tile_gemm"), summ.get("cheb_tile_gemm"),
+                                merged_serial("cheb_tile_gemm", "cheb_tile_gemm_bwd")),
             }
             fams = {k: v for k, v in fams.items() if v is not None}
             if fams:
