@@ -46,7 +46,8 @@ typedef enum {
  *         x (1 + d), |d| <= 2^-22, for |x| >= 2^-18 U and an absolute error <= 2^-40 U below; a product additionally
  *         drops <= 2^-22 |a b|.  Half the matrix-core work of BF16X3.  U comes from an AMAX WORD: a uint32 in device
  *         memory holding the bits of a non-negative float >= max |x| over the tensor, produced on the device by
- *         whoever wrote the tensor (the amax_out arguments, p2m_amax, p2m_amax_rows) - it only has to BOUND the
+ *         whoever wrote the tensor (the amax_out arguments, p2m_amax, p2m_amax_rows; NaN and infinity are left out,
+ *         so a non-finite element poisons its own rows of a contraction, as in fp32, not the scale) - it only has to BOUND the
  *         magnitudes; `bits` arguments add binades of headroom for operands derived from the bounded tensor inside
  *         the same call (Chebyshev planes: p2m_graph_plane_bits).                                                  */
 enum { P2M_ARITH_F32 = 0, P2M_ARITH_BF16X3 = 1, P2M_ARITH_F16X2 = 2 };

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
   const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
   const float o = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
   if (live) gy[idx] = o;
-  if (amax != nullptr) amax_commit(amax, live ? fabsf(o) : 0.f);
+  if (amax != nullptr) amax_commit(amax, live ? amax_abs(o) : 0.f);
 }
 
 // Two stages like the forward finalize.  Stage 1: block = 32 adjacent columns of BOTH partial kinds (128-byte coalesced

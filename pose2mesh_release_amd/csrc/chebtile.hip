@@ -133,7 +133,7 @@ __device__ __forceinline__ void tile_epilogue_full(const TileGemmArgs& g, const 
 #pragma unroll
       for (int j = 0; j < TN; j++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) vmax = fmaxf(vmax, fabsf(acc[i][j][r]));
+        for (int r = 0; r < 16; r++) vmax = fmaxf(vmax, amax_abs(acc[i][j][r]));
     amax_commit(g.amax_out, vmax);
   }
   if (MODE == CT_STATS) {
@@ -236,7 +236,7 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
 #pragma unroll
           for (int j = 0; j < TN; j++) {
             Cb[i][j][voff[r]] = acc[i][j][r];
-            vmax = fmaxf(vmax, fabsf(acc[i][j][r]));
+            vmax = fmaxf(vmax, amax_abs(acc[i][j][r]));
           }
         }
       }

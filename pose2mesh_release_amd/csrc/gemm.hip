@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
           Cq[row * g.Nc + c] = v;
           csum[j] += v;
-          vmax = fmaxf(vmax, fabsf(v));
+          vmax = fmaxf(vmax, amax_abs(v));
         }
       }
       if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
           if (row < g.M) {
             const float pv = acc[i][j][r] + acc[i][j][r + 1];
             Cq[(row >> 1) * g.Nc + c] = pv;
-            vmax = fmaxf(vmax, fabsf(pv));
+            vmax = fmaxf(vmax, amax_abs(pv));
           }
         }
       }
@@ -606,13 +606,13 @@ __global__ __launch_bounds__(1024) void k_amax_one_block(const float* __restrict
     for (int u = 0; u < 8; u++) v[u] = x4[i + u * 1024];
 #pragma unroll
     for (int u = 0; u < 8; u++)
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+      m = fmaxf(fmaxf(m, fmaxf(amax_abs(v[u][0]), amax_abs(v[u][1]))), fmaxf(amax_abs(v[u][2]), amax_abs(v[u][3])));
   }
   for (; i < n4; i += 1024) {
     const f32x4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(fmaxf(m, fmaxf(amax_abs(v[0]), amax_abs(v[1]))), fmaxf(amax_abs(v[2]), amax_abs(v[3])));
   }
-  for (long j = n4 * 4 + threadIdx.x; j < n; j += 1024) m = fmaxf(m, fabsf(x[j]));
+  for (long j = n4 * 4 + threadIdx.x; j < n; j += 1024) m = fmaxf(m, amax_abs(x[j]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -630,11 +630,11 @@ __global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, int h
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x + head);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const f32x4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(fmaxf(m, fmaxf(amax_abs(v[0]), amax_abs(v[1]))), fmaxf(amax_abs(v[2]), amax_abs(v[3])));
   }
   if (blockIdx.x == 0) {
-    if ((int)threadIdx.x < head) m = fmaxf(m, fabsf(x[threadIdx.x]));
-    if ((int)threadIdx.x < tail) m = fmaxf(m, fabsf(x[head + n4 * 4 + threadIdx.x]));
+    if ((int)threadIdx.x < head) m = fmaxf(m, amax_abs(x[threadIdx.x]));
+    if ((int)threadIdx.x < tail) m = fmaxf(m, amax_abs(x[head + n4 * 4 + threadIdx.x]));
   }
   amax_commit(word, m);
 }
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, 
     const int c = (int)(i - row * f4);
     const int b = (int)(row / rs.n), r = (int)(row - (long)b * rs.n);
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * rs.V + (rs.ids ? rs.ids[r] : r)) * F + c * 4);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = fmaxf(fmaxf(m, fmaxf(amax_abs(v[0]), amax_abs(v[1]))), fmaxf(amax_abs(v[2]), amax_abs(v[3])));
   }
   amax_commit(word, m);
 }

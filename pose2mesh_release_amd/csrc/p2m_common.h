@@ -121,8 +121,14 @@ __device__ __forceinline__ void amax_commit(unsigned* word, float m) {
     if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
   }
 }
+// |v| as it enters an amax word: NaN and infinity do not count (a non-finite element then poisons its own row of the
+// contraction, as in fp32, instead of the scale of the whole tensor)
+__device__ __forceinline__ float amax_abs(float v) {
+  const float a = fabsf(v);
+  return a < __builtin_inff() ? a : 0.f;
+}
 __device__ __forceinline__ float amax4(float m, const float* o) {
-  return fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  return fmaxf(fmaxf(m, fmaxf(amax_abs(o[0]), amax_abs(o[1]))), fmaxf(amax_abs(o[2]), amax_abs(o[3])));
 }
 #endif
 

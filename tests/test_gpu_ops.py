@@ -373,16 +373,17 @@ def test_f16x2_is_scale_free_and_zero_safe(ops, monkeypatch, magnitude):
     assert ((C2.double() - ref2).abs().max() < 2e-6 * ref2.abs().max()).item()
     rows = torch.arange(M, device="cuda") != 3
     assert ((C2.double() - ref2)[rows].abs().max() < 4e-6 * ref[rows.cpu()].abs().max()).item()
-    # a NaN stays in its own row, as in fp32: the amax reduction skips it (fmaxf), the scale is that of the finite data
+    # a NaN stays in its own row, as in fp32: the amax reduction skips non-finite values, the scale is that of the finite data
     (C0,), _ = ops.gemm_planes([A], Ka, 0, Bm, None, M, N, 1, False)
     A3 = A.clone()
     A3[7, 3] = float("nan")
     (C3,), _ = ops.gemm_planes([A3], Ka, 0, Bm, None, M, N, 1, False)
     assert torch.isnan(C3[7]).all()
     assert torch.equal(C3[rows7 := (torch.arange(M, device="cuda") != 7)], C0[rows7])
-    A3[7, 3] = float("inf")                     # an infinite operand poisons the bound, hence everything: loudly, not subtly
+    A3[7, 3] = float("inf")                     # ... and so does an infinity (it does not enter the amax word either)
     (C4,), _ = ops.gemm_planes([A3], Ka, 0, Bm, None, M, N, 1, False)
     assert not torch.isfinite(C4[7]).any()
+    assert torch.equal(C4[rows7], C0[rows7])
 
 
 def test_f16x2_weight_image(ops, monkeypatch):
