@@ -2,6 +2,8 @@
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -64,3 +66,30 @@ def test_class_representatives_cpu_logic():
     rep1, _ = o.class_representatives(16, fake, 1)
     assert rep1.tolist() == [0, 1, 2, 2, 4, 4, 6, 6, 8, 9, 10, 11, 12, 12, 14, 14]
     assert o.class_representatives(16, fake, 0)[0].tolist() == list(range(16))
+
+
+def test_slice_arithmetic_host_logic():
+    """Host side of P2M_ARITH_F16X2 (no GPU): headroom of an effective weight, the knob's values, and the scale exponent
+    rule of csrc/p2m_split.h restated (U 2^bits 2^s lands in [2^14, 2^15), clamped, 0 for an all-zero tensor)."""
+    import subprocess
+    import sys
+    from pose2mesh_release_amd import ops as o
+    assert [o.eff_bits(a, b) for a, b in ((0, 0), (1, 0), (0.5, 0.5), (1, 2), (-0.6, 0.3), (3, 4))] == [0, 1, 1, 2, 1, 3]
+    assert {k: v for k, v in zip(("f32", "bf16x3", "f16x2"), (0, 1, 2))} == \
+        {a: (setattr(o, "GEMM_ARITH", a), o.arith_code())[1] for a in ("f32", "bf16x3", "f16x2")}
+    o.GEMM_ARITH = os.environ.get("P2M_GEMM_ARITH", "f16x2")
+    r = subprocess.run([sys.executable, "-c", "import pose2mesh_release_amd.ops"], capture_output=True, text=True,
+                       env=dict(os.environ, P2M_GEMM_ARITH="fp8"))
+    assert r.returncode != 0 and "P2M_GEMM_ARITH" in r.stderr
+
+    def scale_exp(u, bits):                       # slice_scale_exp(bits of u, bits)
+        if u == 0.0:
+            return 0
+        e = (np.float32(u).view(np.uint32) >> 23) & 0xFF
+        return int(np.clip(141 - int(e) - bits, -120, 120))
+    for u in (1e-30, 3.7e-7, 0.05, 1.0, 2.0, 7.9, 6.5e4, 1e30):
+        for bits in (0, 1, 3):
+            s = scale_exp(u, bits)
+            if abs(141 - int((np.float32(u).view(np.uint32) >> 23) & 0xFF) - bits) <= 120:
+                assert 2.0 ** 14 <= u * 2.0 ** bits * 2.0 ** s < 2.0 ** 15, (u, bits, s)
+    assert scale_exp(0.0, 2) == 0 and scale_exp(1e-45, 0) == 120
