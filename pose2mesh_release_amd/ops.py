@@ -115,7 +115,8 @@ CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
 if TILE_GEMM not in ("auto", "0", "1"):
     raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
-TILE_GEMM_MG_MIN_ROWS = 1500   # "auto", f16x2 and N <= 128: the three finest SMPL-like levels (6890, 3638, 1923 real rows)
+TILE_GEMM_MG_MIN_ROWS = 300    # "auto", f16x2 and N <= 128: every split level with a 128- or 64-wide output (SMPL-like: 6890,
+                               # 3638, 1923 real rows; MANO-like: 778, 389).  1500 -> 300: MANO B=512 +1.4 %, SMPL +0.3 %
 TILE_GEMM_MIN_ROWS = 3000      # "auto", otherwise: the two finest levels, forward-form launches only ...
 TILE_GEMM_MIN_BATCH = 128      # ... and, for the VALU-gather kernel, enough sample groups per tile to amortise a block's tables
                                # (B = 64 inference: 4.14 vs 3.83 ms per batch with that kernel on, measured)
