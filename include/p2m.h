@@ -197,11 +197,13 @@ int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* x[r,f] = act(y[r,f]*scale[f] + shift[f]) + lerp_F(resid[r>>res_shift, 0..Fres))[f]
  * act = ReLU if relu!=0; scale/shift may be NULL (identity); resid may be NULL.
  * lerp_F is F.interpolate(mode='linear', align_corners=False) along the FEATURE axis
- * (meshnet.py:109,114).  amax_out (optional, F % 4 == 0): atomic max of |x stored| into a zeroed amax word
- * (P2M_ARITH_F16X2 above) - the bound for the contraction that consumes x.                     */
+ * (meshnet.py:109,114).  Rows: all M; with `classes` (a level's handle) the live rows of a level with declared
+ * classes (holes are skipped); with real_rows_only != 0 only the handle's real vertices (inference on the real rows:
+ * the other rows of y hold no data and x's stay untouched).  amax_out (optional, F % 4 == 0): atomic max of |x stored|
+ * into a zeroed amax word (P2M_ARITH_F16X2 above) - the bound for the contraction that consumes x.                  */
 int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                    const float* resid, int32_t Fres, int32_t res_shift,
-                   float* x, int64_t M, int32_t F, p2m_graph_t classes /* or NULL: holes are skipped */,
+                   float* x, int64_t M, int32_t F, p2m_graph_t classes /* or NULL */, int32_t real_rows_only,
                    void* amax_out, void* stream);
 /* backward through ReLU + BatchNorm (train: batch statistics; eval: running statistics).
  *   go = gx * (y*scale+shift > 0 or !relu)

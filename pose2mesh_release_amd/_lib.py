@@ -72,7 +72,7 @@ HIP_SYMBOLS = {
     "p2m_bn_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                    _i32, _i32, _vp]),
     "p2m_bn_eval_coeffs": (_c.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "p2m_bn_act_fwd": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     "p2m_bn_bwd_blocks": (_i32, [_i64, _i32]),
     "p2m_bn_bwd_blocks_classes": (_i32, [_vp, _i64, _i32]),
     "p2m_bn_bwd_reduce": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),

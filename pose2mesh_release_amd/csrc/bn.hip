@@ -972,8 +972,9 @@ extern "C" int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const f
 
 extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                               const float* resid, int32_t Fres, int32_t res_shift, float* x, int64_t M, int32_t F,
-                              p2m_graph_t classes, void* amax_out, void* stream) {
+                              p2m_graph_t classes, int32_t real_rows_only, void* amax_out, void* stream) {
   P2M_CHECK_ARG(y && x && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(!real_rows_only || classes != nullptr, "real_rows_only needs the level's graph handle");
   unsigned* amax = static_cast<unsigned*>(amax_out);
   P2M_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale/shift must both be given or both NULL");
   P2M_CHECK_ARG(resid == nullptr || Fres > 0, "Fres must be positive with a residual");
@@ -986,17 +987,24 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
       const long rows_per_block = (long)(256 / F4) * ACT_UNROLL * ACT_PASSES;
       RowMap m;
       long Mlog;
-      P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
+      if (real_rows_only) {               // inference on the real rows: the other rows of y hold no data
+        const Graph& g = *reinterpret_cast<const Graph*>(classes);
+        P2M_CHECK_ARG(M % g.V == 0 && M < (1LL << 32) && g.n_real > 0, "M is not a multiple of the level's vertex count");
+        m.w = nullptr; m.ids = g.real_ids; m.n = (unsigned)g.n_real; m.V = (unsigned)g.V;
+        Mlog = (M / g.V) * (long)g.n_real;
+      } else {
+        P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
+      }
       hipLaunchKernelGGL(k_bn_act_fwd, dim3(cdiv(Mlog, rows_per_block)), dim3(256), 0, s, y, scale, shift, relu, resid,
                          Fres, res_shift, x, Mlog, F, m, amax);
     } else {
-      P2M_CHECK_ARG(classes == nullptr || amax == nullptr, "amax_out with classes needs 256 % (F / 4) == 0");
+      P2M_CHECK_ARG((classes == nullptr || amax == nullptr) && !real_rows_only, "row maps need 256 % (F / 4) == 0");
       long tot = M * F4;
       hipLaunchKernelGGL(k_bn_act_fwd_v4, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid, Fres,
                          res_shift, x, (long)M, F, amax);
     }
   } else {
-    P2M_CHECK_ARG(amax == nullptr, "amax_out needs F % 4 == 0");
+    P2M_CHECK_ARG(amax == nullptr && !real_rows_only, "amax_out / real_rows_only need F % 4 == 0");
     long tot = M * F;
     hipLaunchKernelGGL(k_bn_act_fwd_generic, dim3(cdiv(tot, 256)), dim3(256), 0, s, y, scale, shift, relu, resid,
                        Fres, res_shift, x, (long)M, F);

@@ -157,7 +157,7 @@ def _forward_inference(net, graphs, x, params):
         del T1, T2
         if L.has_bn and L.last_in_block and 1 <= L.block <= nblk - 2:        # residual (meshnet.py:108-115)
             y = ops.bn_act_fwd(y, None, False, block_in, block_in_F, block_in_shift, M, L.Fout,
-                               amax_rows=(g, B, 1) if g.split else None)
+                               real_rows=g if g.split else None)
         cur, cur_shift = y, 0
         if L.last_in_block:
             if L.block == 0:                                                  # fc lift (:104-106)

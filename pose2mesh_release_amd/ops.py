@@ -828,23 +828,22 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, amax_rows=None):
-    """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped).  f16x2: the output comes
-    back tagged with its amax word - over the live rows (classes), over amax_rows = (DeviceGraph, B, row_set) when only
-    those rows of y hold data (inference on the real rows), else over all rows."""
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_rows=None):
+    """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped); real_rows: the level's
+    DeviceGraph when only the REAL rows of y hold data (inference on the real rows): only those are walked.  f16x2: the
+    output comes back tagged with the amax word of what was written."""
     x = torch.empty((M, F), device=y.device, dtype=torch.float32)
     sc = None if co is None else co[2]
     sh = None if co is None else co[3]
     cls = classes.handle if (classes is not None and classes.classes) else None
-    # the pass itself bounds what it writes, unless it also walks rows that hold no data (amax_rows)
-    word = new_amax(y.device) if (f16x2() and F % 4 == 0 and amax_rows is None) else None
+    if real_rows is not None:
+        cls = real_rows.handle
+    word = new_amax(y.device) if (f16x2() and F % 4 == 0) else None
     check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
                                     _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),
-                                    _p(x), M, F, cls, _p(word), _stream()), "p2m_bn_act_fwd")
+                                    _p(x), M, F, cls, int(real_rows is not None), _p(word), _stream()), "p2m_bn_act_fwd")
     if word is not None:
         tag_amax(x, word)
-    elif f16x2() and F % 4 == 0:
-        amax_of(x, amax_rows[0], amax_rows[1], amax_rows[2])
     return x
 
 
