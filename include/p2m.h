@@ -165,6 +165,23 @@ int p2m_gemm_planes(const float* A0, const float* A1, const float* A2, int32_t n
 int64_t p2m_weight_split_elems(int32_t K, int32_t N, int32_t arith);
 int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t arith, const void* amax_in, int32_t amax_bits,
                      void* Bx, void* stream);
+/* Every slice image of a network's conv weights in two launches (instead of p2m_weight_pack + p2m_weight_eff x 2 +
+ * p2m_weight_split x 4 + p2m_amax per layer and optimizer step).  dev_desc: DEVICE array of n descriptors, one per conv
+ * layer with weight W[Fout][Fin * 3 + k] (nn.Linear layout, cheby_graph_conv.py:37): the images (each sized by
+ * p2m_weight_split_elems for its [K, N]; NULL = not wanted)
+ *   Bx_f   [3 Fin, Fout]   forward, real rows            Bx_ef  [Fin, Fout]   forward, padding rows: W0 + a W1 + b W2
+ *   Bx_b   [3 Fout, Fin]   backward dX, real rows        Bx_eb  [Fout, Fin]   backward dX, padding rows
+ * and, for P2M_ARITH_F16X2, the parameter's amax word (written here; eff_bits = ceil(log2(1 + |a| + |b|)) is the headroom
+ * of the two effective forms).  The buffers and the descriptor array can be allocated once and reused every step.      */
+typedef struct p2m_conv_weights {
+  const float* W;
+  int32_t Fout, Fin;
+  float fake_a, fake_b;
+  int32_t eff_bits, reserved;
+  void *Bx_f, *Bx_ef, *Bx_b, *Bx_eb;
+  void* amax;
+} p2m_conv_weights;
+int p2m_conv_weights_prepare(const p2m_conv_weights* dev_desc, int32_t n, int32_t arith, void* stream);
 /* amax words: atomic max of |x| into *word (uint32, device; the caller zeroes it before the first contribution).
  * p2m_amax: n contiguous floats.  p2m_amax_rows: rows of a [B, V, F] tensor of a level -
  * row_set 0 = every row that holds data (all rows; the live rows once classes are declared), 1..4 = that row set.   */

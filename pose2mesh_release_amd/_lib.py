@@ -54,6 +54,7 @@ HIP_SYMBOLS = {
                                       _vp, _i32, _vp, _i32, _vp]),
     "p2m_graph_plane_bits": (_i32, [_vp, _i32]),
     "p2m_amax": (_c.c_int, [_vp, _i64, _vp, _vp]),
+    "p2m_conv_weights_prepare": (_c.c_int, [_vp, _i32, _i32, _vp]),
     "p2m_amax_rows": (_c.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "p2m_bn_finalize_tiles": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                          _i32, _vp]),

@@ -1197,6 +1197,107 @@ __global__ void k_weight_eff(const float* __restrict__ Wt, float* __restrict__ W
   We[idx] = Wt[idx] + a * Wt[plane + idx] + b * Wt[2 * plane + idx];
 }
 
+// ---- every slice image of a network's conv weights in two launches ----------------------------------------------------
+// A split conv needs four pre-split operands of its weight W[Fout][Fin * 3 + k] per optimizer step: [3 Fin, Fout] (forward,
+// real rows), its effective K = Fin form W0 + a W1 + b W2 (forward, padding rows), [3 Fout, Fin] (backward dX, real rows)
+// and that one's effective form.  Through p2m_weight_pack / _eff / _split / p2m_amax that is 8 launches per layer, ~150
+// per step, each a few microseconds long with a pipeline drain on either side - 1.5 ms of a 38 ms step.  Here: one block per
+// layer for the parameters' amax words, then ONE launch that writes all images straight from W (blockIdx.y = layer).
+struct ConvWeights {            // == p2m_conv_weights of include/p2m.h
+  const float* W;
+  int Fout, Fin;
+  float fake_a, fake_b;
+  int eff_bits, reserved;
+  unsigned short *Bx_f, *Bx_ef, *Bx_b, *Bx_eb;
+  unsigned* amax;
+};
+static_assert(sizeof(ConvWeights) == 72, "layout shared with the callers (include/p2m.h, ops.py)");
+
+__global__ __launch_bounds__(1024) void k_conv_weights_amax(const ConvWeights* __restrict__ d) {
+  __shared__ float red[16];
+  const ConvWeights c = d[blockIdx.x];
+  const long n = (long)c.Fout * c.Fin * 3;
+  float m = 0.f;
+  const long n4 = (reinterpret_cast<uintptr_t>(c.W) & 15) == 0 ? n >> 2 : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(c.W);
+  for (long i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(amax_abs(v[0]), amax_abs(v[1]))), fmaxf(amax_abs(v[2]), amax_abs(v[3])));
+  }
+  for (long j = n4 * 4 + threadIdx.x; j < n; j += 1024) m = fmaxf(m, amax_abs(c.W[j]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) m = fmaxf(m, red[w]);
+    *c.amax = __float_as_uint(m);
+  }
+}
+
+// one image: Bx[k / 16][slice][n][k % 16] of value(k, n), n < Npad (zero beyond N), + the trailing amax word (NS = 2)
+template <int NS, typename F>
+__device__ __forceinline__ void write_weight_image(unsigned short* __restrict__ Bx, int K, int N, unsigned word, int bits,
+                                                   F value) {
+  if (Bx == nullptr) return;
+  const int Npad = cdiv_dev(N, 128) * 128;
+  const long sl = (long)Npad * 16, tot = (long)Npad * K;
+  float sc = 1.f;
+  if constexpr (NS == 2) {
+    sc = exp2_int(slice_scale_exp(word, bits));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      *reinterpret_cast<unsigned*>(Bx + (long)NS * Npad * K) =
+          word == 0u ? 0u : __float_as_uint(__builtin_ldexpf(__uint_as_float(word), bits));
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / Npad), n = (int)(i - (long)k * Npad);
+    const float v = n < N ? value(k, n) : 0.f;
+    unsigned short* dst = Bx + (long)(k >> 4) * NS * sl + (long)n * 16 + (k & 15);
+    if constexpr (NS == 3) {
+      unsigned h, m, l;
+      split3(v, h, m, l);
+      dst[0] = (unsigned short)(h >> 16);
+      dst[sl] = (unsigned short)(m >> 16);
+      dst[2 * sl] = (unsigned short)(l >> 16);
+    } else {
+      const float y = v * sc;
+      const _Float16 h = (_Float16)y;
+      const _Float16 l = (_Float16)(y - (float)h);
+      dst[0] = __builtin_bit_cast(unsigned short, h);
+      dst[sl] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_conv_weights_images(const ConvWeights* __restrict__ d) {
+  const ConvWeights c = d[blockIdx.y];
+  const float* __restrict__ W = c.W;
+  const int Fout = c.Fout, Fin = c.Fin, ld = 3 * c.Fin;
+  const float a = c.fake_a, b = c.fake_b;
+  const unsigned word = NS == 2 ? *c.amax : 0u;
+  // forward, real rows: Wt[kk * Fin + fin][fo] = W[fo][fin * 3 + kk]
+  write_weight_image<NS>(c.Bx_f, 3 * Fin, Fout, word, 0, [&](int k, int n) {
+    const int kk = k / Fin, fin = k - kk * Fin;
+    return W[(long)n * ld + fin * 3 + kk];
+  });
+  // forward, padding rows: (W0 + a W1 + b W2)[fin][fo]   (the expression of k_weight_eff)
+  write_weight_image<NS>(c.Bx_ef, Fin, Fout, word, c.eff_bits, [&](int k, int n) {
+    const float* w = W + (long)n * ld + k * 3;
+    return w[0] + a * w[1] + b * w[2];
+  });
+  // backward dX, real rows: W3[kk * Fout + fo][fin] = W[fo][fin * 3 + kk]
+  write_weight_image<NS>(c.Bx_b, 3 * Fout, Fin, word, 0, [&](int k, int n) {
+    const int kk = k / Fout, fo = k - kk * Fout;
+    return W[(long)fo * ld + n * 3 + kk];
+  });
+  // backward dX, padding rows: (W3_0 + a W3_1 + b W3_2)[fo][fin]
+  write_weight_image<NS>(c.Bx_eb, Fout, Fin, word, c.eff_bits, [&](int k, int n) {
+    const float* w = W + (long)k * ld + n * 3;
+    return w[0] + a * w[1] + b * w[2];
+  });
+}
+
 // Block = 32 consecutive output elements x UNP_CG chunk groups: the partial buffers hold hundreds of chunks (one per
 // sample in row-set mode), so the chunk loop is split UNP_CG ways (4 loads in flight each) and reduced through LDS.
 // 8 groups (256 threads): alone on the GPU 32 groups are faster, but this kernel runs on the side stream next to the
@@ -1317,6 +1418,22 @@ extern "C" int p2m_weight_split(const float* Bm, int32_t K, int32_t N, int32_t a
     hipLaunchKernelGGL(k_weight_split<3>, grid, dim3(256), 0, (hipStream_t)stream, Bm, bx, K, N, Npad, nullptr, 0);
   }
   return check_launch("weight_split");
+}
+
+extern "C" int p2m_conv_weights_prepare(const p2m_conv_weights* dev_desc, int32_t n, int32_t arith, void* stream) {
+  static_assert(sizeof(p2m_conv_weights) == sizeof(ConvWeights), "descriptor layout");
+  P2M_CHECK_ARG(dev_desc != nullptr && n > 0, "null descriptor array or no layers");
+  P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
+  const ConvWeights* d = reinterpret_cast<const ConvWeights*>(dev_desc);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(96, n);                    // grid-stride over each image: the largest (768 x 256) is 768 elements per thread
+  if (arith == P2M_ARITH_F16X2) {
+    hipLaunchKernelGGL(k_conv_weights_amax, dim3(n), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_conv_weights_images<2>, grid, dim3(256), 0, s, d);
+  } else {
+    hipLaunchKernelGGL(k_conv_weights_images<3>, grid, dim3(256), 0, s, d);
+  }
+  return check_launch("conv_weights_prepare");
 }
 
 extern "C" int p2m_amax(const float* x, int64_t n, void* word, void* stream) {

@@ -106,6 +106,9 @@ static inline RowSet row_set_of(const Graph& g, int which) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+#ifdef __HIPCC__
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+#endif
 
 #ifdef __HIPCC__
 // amax words (include/p2m.h, P2M_ARITH_F16X2): max |v| over a wave -> one atomic max on the word (the bits of non-negative

@@ -193,6 +193,10 @@ class _MeshNetFn(torch.autograd.Function):
         training = net.training
         wc = net._weight_cache
         ops.amax_begin_step(x.device)
+        # every slice image of the split convs' weights in two launches (ops.ConvWeightSet), refreshed when they changed
+        cws = net._conv_weight_set(graphs, params, x.device)
+        if cws is not None:
+            cws.refresh()
         J, cin = net.num_joint, net.num_joint_input_chan
         if training:
             ops.bump_weight_epoch()       # running statistics change behind torch's back: cached eval coefficients are stale
@@ -231,18 +235,23 @@ class _MeshNetFn(torch.autograd.Function):
                 continue
             need_stats = L.has_bn and training
             bwd_fwdform = _bwd_forward_form(L)
-            # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache)
-            want_w3 = bwd_fwdform
-            Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
-                                                                           need_w3=want_w3))
             split = g.split and bwd_fwdform
+            batched = split and cws is not None and L.ci in cws.images
+            # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache); the split
+            # convs of the slice arithmetics read nothing but the images of `cws`: W stands in for the fp32 operands
+            want_w3 = bwd_fwdform
+            if batched:
+                Wt, W2, W3 = W, None, W
+            else:
+                Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
+                                                                               need_w3=want_w3))
             if split:
                 # real / fake vertex launches: fake vertices are isolated, T1 = a x and T2 = b x, so they take a
                 # K = Fin contraction with W0 + a W1 + b W2 and no basis planes at all
                 y = torch.empty((M, L.Fout), device=cur.device, dtype=torch.float32)
-                opf = wc.get((L.ci, "split_fwd"), W,
-                             lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b,
-                                                        wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
+                opf = cws.fwd(L.ci, W) if batched else wc.get(
+                    (L.ci, "split_fwd"), W, lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b,
+                                                                      wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
                                                         g.fake_b, need_stats, operands=opf, want_planes=False)
                 tile_rows = ("tiles", cur_shift) if tiled else "rows"
@@ -302,7 +311,7 @@ class _MeshNetFn(torch.autograd.Function):
                 elif L.block < nblk - 2:                              # virtual x2 un-pool (:111)
                     cur_shift = 1
         V0 = graphs[0].V
-        ctx.net, ctx.saved, ctx.fc_saved, ctx.B, ctx.training = net, saved, fc_saved, B, training
+        ctx.net, ctx.saved, ctx.fc_saved, ctx.B, ctx.training, ctx.cws = net, saved, fc_saved, B, training, cws
         ctx.n_params = len(params)
         ctx.param_shapes = [p.shape for p in params]
         return cur.view(B, V0, net.num_mesh_output_chan)
@@ -323,6 +332,7 @@ class _MeshNetFn(torch.autograd.Function):
             raise P2MError("backward called but the forward ran without gradient tracking (or twice)")
         graphs = net._graph_cache.on(grad_out.device)
         wc = net._weight_cache
+        cws = ctx.cws
         P = net._param_index
         params = ctx.saved_params
         grads = [None] * ctx.n_params
@@ -474,9 +484,9 @@ class _MeshNetFn(torch.autograd.Function):
                 dX = (torch.zeros if coarse_full else torch.empty)((Mc, L.Fin), device=gy.device, dtype=torch.float32)
                 add = (Gs_block if Gs_block is not None else ops.pair_sum(G, Mc, Fblk, classes=gph)) if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
-                opb = wc.get((L.ci, "split_bwd"), Wl,
-                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
-                                                        wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
+                opb = cws.bwd(L.ci, Wl) if (cws is not None and L.ci in cws.images) else wc.get(
+                    (L.ci, "split_bwd"), Wl, lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
+                                                                      wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 P0, E1, E2 = ops.conv_pair(gph, B, gy, L.Fout, W2, add, dX, L.Fin, opb, P0=P0)
                 ga = ops.amax_of(gy, gph, B)       # bounds S g (x 2) and the paired planes (x 2^(plane_bits + 1))
                 with side_ctx(keep, X, P0, E1, E2):
@@ -497,9 +507,9 @@ class _MeshNetFn(torch.autograd.Function):
                 dXf = torch.empty((M, L.Fin), device=gy.device, dtype=torch.float32)
                 add = G if fuse_res else None
                 Wl = params[P[f"cl.{L.ci}.weight"]]
-                opb = wc.get((L.ci, "split_bwd"), Wl,
-                             lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
-                                                        wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
+                opb = cws.bwd(L.ci, Wl) if (cws is not None and L.ci in cws.images) else wc.get(
+                    (L.ci, "split_bwd"), Wl, lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
+                                                                      wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 E1, E2, _, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
                                                  gph.fake_b, operands=opb)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
@@ -630,6 +640,7 @@ class Pose2Mesh(nn.Module):
         self._class_rep = {}
         self._graph_cache = ops.GraphCache(graph_L, class_plan=self._class_plan)
         self._weight_cache = ops.WeightCache()
+        self._conv_weight_sets = {}
         self._direct_grad = False
         self._grad_sink = None
         self._infer_real_only = False
@@ -676,6 +687,27 @@ class Pose2Mesh(nn.Module):
         for gi, depth in plan.items():
             self._class_rep[gi] = ops.class_representatives(graphs[gi].V, np.where(masks[chain.index(gi)])[0], depth)[0]
         return plan
+
+    def _conv_weight_set(self, graphs, params, device):
+        """ops.ConvWeightSet over the split convs (slice arithmetics only), one per (device, arithmetic)."""
+        if ops.GEMM_ARITH == "f32":
+            return None
+        key = (torch.device(device).index, ops.GEMM_ARITH)
+        cws = self._conv_weight_sets.get(key)
+        if cws is None:
+            P = self._param_index
+            ent = [(L.ci, params[P[f"cl.{L.ci}.weight"]], graphs[L.graph].fake_a, graphs[L.graph].fake_b)
+                   for L in self._layers if graphs[L.graph].split and _bwd_forward_form(L) and not _narrow(L)]
+            cws = ops.ConvWeightSet(ent, device) if ent else False
+            self._conv_weight_sets[key] = cws
+        if cws is False:
+            return None
+        # the same parameter objects as when the set was built? (replicas, re-created parameters)
+        P = self._param_index
+        if any(w is not params[P[f"cl.{k}.weight"]] for k, w in zip(cws.keys, cws.weights)):
+            cws.weights = [params[P[f"cl.{k}.weight"]] for k in cws.keys]
+            cws.tag = None
+        return cws
 
     def _param_list(self):
         names, params = ["fc.weight", "fc.bias"], [self.fc.weight, self.fc.bias]

@@ -531,6 +531,70 @@ def side_stream(device, which=0):
     return st
 
 
+class _ConvWeightsDesc(ctypes.Structure):       # == p2m_conv_weights (include/p2m.h)
+    _fields_ = [("W", _vp), ("Fout", ctypes.c_int32), ("Fin", ctypes.c_int32), ("fake_a", ctypes.c_float),
+                ("fake_b", ctypes.c_float), ("eff_bits", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("Bx_f", _vp), ("Bx_ef", _vp), ("Bx_b", _vp), ("Bx_eb", _vp), ("amax", _vp)]
+
+
+class ConvWeightSet:
+    """The four slice images (forward / backward, real / padding rows) of EVERY split conv of a network, refreshed by
+    p2m_conv_weights_prepare in two launches per optimizer step instead of eight per layer (include/p2m.h).  Buffers and the
+    device-side descriptor array are allocated once per device; `refresh` re-uploads the descriptors only when a weight
+    moved.  entries: list of (key, weight tensor, fake_a, fake_b)."""
+
+    def __init__(self, entries, device):
+        self.device = torch.device(device)
+        self.keys = [k for k, _, _, _ in entries]
+        self.weights = [w for _, w, _, _ in entries]
+        self.coef = [(float(a), float(b)) for _, _, a, b in entries]
+        lib = _lib.hip()
+        code = arith_code()
+        self.arith = code
+        self.images = {}
+        for k, w in zip(self.keys, self.weights):
+            Fout, Fin = w.shape[0], w.shape[1] // 3
+            shapes = ((3 * Fin, Fout), (Fin, Fout), (3 * Fout, Fin), (Fout, Fin))
+            self.images[k] = tuple(torch.zeros((int(lib.p2m_weight_split_elems(K, N, code)),), device=self.device,
+                                               dtype=torch.int16) for K, N in shapes)
+        self.words = torch.zeros((len(entries),), device=self.device, dtype=torch.int32)
+        self.desc = None
+        self._ptrs = None
+        self.tag = None
+
+    def _upload(self):
+        arr = (_ConvWeightsDesc * len(self.keys))()
+        for i, (k, w, (a, b)) in enumerate(zip(self.keys, self.weights, self.coef)):
+            f, ef, bw, eb = self.images[k]
+            arr[i] = _ConvWeightsDesc(_req(w, "weight").data_ptr(), w.shape[0], w.shape[1] // 3, a, b, eff_bits(a, b), 0,
+                                      f.data_ptr(), ef.data_ptr(), bw.data_ptr(), eb.data_ptr(),
+                                      self.words[i:i + 1].data_ptr())
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.desc = host.to(self.device)
+        self._ptrs = [w.data_ptr() for w in self.weights]
+
+    def refresh(self):
+        """Recompute every image from the current weights (no-op when they have not changed since the last call)."""
+        tag = tuple((w.data_ptr(), w._version) for w in self.weights) + (WEIGHT_EPOCH,)
+        if tag == self.tag:
+            return
+        if self.desc is None or self._ptrs != [w.data_ptr() for w in self.weights]:
+            self._upload()
+        check(_lib.hip().p2m_conv_weights_prepare(_p(self.desc), len(self.keys), self.arith, _stream()),
+              "p2m_conv_weights_prepare")
+        self.tag = tag
+
+    def fwd(self, key, dummy):
+        """(Bx, We, Wex) as split_operands returns them; `dummy`: any fp32 tensor standing in for the fp32 operands the
+        slice kernels never read."""
+        f, ef, _, _ = self.images[key]
+        return f, dummy, ef
+
+    def bwd(self, key, dummy):
+        _, _, b, eb = self.images[key]
+        return b, dummy, eb
+
+
 def split_operands(Bm, Ka, N, fake_a, fake_b, amax=None):
     """Derived operands of one split contraction: (Bx, We, Wex) = pre-split Bm, the fake-vertex effective weight
     W0 + a*W1 + b*W2 and its pre-split copy.  amax: the amax word of the parameter Bm is a permutation of (f16x2)."""
