@@ -151,7 +151,7 @@ __device__ __forceinline__ float lerp_feat(const float* __restrict__ row, int Fr
 
 // One float4 column group per thread, ACT_UNROLL rows per thread with all loads issued before the arithmetic (a
 // single 16-byte load per thread leaves the memory pipe half empty: 3.3 TB/s -> see DESIGN.md).  Needs 256 % (F/4) == 0.
-constexpr int ACT_UNROLL = 4;
+constexpr int ACT_UNROLL = 4;     // (stand-alone 5.0 - 5.3 TB/s; 8 x 2, 8 x 4, 4 x 8, 2 x 8 measure the same)
 constexpr int ACT_PASSES = 4;     // passes of ACT_UNROLL row groups per block: one amax commit (a wave reduction + a load of
                                   // the word) per 16 rows of a thread instead of per 4
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const float* __restrict__ y, const float* __restrict__ scale,
