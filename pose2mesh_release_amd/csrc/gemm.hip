@@ -955,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       pitch = g.Ka;
       shift = (ap == 0) ? g.a0_shift : 0;
       compact_rows = false;
-      dst = As + (c4 * 4) * LDX + rq * 4;
+      dst = As + (c4 >> 2) * 16 * LDX + (c4 & 3) * 2 * LDX + rq * 4;
       slice_stride = BM * LDX;
     } else {
       int n = n0 + c4 * 4;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       pitch = g.Gc;
       shift = 0;
       compact_rows = ROWS && gq != 0 && g.compact;
-      dst = Gs + (c4 * 4) * LDX + rq * 4;
+      dst = Gs + (c4 >> 2) * 16 * LDX + (c4 & 3) * 2 * LDX + rq * 4;
       slice_stride = BN * LDX;
     }
   }
@@ -1026,15 +1026,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     for (int e = 0; e < 4; e++) {
       u32x2 sl[NS];
       split_pack4<NS>(x[0][e], x[1][e], x[2][e], x[3][e], my_sc, sl);
+      // LDS rows are PERMUTED inside every block of 16: column 4 c + e of the block lives in row 2 c + (e & 1) + 8 (e >> 1).
+      // The 16 lanes of a ds_write_b64 group are 4 column quads x 4 row quads: with the natural order their rows are 4
+      // apart = 48 dwords = 16 banks, i.e. 2-way conflicts on every store (PMC: 33 % of the kernel's LDS cycles); rows
+      // 2 apart are 24 dwords: four distinct 8-dword windows.  The MFMA waves read a block's 16 rows as a set either way.
 #pragma unroll
-      for (int q = 0; q < NS; q++) *reinterpret_cast<u32x2*>(d + e * LDX + q * slice_stride) = sl[q];
+      for (int q = 0; q < NS; q++)
+        *reinterpret_cast<u32x2*>(d + ((e & 1) + 8 * (e >> 1)) * LDX + q * slice_stride) = sl[q];
     }
   };
   using std::false_type;
   using std::true_type;
   auto compute = [&](int cur) {
-    const unsigned short* as = As + cur * A_BUF + (wm * 64 + l31) * LDX + lhi * 8;
-    const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + l31) * LDX + lhi * 8;
+    // (row permutation of the staging stores: logical row j of a 16-block -> 2 (j >> 2) + (j & 1) + 8 ((j & 3) >> 1))
+    const int lrow = (l31 & 16) + 2 * ((l31 & 15) >> 2) + (l31 & 1) + 8 * ((l31 & 3) >> 1);
+    const unsigned short* as = As + cur * A_BUF + (wm * 64 + lrow) * LDX + lhi * 8;
+    const unsigned short* gs = Gs + cur * G_BUF + (wn * WTN + lrow) * LDX + lhi * 8;
     frag_t fa[NS][TM], fb[NS][TN];       // [slice, high first][tile]
 #pragma unroll
     for (int sl = 0; sl < NS; sl++) {
