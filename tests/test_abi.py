@@ -93,3 +93,19 @@ def test_slice_arithmetic_host_logic():
             if abs(141 - int((np.float32(u).view(np.uint32) >> 23) & 0xFF) - bits) <= 120:
                 assert 2.0 ** 14 <= u * 2.0 ** bits * 2.0 ** s < 2.0 ** 15, (u, bits, s)
     assert scale_exp(0.0, 2) == 0 and scale_exp(1e-45, 0) == 120
+
+
+def test_conv_weights_descriptor_layout():
+    """ops._ConvWeightsDesc must be byte-for-byte the p2m_conv_weights of include/p2m.h (72 bytes, natural alignment): the
+    descriptor array is built on the host with ctypes and read by the device kernels."""
+    import ctypes
+    from pose2mesh_release_amd import ops as o
+    d = o._ConvWeightsDesc
+    assert ctypes.sizeof(d) == 72
+    offs = {n: getattr(d, n).offset for n, _ in d._fields_}
+    assert offs == {"W": 0, "Fout": 8, "Fin": 12, "fake_a": 16, "fake_b": 20, "eff_bits": 24, "reserved": 28,
+                    "Bx_f": 32, "Bx_ef": 40, "Bx_b": 48, "Bx_eb": 56, "amax": 64}
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "p2m.h")).read()
+    body = hdr[hdr.index("typedef struct p2m_conv_weights {"):hdr.index("} p2m_conv_weights;")]
+    order = [m for m in re.findall(r"\b(W|Fout|Fin|fake_a|fake_b|eff_bits|reserved|Bx_f|Bx_ef|Bx_b|Bx_eb|amax)\b", body)]
+    assert order == [n for n, _ in d._fields_]
