@@ -102,6 +102,8 @@ class TrainStep:
 
     def __call__(self):
         m = self.model
+        if self.reducer is not None:
+            self.reducer.mark_step_start()          # (no-op unless the reducer's timing is switched on)
         self.opt.zero_grad()
         pred_mesh, lift_pose = m(self.pose2d)
         if not self.stock_losses:
@@ -282,6 +284,42 @@ def _traffic_for(*kernel_prefixes):
     return {"hbm_bytes_per_launch": tot / n, "launches": n}, t.get("source")
 
 
+def timed_run(step, warmup, steps, barrier):
+    """`warmup` untimed steps, then EXACTLY `steps` steps between two barrier + synchronize pairs -> (wall seconds,
+    per-step milliseconds).  The timed region is clean: no per-launch events in it, only one HIP event per STEP on the
+    main stream (recorded, never waited on inside the region) from which the per-step median / spread are read."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        step()
+        ev[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def step_stats(per_step_ms):
+    a = np.sort(np.asarray(per_step_ms, dtype=np.float64))
+    return {"median": round(float(np.median(a)), 3), "min": round(float(a[0]), 3), "max": round(float(a[-1]), 3),
+            "p10": round(float(np.percentile(a, 10)), 3), "p90": round(float(np.percentile(a, 90)), 3),
+            "note": "per-step time between HIP events recorded on the main stream after every step of the timed region "
+                    "(GPU-side; `value` and `ms_per_step` are wall-clock over the whole region, as the contract asks)"}
+
+
+DTYPE_NOTE = {
+    "f16x2": "f32 (emulated on the FP16 matrix pipe: every operand as 2 scaled fp16 slices = 22-bit significands, 3 slice "
+             "products per fp32 product, fp32 accumulate; activations, weights, gradients and optimizer state are stored "
+             "in fp32)",
+    "bf16x3": "f32 (emulated on the BF16 matrix pipe: every operand as 3 exact bf16 slices = 24-bit significands, 6 slice "
+              "products per fp32 product, fp32 accumulate)",
+    "f32": "f32 (native v_mfma_f32_32x32x2_f32)",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,16 +339,31 @@ def main():
     ap.add_argument("--infer-path", default="graph", choices=["graph", "eager", "general"],
                     help="--mode infer: captured hipGraph of the real-only path (default), the same launch by launch, "
                          "or the general drop-in module + epilogue kernel")
+    ap.add_argument("--also", default=None,
+                    help="comma list of extra legs measured after the main one and reported under `also` (1 GPU, default "
+                         "train run only): infer = BASELINE configs[1] (batch 64, J=17, eval forward + Tester epilogue, "
+                         "captured hipGraph), mano = configs[4] (MANO-like, batch 512, train step).  Default: infer,mano; "
+                         "`none` switches them off")
+    ap.add_argument("--no-arith-ab", action="store_true",
+                    help="skip the same-process A/B of the other contraction arithmetics (`arith_ab`)")
     args = ap.parse_args()
     infer = args.mode == "infer"
+    default_run = (not infer and args.batch is None and args.joint_set is None and not args.train_graph
+                   and not args.stock_losses and args.optimizer == "adam")
     if args.batch is None:
         args.batch = 64 if infer else 256
     if args.joint_set is None:
         args.joint_set = "human36" if infer else "coco"
+    # >= 20 warm-up, >= 50 timed iterations, median (the line carries total-time throughput as `value`, as the
+    # driver's contract asks, and the per-step median / spread from HIP events beside it)
     if args.steps is None:
-        args.steps = 50 if infer else 10
+        args.steps = 100 if infer else 50
     if args.warmup is None:
-        args.warmup = 10 if infer else 3
+        args.warmup = 20
+    also = [] if args.also in ("none", "") else (args.also.split(",") if args.also else (["infer", "mano"] if default_run else []))
+    for a in also:
+        if a not in ("infer", "mano"):
+            ap.error(f"--also: unknown leg {a!r} (infer, mano, none)")
 
     rank, world, local = p2m_dist.init_from_env()
     if world != args.gpus:
@@ -337,28 +390,23 @@ def main():
         step = p2m_train.GraphedTrainStep(eager_step.model, eager_step.opt, eager_step.loss_fn, warmup=2)
         args.warmup = max(args.warmup, 4)              # 2 eager steps, the capture, one replay before the clock starts
         graphed = True
-    for _ in range(args.warmup):
-        step()
-    # the timed region is CLEAN: no per-launch HIP events in it (round 2 had the timer on inside; it cost ~1 %)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    if world > 1:
+        seen = p2m_dist.ranks_seen(device)            # every rank sees every rank over the job's backend (RCCL)
+    dt, per_step_ms = timed_run(step, args.warmup, args.steps, barrier)
+    ksteps = min(args.steps, 10)          # steps of the per-kernel timing pass (untimed; ~1 200 HIP events per step)
     if not args.no_kernel_timing:
         # per-kernel rooflines: the SAME steps once more, launch by launch, every launch bracketed by HIP events on its
         # stream (a replayed graph cannot be bracketed node by node, so the graphed paths re-issue their launches eagerly)
         ops.TIMER = ops.KernelTimer()
         if train_graph:
-            for _ in range(args.steps):
+            for _ in range(ksteps):
                 eager_step()
         elif graphed:
             with torch.no_grad():
-                for _ in range(args.steps):
+                for _ in range(ksteps):
                     step.step._eager()
         else:
-            for _ in range(args.steps):
+            for _ in range(ksteps):
                 step()
         torch.cuda.synchronize()
     timer_serial = None
@@ -380,6 +428,73 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     timer, ops.TIMER = ops.TIMER, None
+
+    # ---- multi-GPU diagnostics (untimed, after the timed region): two more steps with HIP events around every collective
+    multi = None
+    if world > 1 and not infer and eager_step.reducer is not None:
+        red = eager_step.reducer
+        red.timing = True
+        for _ in range(2):
+            eager_step()
+        rep = red.timing_report()
+        red.timing = False
+        mine = {"rank": rank, "device": local, "n_buckets": len(red.buckets), **(rep or {})}
+        allrep = [None] * world
+        torch.distributed.all_gather_object(allrep, mine)
+        multi = {"ranks_seen": seen, "bucket_MiB": 64, "per_rank": allrep,
+                 "note": "one extra, untimed step with HIP events on the communication stream around every all-reduce and on "
+                         "the main stream around finish(): times in ms since the start of the step; exposed_ms = what the "
+                         "main stream waited for collectives after its own backward work; hidden_frac = 1 - exposed / sum "
+                         "of the collectives' durations"}
+
+    # ---- same-process A/B of the contraction arithmetics (1 GPU, train): a fresh TrainStep per arithmetic, few steps
+    arith_ab = None
+    if world == 1 and not infer and not args.no_arith_ab and not train_graph:
+        arith_ab = {}
+        main_arith = ops.GEMM_ARITH
+        for ar in ("bf16x3", "f32"):
+            if ar == main_arith:
+                continue
+            ops.GEMM_ARITH = ar
+            ops.bump_weight_epoch()
+            try:
+                st2 = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss,
+                                stock_losses=args.stock_losses, optimizer=args.optimizer)
+                d2, ps2 = timed_run(st2, 3, 10, barrier)
+                arith_ab[ar] = {"value": round(args.batch * 10 / d2, 2), "unit": "meshes/s", "steps": 10, "warmup": 3,
+                                "ms_per_step_median": step_stats(ps2)["median"], "dtype": DTYPE_NOTE[ar]}
+                del st2
+            finally:
+                ops.GEMM_ARITH = main_arith
+                ops.bump_weight_epoch()
+            torch.cuda.empty_cache()
+
+    # ---- the other single-GPU configurations of BASELINE.json, measured by the same command (`--also`)
+    also_out = {}
+    if world == 1 and also:
+        for leg in also:
+            if leg == "infer":
+                st3 = InferStep(device, 64, "human36", path="graph")
+                d3, ps3 = timed_run(st3, 20, 100, barrier)
+                also_out["configs[1]_infer"] = {
+                    "metric": "SMPL meshes/sec fwd at batch 64", "value": round(64 * 100 / d3, 2), "unit": "meshes/s",
+                    "steps": 100, "warmup": 20, "ms_per_step": round(1000 * d3 / 100, 3),
+                    "ms_per_step_stats": step_stats(ps3),
+                    "workload": f"configs[1]: batch=64 synthetic human36 2D poses (J={st3.J}), SMPL-like hull mesh {st3.nv} "
+                                f"verts (padded {st3.V0}), FlatPose2Mesh eval forward + Tester epilogue, captured hipGraph of "
+                                f"the real-vertices-only inference path (python bench.py --mode infer)"}
+            else:
+                st3 = TrainStep(device, 512, "mano", 1, edge_loss=not args.no_edge_loss)
+                d3, ps3 = timed_run(st3, 5, 20, barrier)
+                also_out["configs[4]_mano"] = {
+                    "metric": "MANO meshes/sec fwd+bwd", "value": round(512 * 20 / d3, 2), "unit": "meshes/s",
+                    "steps": 20, "warmup": 5, "ms_per_step": round(1000 * d3 / 20, 3),
+                    "ms_per_step_stats": step_stats(ps3),
+                    "workload": f"configs[4]: batch=512 synthetic mano 2D poses (J={st3.J}), MANO-like hull mesh {st3.nv} "
+                                f"verts (padded {st3.V0}), FlatPose2Mesh fwd + 5 reference losses + bwd + Adam "
+                                f"(python bench.py --joint-set mano --batch 512)"}
+            del st3
+            torch.cuda.empty_cache()
     if train_graph:
         step = eager_step                    # the attributes the report reads live on the TrainStep
 
@@ -406,7 +521,8 @@ def main():
             "metric": metric,
             "value": round(total / dt, 2), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_stats": step_stats(per_step_ms),
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[ops.GEMM_ARITH], "data": "synthetic",
             "config": {"workload": workload,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "gemm_arith": {"bf16x3": "fp32 contraction as 3 exact bf16 slices x 6 products on the BF16 MFMA pipe, "
@@ -477,7 +593,7 @@ def main():
                      "hbm": {"achieved_GBps": round(gbs, 1), "peak": PEAK_HBM_GBPS, "frac": round(f_h, 4),
                              "frac_of_copy_ceiling_6300": round(gbs / 6300.0, 4)},
                      "launches": rec["launches"], "avg_launch_ms": round(rec["ms"] / rec["launches"], 4),
-                     "ms_per_step": round(rec["ms"] / args.steps, 3),
+                     "ms_per_step": round(rec["ms"] / ksteps, 3),
                      "note": "achieved = algorithmic work / HIP-event time over ALL launches of the family in the timed "
                              "steps (backward launches share the GPU with the side-stream weight gradient); matrix-pipe peak "
                              "in algorithmic fp32 FLOPs = 2500 / slice products (or the f32 MFMA's 157.3); algorithmic "
@@ -559,7 +675,21 @@ def main():
                         "achieved": round(movf, 1), "frac": round(movf / PEAK_HBM_GBPS, 4),
                         "frac_of_copy_ceiling_6300": round(movf / 6300.0, 4),
                         "launches": f["launches"], "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
-            line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in summ.items()}
+            line["kernel_ms_per_step"] = {k: round(v["ms"] / ksteps, 3) for k, v in summ.items()}
+        if arith_ab is not None:
+            arith_ab[ops.GEMM_ARITH] = {"value": line["value"], "unit": "meshes/s", "steps": args.steps,
+                                        "warmup": args.warmup, "ms_per_step_median": line["ms_per_step_stats"]["median"],
+                                        "dtype": DTYPE_NOTE[ops.GEMM_ARITH], "note": "the main measurement of this line"}
+            line["arith_ab"] = dict(arith_ab, note="same process, same box, same synthetic batch: a fresh TrainStep per "
+                                                    "contraction arithmetic (P2M_GEMM_ARITH), 3 warm-up + 10 timed steps "
+                                                    "for the two that are not the default; bf16x3 is the exact-fp32 "
+                                                    "emulation (24-bit operands), f32 the native f32 MFMA (which also "
+                                                    "switches the tile kernels off: they exist in the slice arithmetics "
+                                                    "only)")
+        if also_out:
+            line["also"] = also_out
+        if multi is not None:
+            line["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.joint_set, args.cpu_seconds, edge_loss=not args.no_edge_loss,
                                                 batch=64 if infer else 32, mode=args.mode)

@@ -55,6 +55,7 @@ class _ChebConvFn(torch.autograd.Function):
             raise P2MError(f"x has {V} vertices but the graph has {g.V}")
         M = B * V
         with torch.cuda.device(x.device):
+            ops.amax_begin_step(x.device)      # fresh amax words per call (a captured graph must re-zero its own)
             xc = x.contiguous().float().view(M, Fin)
             T1, T2 = ops.cheb_basis_fwd(g, xc, B, Fin, 0)
             Wt, W2, _ = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)

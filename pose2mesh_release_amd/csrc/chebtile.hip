@@ -35,6 +35,8 @@
 // latencies) for N <= 128, 4 + 4 for N = 256 (the 128-register accumulator needs the 256-register budget).
 #include "p2m_split.h"
 
+#include <mutex>
+
 namespace p2m {
 
 constexpr int CT_S = 4;                       // samples per group (M tile = 4 x 32 rows)
@@ -865,6 +867,31 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
 
 using namespace p2m;
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute of a kernel: under nn.DataParallel (one host
+// thread per GPU, lib/core/base.py:108) every device needs its own call, and two threads may get here at once.  One of
+// these per kernel instantiation: a mutex-guarded bitmap over the devices of the process.
+struct DeviceOnce {
+  std::mutex mu;
+  uint64_t done[4] = {0, 0, 0, 0};       // 256 devices
+  template <class F>
+  int run(F&& set_attr, const char* what, int lds_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+      set_error("%s: cannot identify the current device", what);
+      return P2M_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev >> 6] >> (dev & 63) & 1) return P2M_OK;
+    const hipError_t e = set_attr();
+    if (e != hipSuccess) {
+      set_error("%s: cannot reserve %d bytes of LDS on device %d: %s", what, lds_bytes, dev, hipGetErrorString(e));
+      return P2M_ERR_HIP;
+    }
+    done[dev >> 6] |= uint64_t(1) << (dev & 63);
+    return P2M_OK;
+  }
+};
+
 // gpb: sample groups a block walks (tables loaded once per block).  At least ~8 blocks per CU so that the last round of
 // blocks is well filled (measured over the 16 real-row shapes of a train step: gpb 16 / 8 / 4 / 2 -> 21.4 / 19.0 / 18.4 /
 // 18.0 ms; the finest level alone prefers 8 by 2 %).
@@ -877,17 +904,13 @@ static int pick_gpb(int ntiles, int ngroups) {
 template <int TM, int TN, int NPW, int MODE, int NS>
 static int launch_tile_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
   constexpr int LDS_BYTES = ct_lds_bytes(NS);
-  static bool attr_set = false;     // once per process and instantiation (never inside a stream capture: the first call
+  static DeviceOnce attr_set;       // once per DEVICE and instantiation (never inside a stream capture: the first call
                                     // of every shape happens in the eager warm-up steps)
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e));
-      return P2M_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  if (const int rc = attr_set.run([] {
+        return hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      }, "p2m_cheb_tile_gemm", LDS_BYTES))
+    return rc;
   const int ngroups = cdiv(a.B, CT_S);
   const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
   hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>), dim3(nblocks), dim3(256 + 64 * NPW), LDS_BYTES, s, a);
@@ -903,16 +926,12 @@ static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
 }
 template <int TM, int TN, int NPW, int MODE>
 static int launch_mg_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute((const void*)k_cheb_mg_gemm<TM, TN, NPW, MODE>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("p2m_cheb_tile_gemm: cannot reserve %d bytes of LDS: %s", MG_LDS_BYTES, hipGetErrorString(e));
-      return P2M_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static DeviceOnce attr_set;
+  if (const int rc = attr_set.run([] {
+        return hipFuncSetAttribute((const void*)k_cheb_mg_gemm<TM, TN, NPW, MODE>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
+      }, "p2m_cheb_tile_gemm(matrix gather)", MG_LDS_BYTES))
+    return rc;
   const int ngroups = cdiv(a.B, CT_S);
   const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
   hipLaunchKernelGGL((k_cheb_mg_gemm<TM, TN, NPW, MODE>), dim3(nblocks), dim3(256 + 64 * NPW), MG_LDS_BYTES, s, a);

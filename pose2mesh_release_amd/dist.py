@@ -36,6 +36,31 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def ranks_seen(device=None):
+    """Diagnostics for the first multi-GPU run: every rank contributes (rank, local device index) through an all-gather on
+    the job's backend - RCCL when it is "nccl" - and gets the full list back.  A communicator that silently spans fewer
+    ranks, or two ranks on one GPU, shows up here."""
+    if not dist.is_initialized():
+        return {"backend": None, "world": 1, "ranks": [0]}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    if device is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
+    local = device.index if (device is not None and torch.device(device).type == "cuda") else -1
+    # the exchange itself runs where the backend can run it: RCCL on the GPU, gloo on the host
+    mine = torch.tensor([rank, local], dtype=torch.int64, device=device if backend == "nccl" else torch.device("cpu"))
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    info = {"backend": backend, "world": world, "ranks": [int(t[0]) for t in out],
+            "local_devices": [int(t[1]) for t in out]}
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["rccl_version"] = None
+    return info
+
+
 class BucketedAllReduce:
     """Sum-all-reduce of a flat gradient buffer in buckets, overlapped with backward.
 
@@ -72,6 +97,13 @@ class BucketedAllReduce:
         self._comm = None
         self.launch_log = []       # per step: (bucket, gradients reported so far when it was launched) - for the tests
         self._seen = 0
+        # optional timing (bench.py --gpus N, tests): HIP events around every collective on the communication stream and
+        # around finish()'s wait on the main stream -> timing_report().  Off by default: with it on, the communication
+        # stream waits for each collective (one more stream dependency per bucket, no host synchronisation).
+        self.timing = False
+        self._t_ref = self._t_bwd_end = self._t_done = None
+        self._t_buckets = []
+        self._report = None
         if self.active:
             for i, p in enumerate(params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -81,6 +113,7 @@ class BucketedAllReduce:
         self._pending = [len(idx) for (_, _, idx) in self.buckets]
         self._handles = []
         self._seen = 0
+        self.last_launch_log, self.launch_log = getattr(self, "launch_log", []), []   # one step's entries, never more
         self._streams = [set() for _ in self.buckets]      # streams that carry gradient-writing kernels of each bucket
         self._done = set()
 
@@ -134,8 +167,41 @@ class BucketedAllReduce:
         for st in self._streams[b] | {cur}:
             self._comm.wait_stream(st)
         with torch.cuda.stream(self._comm):
-            self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                 async_op=True))
+            if self.timing:
+                ev_s, ev_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev_s.record(self._comm)
+            h = dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append(h)
+            if self.timing:
+                h.wait()           # stream wait: the communication stream (not the host) waits for the collective
+                ev_e.record(self._comm)
+                self._t_buckets.append((b, (e - s) * 4, self._seen, ev_s, ev_e))
+
+    def mark_step_start(self):
+        """timing: the reference point of timing_report() - call at the start of the step, on the main stream."""
+        if self.timing and self.flat_grad.is_cuda:
+            self._t_ref = torch.cuda.Event(enable_timing=True)
+            self._t_ref.record(torch.cuda.current_stream(self.flat_grad.device))
+            self._t_buckets = []
+
+    def timing_report(self):
+        """After a step with `timing` on (and mark_step_start() at its start): synchronises the device and returns
+        {buckets: [{bucket, bytes, grads_seen_at_launch, start_ms, end_ms}], backward_end_ms, step_end_ms,
+        allreduce_ms_total, exposed_ms, hidden_frac}: times relative to mark_step_start(); exposed = what the main stream
+        waited for collectives after its own backward work was done; hidden_frac = 1 - exposed / total."""
+        rep = self._report
+        if rep is None or rep["ref"] is None:
+            return None
+        torch.cuda.synchronize(self.flat_grad.device)
+        ref = rep["ref"]
+        bl = [{"bucket": b, "bytes": nb, "grads_seen_at_launch": seen, "start_ms": round(ref.elapsed_time(es), 4),
+               "end_ms": round(ref.elapsed_time(ee), 4)} for b, nb, seen, es, ee in rep["buckets"]]
+        total = sum(x["end_ms"] - x["start_ms"] for x in bl)
+        bwd_end, done = ref.elapsed_time(rep["bwd_end"]), ref.elapsed_time(rep["done"])
+        exposed = max(0.0, done - bwd_end)
+        return {"buckets": bl, "backward_end_ms": round(bwd_end, 4), "step_end_ms": round(done, 4),
+                "allreduce_ms_total": round(total, 4), "exposed_ms": round(exposed, 4),
+                "hidden_frac": round(max(0.0, 1.0 - exposed / total), 4) if total > 0 else None}
 
     def finish(self):
         """Call after backward: launches buckets whose hooks never fired (unused parameters),
@@ -145,9 +211,20 @@ class BucketedAllReduce:
                 if left > 0:
                     self._pending[b] = 0
                     self._launch(b)
+            timed = self.timing and self.flat_grad.is_cuda
+            if timed:
+                cur = torch.cuda.current_stream(self.flat_grad.device)
+                self._t_bwd_end = torch.cuda.Event(enable_timing=True)
+                self._t_bwd_end.record(cur)           # the main stream's own backward work ends here
             for h in self._handles:
                 h.wait()           # nccl (RCCL): the CURRENT stream waits for the collective's stream; gloo: blocks the host
             if self._comm is not None:
                 torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm)
+            if timed:
+                self._t_done = torch.cuda.Event(enable_timing=True)
+                self._t_done.record(cur)
+                self._report = {"ref": self._t_ref, "bwd_end": self._t_bwd_end, "done": self._t_done,
+                                "buckets": list(self._t_buckets)}
+                self._t_buckets = []
         self.reset()
         return 1.0 / self.world

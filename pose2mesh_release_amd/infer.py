@@ -43,13 +43,33 @@ class GraphedInference:
         self.captures = 0
         self._capture()
 
+    # the full walk over every parameter / buffer version costs ~0.2 ms of host time per call - as much as a tenth of a
+    # batch-64 replay.  ops.WEIGHT_EPOCH (bumped by the flat optimizers, by every train-mode forward and by
+    # GraphedTrainStep) is compared on EVERY call; the walk - which catches plain torch optimizers, load_state_dict
+    # and in-place edits, none of which touch the epoch - runs on the first call after a capture and then every
+    # FULL_CHECK_EVERY calls.
+    FULL_CHECK_EVERY = 16
+
     def _weights_tag(self):
-        return (_ops.WEIGHT_EPOCH,) + tuple((t.data_ptr(), t._version)
-                                           for t in list(self.model.parameters()) + list(self.model.buffers()))
+        return (_ops.WEIGHT_EPOCH,) + tuple((t.data_ptr(), t._version) for t in self._tensors)
+
+    def _weights_moved(self):
+        if _ops.WEIGHT_EPOCH != self._tag[0]:
+            return True
+        self._calls += 1
+        if self._calls == 1 or self._calls % self.FULL_CHECK_EVERY == 0:
+            return self._weights_tag() != self._tag
+        return False
 
     def _capture(self):
+        if self.model.training:
+            # a capture in train() would bake batch statistics into the graph and let every replay move the running
+            # statistics; the instance owns the module's mode (see the class docstring), so put it back
+            self.model.eval()
         with torch.cuda.device(self.device), torch.no_grad():
             self.graph = None
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+            self._calls = 0
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # warm-up: graph handles, weight packs, allocator pools
@@ -86,8 +106,9 @@ class GraphedInference:
     @torch.no_grad()
     def __call__(self, pose2d):
         self.pose2d.copy_(pose2d.reshape(self.pose2d.shape), non_blocking=True)
-        if self.graph is not None and self._weights_tag() != self._tag:
+        if self.graph is not None and (self.model.training or self._weights_moved()):
             self._capture()                            # the weights moved since the capture: its operands are stale
+                                                       # (or someone left the module in train(): re-capture in eval())
         if self.graph is not None:
             self.graph.replay()
             return self.mesh, self.joints, self.pose3d

@@ -345,51 +345,87 @@ def f16x2():
 
 
 def amax_begin_step(device):
+    """Renew the device's chunk of amax words: called at the start of every forward that hands words out (the network's
+    AND the stand-alone ChebConv's)."""
     _amax_chunks.pop(torch.device(device).index, None)
 
 
+def _capturing():
+    try:
+        return bool(torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return False
+
+
 def new_amax(device):
+    """One zeroed amax word.  A chunk belongs to the capture state it was created in: a chunk made before a stream capture
+    is never re-zeroed by the graph's replays (its words would only grow), and one made INSIDE a capture is graph-private
+    memory (zeroed by every replay, uninitialised before the first) - so the chunk is dropped whenever that state flips.
+    A chunk is zeroed on the stream that created it; any other stream that draws a word from it first waits for that."""
     key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    cap = _capturing()
     ent = _amax_chunks.get(key)
-    if ent is None or ent[1] >= ent[0].numel():
-        ent = [torch.zeros(256, dtype=torch.int32, device=device), 0]
+    if ent is None or ent[1] >= ent[0].numel() or ent[2] != cap:
+        with torch.cuda.device(key):
+            buf = torch.zeros(256, dtype=torch.int32, device=torch.device("cuda", key))
+            st = torch.cuda.current_stream()
+            ev = None
+            if not cap:
+                ev = torch.cuda.Event()
+                ev.record(st)
+        ent = [buf, 0, cap, ev, {st.cuda_stream}]
         _amax_chunks[key] = ent
+    elif ent[3] is not None:
+        st = torch.cuda.current_stream(torch.device("cuda", key))
+        if st.cuda_stream not in ent[4]:
+            st.wait_event(ent[3])
+            ent[4].add(st.cuda_stream)
     w = ent[0][ent[1]:ent[1] + 1]
     ent[1] += 1
     return w
 
 
 def tag_amax(t, word):
+    """Attach the amax word of t's CURRENT contents (the producing kernel wrote both).  The tag remembers the tensor's
+    storage and version: a caller that later refills the tensor through torch (in place: the version moves; or rebinds
+    .data: the pointer moves) gets a fresh bound from amax_of instead of the stale word."""
     t._p2m_amax = word
+    t._p2m_amax_of = (t.data_ptr(), t._version)
     return t
+
+
+def _tag_valid(t):
+    return getattr(t, "_p2m_amax", None) is not None and getattr(t, "_p2m_amax_of", None) == (t.data_ptr(), t._version)
 
 
 def view_tagged(t, *shape):
     """t.view(*shape) that keeps t's amax word (a view is a new tensor object)."""
     v = t.view(*shape)
-    w = getattr(t, "_p2m_amax", None)
-    if w is not None:
-        v._p2m_amax = w
+    if _tag_valid(t):
+        tag_amax(v, t._p2m_amax)
     return v
 
 
 def amax_of(t, g=None, B=None, row_set=0):
-    """The amax word of t (None unless GEMM_ARITH is f16x2): the one its producer attached, else computed now - over the
-    rows of `row_set` of level g when given (0: every row that holds data), else over the whole tensor."""
+    """The amax word of t (None unless GEMM_ARITH is f16x2): the one its producer attached - if the tensor has not been
+    modified through torch since -, else computed now - over the rows of `row_set` of level g when given (0: every row that
+    holds data), else over the whole tensor."""
     if not f16x2() or t is None or t.shape[-1] % 4 != 0:    # (widths that are not MFMA shapes take the scalar kernels)
         return None
-    w = getattr(t, "_p2m_amax", None)
-    if w is None:
-        w = new_amax(t.device)
-        if g is not None:
-            F = t.shape[-1]
-            if t.numel() != B * g.V * F:
-                raise P2MError("amax_of: the tensor is not a [B, V, F] tensor of this level (un-pooled operands must come "
-                               "tagged from their producer)")
-            check(_lib.hip().p2m_amax_rows(g.handle, row_set, _p(_req(t, "x")), B, F, _p(w), _stream()), "p2m_amax_rows")
-        else:
-            check(_lib.hip().p2m_amax(_p(_req(t, "x")), t.numel(), _p(w), _stream()), "p2m_amax")
-        t._p2m_amax = w
+    if _tag_valid(t):
+        return t._p2m_amax
+    w = new_amax(t.device)
+    if g is not None:
+        F = t.shape[-1]
+        if t.numel() != B * g.V * F:
+            raise P2MError("amax_of: the tensor is not a [B, V, F] tensor of this level (un-pooled operands must come "
+                           "tagged from their producer)")
+        check(_lib.hip().p2m_amax_rows(g.handle, row_set, _p(_req(t, "x")), B, F, _p(w), _stream()), "p2m_amax_rows")
+    else:
+        check(_lib.hip().p2m_amax(_p(_req(t, "x")), t.numel(), _p(w), _stream()), "p2m_amax")
+    tag_amax(t, w)
     return w
 
 

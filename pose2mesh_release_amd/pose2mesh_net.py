@@ -13,10 +13,16 @@ from . import meshnet, posenet
 
 
 class FlatPose2Mesh(nn.Module):
-    def __init__(self, num_joint, graph_L, mano=None):
+    def __init__(self, num_joint, graph_L, mano=None, posenet_pretrained=None, posenet_path=None):
+        """posenet_pretrained / posenet_path: default = cfg.MODEL.posenet_pretrained / cfg.MODEL.posenet_path of the
+        reference's config when its scripts have loaded it (lib/models/pose2mesh_net.py:13, lib/models/posenet.py:89-92
+        -- every training yaml sets posenet_pretrained: True), else False."""
         super().__init__()
         self.num_joint = num_joint
-        self.pose_lifter = posenet.get_model(num_joint, hid_dim=4096, num_layer=2, p_dropout=0.5, pretrained=False)
+        if posenet_pretrained is None:
+            posenet_pretrained = posenet.cfg_posenet_pretrained()
+        self.pose_lifter = posenet.get_model(num_joint, hid_dim=4096, num_layer=2, p_dropout=0.5,
+                                             pretrained=posenet_pretrained, posenet_path=posenet_path)
         self.pose2mesh = meshnet.get_model(num_joint_input_chan=2 + 3, num_mesh_output_chan=3, graph_L=graph_L,
                                            mano=mano)
 
@@ -32,6 +38,6 @@ class FlatPose2Mesh(nn.Module):
         return self.pose2mesh(pose_combine), pose3d
 
 
-def get_model(num_joint, graph_L, mano=None):
+def get_model(num_joint, graph_L, mano=None, posenet_pretrained=None, posenet_path=None):
     """lib/models/pose2mesh_net.py:25-28."""
-    return FlatPose2Mesh(num_joint, graph_L, mano=mano)
+    return FlatPose2Mesh(num_joint, graph_L, mano=mano, posenet_pretrained=posenet_pretrained, posenet_path=posenet_path)

@@ -36,6 +36,8 @@ def _worker(rank, world, port, bucket_bytes, out):
     from pose2mesh_release_amd import dist as pd
     r, w, _ = pd.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
+    seen = pd.ranks_seen()                     # the diagnostics bench.py --gpus N prints: every rank sees every rank
+    assert seen["backend"] == "gloo" and seen["world"] == world and seen["ranks"] == list(range(world))
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 33), torch.nn.ReLU(),
                                 torch.nn.Linear(33, 5))
@@ -44,11 +46,16 @@ def _worker(rank, world, port, bucket_bytes, out):
     g = torch.Generator().manual_seed(42)
     X, Y = torch.randn(16, 20, generator=g), torch.randn(16, 5, generator=g)
     xs, ys = X[rank * 8:(rank + 1) * 8], Y[rank * 8:(rank + 1) * 8]
+    red.timing = True                          # a CPU buffer has no streams to time: the switch must be harmless
     for _ in range(2):                         # two steps: hooks/pending counters must re-arm
         flat.zero_()
+        red.mark_step_start()
         ((model(xs) - ys) ** 2).mean().backward()
+        assert len(red.launch_log) <= len(red.buckets)
         scale = red.finish()
         flat.mul_(scale)
+        assert red.launch_log == [] and len(red.last_launch_log) == len(red.buckets)   # one step's entries, then cleared
+    assert red.timing_report() is None
     if rank == 0:
         torch.save({"flat": flat.clone(), "nb": len(red.buckets)}, out)
     dist.barrier()

@@ -203,13 +203,40 @@ for use_rccl in (False, True):
             n_launched_in_backward = len(red.launch_log)
             scale = red.finish()
             assert scale == 1.0 and n_launched_in_backward >= 3
-            red.launch_log.clear()
+            assert red.launch_log == []               # one step's entries only (reset() clears them)
         opt.step(scale)
     torch.cuda.synchronize()
     finals.append((opt.flat_param.clone(), opt.exp_avg.clone()))
 # a sum over ONE rank is the identity: with the collectives (async Work objects, waited on by the stream, issued from the
 # communication stream) in the step, three updates are bit for bit those of the plain loop
 assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+# ... and the overlap by TIME, not only by launch order (HIP events around every collective on the communication stream,
+# around finish()'s wait on the main stream): one more step at a batch whose backward takes milliseconds
+seen = pd.ranks_seen()
+assert seen["backend"] == "nccl" and seen["ranks"] == [0] and seen["local_devices"] == [0] and seen["rccl_version"]
+red.timing = True
+big = synth.pose2d_batch(64, 21, seed=32).to(dev)
+cb = helpers.loss_case("mano", B=64, seed=24)
+tgt = [cb[k].to(dev) for k in ("gt_mesh", "gt_reg3dpose", "val_mesh", "val_reg3dpose", "gt_lift3dpose", "val_lift3dpose")]
+for _ in range(2):
+    opt.zero_grad()
+    red.mark_step_start()
+    mesh, lift = net(big)
+    total, _ = fused(mesh, tgt[0], tgt[1], tgt[2], tgt[3])
+    (1e-3 * stock[4](lift, tgt[4], tgt[5])).backward()
+    total.backward()
+    red.finish()
+rep = red.timing_report()
+assert rep is not None and len(rep["buckets"]) == len(red.buckets) and rep["allreduce_ms_total"] > 0
+mesh_ids = {{id(p) for p in net.pose2mesh.parameters()}}
+early = [x for x in rep["buckets"] if all(id(opt.params[i]) in mesh_ids for i in red.buckets[x["bucket"]][2])]
+# the PoseNet buckets (270 MB, back-propagated first) finish while the MeshNet backward is still running, and at least one
+# MeshNet-only bucket is complete before the main stream reaches the end of its backward work
+pose_b = [x for x in rep["buckets"] if not any(id(opt.params[i]) in mesh_ids for i in red.buckets[x["bucket"]][2])]
+assert pose_b and max(x["end_ms"] for x in pose_b) < rep["backward_end_ms"], rep
+assert early and min(x["end_ms"] for x in early) < rep["backward_end_ms"], rep
+assert rep["hidden_frac"] is not None and 0.0 <= rep["hidden_frac"] <= 1.0 and rep["exposed_ms"] < rep["backward_end_ms"], rep
+print("TIMING", rep["backward_end_ms"], rep["exposed_ms"], rep["hidden_frac"])
 dist.destroy_process_group()
 print("ONE_RANK_RCCL_OK")
 '''

@@ -431,8 +431,9 @@ def test_paired_backward_equals_fine_backward_pair_summed(ops, arith, monkeypatc
     """Backward of an un-pooled conv at the coarse resolution (include/p2m.h "paired operator"): S L g / S L2 g from the
     paired tile plan, row sets 3 / 4, against the fine-resolution backward followed by the pair-sum.  tile_gemm: the
     real rows through p2m_cheb_tile_gemm (plan 2: the planes are formed inside the contraction; opt-in P2M_TILE_GEMM=1)."""
-    if tile_gemm and arith != "bf16x3":
-        pytest.skip("the basis-inside-the-contraction kernel is a bf16x3 kernel")
+    if tile_gemm and arith == "f32":
+        pytest.skip("the basis-inside-the-contraction kernels exist in the slice arithmetics only (bf16x3: VALU gather; "
+                    "f16x2: gather on the matrix cores for N <= 128, VALU gather for N = 256)")
     monkeypatch.setattr(ops, "TILE_GEMM", tile_gemm)
     L = _band_graph(V, 31 + V)
     g = ops.DeviceGraph(L, "cuda:0")

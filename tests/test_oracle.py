@@ -251,3 +251,69 @@ def test_kink_accounting_counts_a_planted_flip():
     assert helpers.rel_l2(g1["bn.6.bias"], g0["bn.6.bias"]) > 1e-5
     # downstream of the flip only the forward value moved, by |y| ~ 1e-7: gradients there are untouched
     assert helpers.rel_l2(g1["cl.9.weight"], g0["cl.9.weight"]) < 1e-6
+
+
+def test_posenet_pretrained_contract(tmp_path, monkeypatch, capsys):
+    """lib/models/pose2mesh_net.py:13 + lib/models/posenet.py:74-75,89-92: FlatPose2Mesh reads cfg.MODEL.posenet_pretrained at
+    construction and, when set (every training yaml sets it), loads checkpoint['model_state_dict'] of cfg.MODEL.posenet_path
+    into the lifter through funcs_utils.load_checkpoint; a missing file raises ValueError("No checkpoint exists!") as
+    lib/funcs_utils.py:122-128 does.  Outside the reference's scripts (no core.config) the default stays random init, and
+    the same is reachable through explicit keyword arguments."""
+    import sys
+    import types
+    from pose2mesh_release_amd import pose2mesh_net, posenet
+    gL, _, _ = helpers.golden_graphs("mano")
+    J = int(gL[-1].shape[0])
+    torch.manual_seed(5)
+    donor = posenet.get_model(J, 4096, 2, 0.5)
+    sd = {k: (v + 0.25 if v.dtype.is_floating_point else v + 3) for k, v in donor.state_dict().items()}
+    ckpt = tmp_path / "final.pth.tar"
+    torch.save({"model_state_dict": sd, "epoch": 7}, str(ckpt))
+
+    def cfg_modules(pretrained, path):
+        cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(posenet_pretrained=pretrained, posenet_path=str(path)),
+                                    DATASET=types.SimpleNamespace(target_joint_set="mano"))
+        core, cc = types.ModuleType("core"), types.ModuleType("core.config")
+        cc.cfg = cfg
+        core.config = cc
+        return core, cc
+
+    def same(net):
+        got = net.pose_lifter.state_dict()
+        return all(torch.equal(got[k], v) for k, v in sd.items())
+    # 1. no reference config loaded: random init (config.py:56 default False)
+    for k in ("core", "core.config", "funcs_utils"):
+        monkeypatch.delitem(sys.modules, k, raising=False)
+    assert not same(pose2mesh_net.get_model(J, gL, mano=True))
+    # 2. inside the reference's scripts: cfg.MODEL.posenet_pretrained = True -> the checkpoint is loaded
+    core, cc = cfg_modules(True, ckpt)
+    monkeypatch.setitem(sys.modules, "core", core)
+    monkeypatch.setitem(sys.modules, "core.config", cc)
+    net = pose2mesh_net.get_model(J, gL)
+    assert same(net) and net.pose2mesh.mano
+    out = capsys.readouterr().out
+    assert "Loading pretrained posenet..." in out and "Fetch model weight from" in out
+    # ... through the reference's own loader when funcs_utils is imported (lib/models/posenet.py:3)
+    calls = []
+    fu = types.ModuleType("funcs_utils")
+
+    def load_checkpoint(load_dir, epoch=0, pick_best=False):
+        calls.append((load_dir, pick_best))
+        return torch.load(load_dir, map_location="cpu")
+    fu.load_checkpoint = load_checkpoint
+    monkeypatch.setitem(sys.modules, "funcs_utils", fu)
+    assert same(pose2mesh_net.get_model(J, gL)) and calls == [(str(ckpt), True)]
+    monkeypatch.delitem(sys.modules, "funcs_utils")
+    # 3. cfg says False -> untouched; a missing file -> the reference's error
+    cc.cfg.MODEL.posenet_pretrained = False
+    assert not same(pose2mesh_net.get_model(J, gL))
+    cc.cfg.MODEL.posenet_pretrained = True
+    cc.cfg.MODEL.posenet_path = str(tmp_path / "nope.pth.tar")
+    with pytest.raises(ValueError, match="No checkpoint exists!"):
+        pose2mesh_net.get_model(J, gL)
+    # 4. explicit arguments, no config
+    monkeypatch.delitem(sys.modules, "core")
+    monkeypatch.delitem(sys.modules, "core.config")
+    assert same(pose2mesh_net.get_model(J, gL, mano=True, posenet_pretrained=True, posenet_path=str(ckpt)))
+    with pytest.raises(ValueError, match="posenet_path"):
+        pose2mesh_net.get_model(J, gL, mano=True, posenet_pretrained=True)
