@@ -59,15 +59,6 @@ const char* p2m_last_error_string(void);
 /* Library version / build info (e.g. "p2m-hip 0.3 (gfx950; ...)"). */
 const char* p2m_version(void);
 
-/* ---- helper streams ------------------------------------------------------------------------
- * The backward's weight-gradient contractions run on a helper stream (nothing downstream in the backward reads them).
- * The host framework's stream pools only hand out streams of the default or a HIGHER priority; this creates one
- * with an explicit HIP priority (hipStreamCreateWithPriority: -1 high, 0 normal, 1 low; clamped to the device's range) and,
- * optionally, a compute-unit mask (hipExtStreamCreateWithCUMask: n_mask_words x 32 bits, bit i = CU i may be used) on
- * the current device.  The caller owns the stream (wrap it, e.g. torch.cuda.ExternalStream) and destroys it.   */
-int p2m_stream_create(int32_t priority, const uint32_t* cu_mask, int32_t n_mask_words, void** out);
-int p2m_stream_destroy(void* stream);
-
 /* ---- graph handle: one per coarsening level ------------------------------------------------
  * Replaces sparse_python_to_torch (lib/graph_utils.py:98-109) and the per-forward
  * `self.graph_L[i].cuda()` upload (lib/models/meshnet.py:81).  Input: host CSR of the rescaled

@@ -22,8 +22,6 @@ _i32, _i64, _f32, _vp = _c.c_int32, _c.c_int64, _c.c_float, _c.c_void_p
 HIP_SYMBOLS = {
     "p2m_last_error_string": (_c.c_char_p, []),
     "p2m_version": (_c.c_char_p, []),
-    "p2m_stream_create": (_c.c_int, [_i32, _vp, _i32, _c.POINTER(_vp)]),
-    "p2m_stream_destroy": (_c.c_int, [_vp]),
     "p2m_graph_create": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _c.POINTER(_vp)]),
     "p2m_graph_destroy": (_c.c_int, [_vp]),
     "p2m_graph_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 4)]),

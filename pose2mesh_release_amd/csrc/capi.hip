@@ -148,37 +148,6 @@ using namespace p2m;
 
 extern "C" const char* p2m_last_error_string(void) { return g_err; }
 
-#define P2M_HIP(call)                                                             \
-  do {                                                                            \
-    const hipError_t e_ = (call);                                                 \
-    if (e_ != hipSuccess) {                                                       \
-      set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_));     \
-      return P2M_ERR_HIP;                                                         \
-    }                                                                             \
-  } while (0)
-
-extern "C" int p2m_stream_create(int32_t priority, const uint32_t* cu_mask, int32_t n_mask_words, void** out) {
-  P2M_CHECK_ARG(out != nullptr, "null pointer");
-  P2M_CHECK_ARG((cu_mask == nullptr) == (n_mask_words == 0) && n_mask_words >= 0, "cu_mask / n_mask_words disagree");
-  int least = 0, greatest = 0;
-  P2M_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));       // numerically: least >= greatest
-  if (priority > least) priority = least;
-  if (priority < greatest) priority = greatest;
-  hipStream_t s = nullptr;
-  if (cu_mask != nullptr) {
-    // a CU-masked stream cannot take a priority at creation: the mask wins (used for experiments only)
-    P2M_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_mask_words, cu_mask));
-  } else {
-    P2M_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
-  }
-  *out = s;
-  return P2M_OK;
-}
-
-extern "C" int p2m_stream_destroy(void* stream) {
-  if (stream != nullptr) P2M_HIP(hipStreamDestroy((hipStream_t)stream));
-  return P2M_OK;
-}
 extern "C" const char* p2m_version(void) { return "p2m-hip 0.4 (gfx950; fp32 contractions as 2 scaled fp16 slices or 3 exact bf16 slices on the matrix pipe, or on the f32 MFMA; basis inside the contraction, paired operator, fake-row classes)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).

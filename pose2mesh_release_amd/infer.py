@@ -43,11 +43,11 @@ class GraphedInference:
         self.captures = 0
         self._capture()
 
-    # the full walk over every parameter / buffer version costs ~0.2 ms of host time per call - as much as a tenth of a
-    # batch-64 replay.  ops.WEIGHT_EPOCH (bumped by the flat optimizers, by every train-mode forward and by
-    # GraphedTrainStep) is compared on EVERY call; the walk - which catches plain torch optimizers, load_state_dict
-    # and in-place edits, none of which touch the epoch - runs on the first call after a capture and then every
-    # FULL_CHECK_EVERY calls.
+    # The full walk over every parameter / buffer (pointer, version) costs ~0.2 ms of host time - a tenth of a batch-64
+    # replay.  Checked on EVERY call: ops.WEIGHT_EPOCH (bumped by the flat optimizers, every train-mode forward and
+    # GraphedTrainStep) and a few SENTINEL tensors (first / last parameter, first / last buffer: any optimizer step or
+    # load_state_dict moves all of them).  The full walk - which also catches an in-place edit of one arbitrary tensor -
+    # runs on the first call after a capture and then every FULL_CHECK_EVERY calls.
     FULL_CHECK_EVERY = 16
 
     def _weights_tag(self):
@@ -55,6 +55,8 @@ class GraphedInference:
 
     def _weights_moved(self):
         if _ops.WEIGHT_EPOCH != self._tag[0]:
+            return True
+        if any((t.data_ptr(), t._version) != self._tag[1 + i] for i, t in self._sentinels):
             return True
         self._calls += 1
         if self._calls == 1 or self._calls % self.FULL_CHECK_EVERY == 0:
@@ -68,7 +70,10 @@ class GraphedInference:
             self.model.eval()
         with torch.cuda.device(self.device), torch.no_grad():
             self.graph = None
-            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+            params, bufs = list(self.model.parameters()), list(self.model.buffers())
+            self._tensors = params + bufs
+            idx = sorted({0, len(params) - 1, len(params), len(self._tensors) - 1} & set(range(len(self._tensors))))
+            self._sentinels = [(i, self._tensors[i]) for i in idx]
             self._calls = 0
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())

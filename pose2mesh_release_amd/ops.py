@@ -100,15 +100,14 @@ def _timed(name, work):
 # BatchNorm-backward reduction in the contraction epilogue, the project-then-combine forward of un-pooled convs, operand
 # prefetch on a helper stream, the gather-in-GEMM f32 kernel.
 SPLIT_FAKE = _os.environ.get("P2M_SPLIT_FAKE", "1") == "1"
-# Where the backward's weight-gradient contractions run (nothing downstream in the backward reads them):
-#   side (default)  a helper stream of normal priority: they overlap the main stream's kernels
-#   low             a helper stream of LOW HIP priority (p2m_stream_create): the dispatcher prefers the main stream's
-#                   workgroups, the weight gradient fills what is left
-#   cuN             a helper stream restricted to N of the 256 compute units (every (256/N)-th CU)
-#   main            on the main stream, serially (the A/B form; bench.py's `exclusive_serial` figures)
+# Weight-gradient contractions on a side stream (nothing downstream in the backward reads them); P2M_DW_STREAM=main runs them
+# on the main stream, serially (the A/B form; bench.py's `exclusive_serial` figures).  Measured in round 4 and removed again
+# (DESIGN.md section 6): a LOW-priority helper stream (38.40 vs 38.22 ms), helper streams masked to 64 / 32 CUs (43.9 /
+# 43.4 ms), and holding the big levels' jobs back until the backward reaches the coarse levels (38.5-38.8 vs 38.0 ms: the
+# main queue is never idle, so the HBM-bound work only moves); serial: 39.2 ms.
 DW_STREAM = _os.environ.get("P2M_DW_STREAM", "side")
-if not (DW_STREAM in ("side", "low", "main") or (DW_STREAM.startswith("cu") and DW_STREAM[2:].isdigit())):
-    raise ValueError(f"P2M_DW_STREAM must be side, low, main or cu<N>, not {DW_STREAM!r}")
+if DW_STREAM not in ("side", "main"):
+    raise ValueError(f"P2M_DW_STREAM must be side or main, not {DW_STREAM!r}")
 DW_SIDE_STREAM = DW_STREAM != "main"
 # backward of un-pooled convs at the coarse resolution (paired operator, include/p2m.h); 0 = at the fine resolution
 # with a pair-sum afterwards (the A/B form, also the independent path of the B=256 parity test)
@@ -571,26 +570,9 @@ def side_stream(device, which=0):
         with _side_lock:
             st = _side_streams.get(key)
             if st is None:
-                st = _make_side_stream(device) if which == 0 else torch.cuda.Stream(device=device)
+                st = torch.cuda.Stream(device=device)
                 _side_streams[key] = st
     return st
-
-
-def _make_side_stream(device):
-    if DW_STREAM in ("side", "main"):
-        return torch.cuda.Stream(device=device)
-    h = _vp()
-    with torch.cuda.device(device):
-        if DW_STREAM == "low":
-            check(_lib.hip().p2m_stream_create(1, None, 0, ctypes.byref(h)), "p2m_stream_create")
-        else:
-            n = max(1, min(256, int(DW_STREAM[2:])))
-            stride = max(1, 256 // n)
-            words = (ctypes.c_uint32 * 8)()
-            for cu in range(0, 256, stride):
-                words[cu >> 5] |= 1 << (cu & 31)
-            check(_lib.hip().p2m_stream_create(0, words, 8, ctypes.byref(h)), "p2m_stream_create")
-    return torch.cuda.ExternalStream(h.value, device=device)      # lives as long as the process: never destroyed
 
 
 class _ConvWeightsDesc(ctypes.Structure):       # == p2m_conv_weights (include/p2m.h)

@@ -5,8 +5,8 @@
   (c) BASELINE configs[2] itself (SMPL-like coco graph, B=256, train): the default kernel set against an INDEPENDENT
       kernel set (native f32 MFMA, no fake-vertex split, row-per-wave basis kernel, 4-wave GEMM) in a child process,
       plus eval slices of the same batch against the oracle;
-  (c') the train-mode FORWARD of configs[2] (B=256) and configs[4] (MANO B=512) against the fp32 oracle under no_grad
-      (full-batch BatchNorm statistics) -- BASELINE's "vertex L2 vs ref at batch 256", oracle-anchored;
+  (c') the train-mode FORWARD of configs[2] (B=256) and configs[4] (MANO B=512) against the fp32 AND the float64 oracle under
+      no_grad (full-batch BatchNorm statistics) -- BASELINE's "vertex L2 vs ref at batch 256", oracle-anchored;
   (d) three optimizer steps of the bench's TrainStep against oracle + torch.optim.Adam;
   (e) train-mode bitwise repeatability.
 All through the C ABI on the default (f16x2) arithmetic.  Achieved maxima are written to
@@ -204,7 +204,7 @@ def test_bench_scale_vs_oracle_train(hip_libs, joint_set, B):
 def test_baseline_sizes_default_vs_independent_kernel_set(hip_libs, tmp_path, joint_set, B, seeds):
     """(c) BASELINE configs[2] (SMPL-like coco graph, B=256, train) and configs[4] (MANO-like, B=512, train).  No CPU
     oracle can run forward + BACKWARD at these sizes (float64 needs ~140 GB for configs[2]; the forward alone is
-    test_baseline_sizes_train_forward_vs_fp32_oracle), so the default kernel set (f16x2 contraction on
+    test_baseline_sizes_train_forward_vs_oracle), so the default kernel set (f16x2 contraction on
     the FP16 pipe, fake-vertex split, LDS-tiled basis, wave-specialised GEMM) is compared with an INDEPENDENT one (native
     f32 MFMA, unsplit rows, row-per-wave gather, 4-wave GEMM) that test_independent_kernel_set_vs_oracle_train pins to the
     float64 oracle at network level.  Forward: per-vertex L2.  Backward: the two runs' ReLU masks are compared bit by
@@ -255,12 +255,18 @@ def test_baseline_sizes_default_vs_independent_kernel_set(hip_libs, tmp_path, jo
 
 
 @pytest.mark.parametrize("joint_set,B,seeds", [("coco", 256, (41, 55, 9)), ("mano", 512, (42, 56, 10))])
-def test_baseline_sizes_train_forward_vs_fp32_oracle(hip_libs, joint_set, B, seeds):
+def test_baseline_sizes_train_forward_vs_oracle(hip_libs, joint_set, B, seeds):
     """(c') BASELINE's own parity figure, oracle-anchored: the TRAIN-mode forward (full-batch BatchNorm statistics,
     lib/models/backbones/cheby_graph_conv.py:39, lib/models/meshnet.py:80-117) of configs[2] (SMPL-like coco graph, B=256)
-    and configs[4] (MANO-like, B=512) on the default kernel set against the fp32 CPU oracle run under no_grad (no saved
-    activations: ~20 GB and well under a minute at B=256 on 16 host threads).  Asserted: max per-vertex L2 <= 1e-4
-    ("vertex L2 vs ref at batch 256"), and the running statistics of every BatchNorm the forward updated."""
+    and configs[4] (MANO-like, B=512) on the default kernel set against the CPU oracle run under no_grad (no saved
+    activations) - in fp32, the reference's own CPU arithmetic, AND in float64, the same operator sequence without its
+    rounding noise.  At B=256 the BatchNorm statistics run over 3.0 M rows per channel; the reference's fp32 CPU path
+    (torch's per-thread fp32 accumulation) is itself ~3e-4 away from the float64 result there (measured, recorded), so
+    "within 1e-4 of the reference" is asserted the only way that is well defined:
+      * HIP vs float64 oracle             <= 1e-4  (per-vertex L2, max over B x V)          -- the bar;
+      * HIP vs fp32 oracle                <= 1e-4 + (fp32 oracle vs float64 oracle)         -- no further away from the
+        reference's fp32 result than that result's own rounding error allows;
+      * running statistics vs the float64 oracle's (rounded to fp32)."""
     ws, xs, gs = seeds
     hip = _hip_run(joint_set, B, "train", ws, xs, gs)
     out = hip["out"].cpu()
@@ -268,18 +274,26 @@ def test_baseline_sizes_train_forward_vs_fp32_oracle(hip_libs, joint_set, B, see
     del hip
     torch.cuda.empty_cache()
     sd, glt, x, mano, _ = _oracle_inputs(joint_set, B, ws, xs, gs)
-    ref, _, ref_sd = helpers.oracle_run(sd, glt, x, mano, True, grad_seed=None)
-    tag = f"c_{joint_set}_B{B}_train_fwd_vs_fp32_oracle"
-    err = helpers.max_vertex_l2(out, ref)
-    _record(f"{tag}_vertex_l2", err)
-    _record(f"{tag}_vertex_l2_mean", float((out.double() - ref.double()).norm(dim=-1).mean()))
-    assert err <= VERTEX_TOL
+    ref32, _, _ = helpers.oracle_run(sd, glt, x, mano, True, grad_seed=None)
+    sd64 = {k: (v.double().clone() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    with torch.no_grad():
+        ref64 = mo.meshnet_forward(sd64, [g.double() for g in glt], x.double(), mano, True)
+    tag = f"c_{joint_set}_B{B}_train_fwd"
+    e64, e32 = helpers.max_vertex_l2(out, ref64), helpers.max_vertex_l2(out, ref32)
+    noise = helpers.max_vertex_l2(ref32, ref64)
+    _record(f"{tag}_vertex_l2_vs_float64_oracle", e64)
+    _record(f"{tag}_vertex_l2_vs_fp32_oracle", e32)
+    _record(f"{tag}_fp32_oracle_vs_float64_oracle", noise)
+    _record(f"{tag}_vertex_l2_mean_vs_float64_oracle", float((out.double() - ref64).norm(dim=-1).mean()))
+    assert e64 <= VERTEX_TOL, (e64, e32, noise)
+    assert e32 <= VERTEX_TOL + noise, (e64, e32, noise)
     worst = 0.0
-    for k, v in ref_sd.items():
+    for k, v in sd64.items():
         if "running" in k:
-            worst = max(worst, float((state[k] - v).abs().max()))
-            assert (state[k] - v).abs().max() < 1e-4, k
-    _record(f"{tag}_running_stats_max_abs", worst)
+            d = float((state[k].double() - v).abs().max())
+            worst = max(worst, d)
+            assert d < 1e-4, (k, d)
+    _record(f"{tag}_running_stats_max_abs_vs_float64_oracle", worst)
 
 
 @pytest.mark.parametrize("env,fwd_bitwise", [({"P2M_CLASSES": "0"}, False), ({"P2M_PAIR_BWD": "0"}, True),
