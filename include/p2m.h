@@ -215,8 +215,10 @@ int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * act = ReLU if relu!=0; scale/shift may be NULL (identity); resid may be NULL.
  * lerp_F is F.interpolate(mode='linear', align_corners=False) along the FEATURE axis
  * (meshnet.py:109,114).  Rows: all M; with `classes` (a level's handle) the live rows of a level with declared
- * classes (holes are skipped); with real_rows_only != 0 only the handle's real vertices (inference on the real rows:
- * the other rows of y hold no data and x's stay untouched).  amax_out (optional, F % 4 == 0): atomic max of |x stored|
+ * classes (holes are skipped); with real_rows_only = 1 only the handle's real vertices (inference on the real rows:
+ * the other rows of y hold no data and x's stay untouched); real_rows_only = 2: only the handle's FAKE vertices (row set 2:
+ * one representative per class once classes are declared) - the rows a consumer with activation on load still reads from x.
+ * amax_out (optional, F % 4 == 0): atomic max of |x stored|
  * into a zeroed amax word (P2M_ARITH_F16X2 above) - the bound for the contraction that consumes x.                  */
 int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                    const float* resid, int32_t Fres, int32_t res_shift,
@@ -289,11 +291,14 @@ int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float*
                          void* amax_out, void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
- * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.                                        */
+ * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.  a_scale / a_shift [Ka] (optional, slice
+ * arithmetics only): activation on load of A, as in p2m_cheb_tile_gemm - A holds the raw conv output y and the operand is
+ * max(fma(y, a_scale[k], a_shift[k]), 0); a_amax then bounds that (p2m_act_bound).                                  */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
                      const float* G0, const float* G1, const float* G2, int32_t nplanesG, int32_t Gc,
                      int32_t planes_compact, int32_t splits, float* P, float* Pdb, int32_t arith,
-                     const void* a_amax, const void* g_amax, int32_t g_bits, void* stream);
+                     const void* a_amax, const void* g_amax, int32_t g_bits, const float* a_scale,
+                     const float* a_shift, void* stream);
 /* We[k][n] = Wt[k][n] + a Wt[Ka+k][n] + b Wt[2Ka+k][n]  (Wt = [3Ka, N]) */
 int p2m_weight_eff(const float* Wt, float* We, int32_t Ka, int32_t N, float a, float b, void* stream);
 /* dW (nn.Linear layout) from the real-vertex partials P[c][fin][k*Fout+fo] plus the fake-vertex partials
@@ -331,12 +336,23 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * (P2M_ARITH_F16X2 with N <= 128: the tile's operator as a dense fp16-sliced block, baked with the plan); act_*: fused eval-mode
  * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  arith: P2M_ARITH_BF16X3 or P2M_ARITH_F16X2 (Bx split with
  * the same arith; x_amax = amax word bounding X and A0, the kernel adds the level's p2m_graph_plane_bits for the planes
- * it forms).  amax_out as in p2m_gemm_planes.                                                                          */
+ * it forms).  amax_out as in p2m_gemm_planes.
+ * in_scale / in_shift [Ka] (optional; P2M_ARITH_F16X2 with N <= 128, no planes out): ACTIVATION ON LOAD - X and A0 hold the
+ * raw output y of the previous conv and the operand is x = max(fma(y, in_scale[f], in_shift[f]), 0), its BatchNorm + ReLU
+ * (lib/models/backbones/cheby_graph_conv.py:39, lib/models/meshnet.py:100) with the two roundings of p2m_bn_act_fwd, applied in
+ * the producer waves between the global load and the LDS image: the activated tensor never exists in HBM.  x_amax must
+ * then bound x (p2m_act_bound).                                                                                            */
 int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
 int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
                        int32_t arith, const void* x_amax, const float* bias, const float* addend, float* C, int32_t N,
                        float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,
-                       int32_t act_relu, void* amax_out, int32_t B, void* stream);
+                       int32_t act_relu, void* amax_out, const float* in_scale, const float* in_shift, int32_t B,
+                       void* stream);
+/* Bound of x = max(fma(y, scale[f], shift[f]), 0) over a tensor y whose amax word is y_amax:
+ *     atomic max of max_f fma(amax(y), |scale[f]|, max(shift[f], 0)) into the amax word `word`
+ * (a true bound in fp32: fma and max are monotone) - the x_amax / a_amax of a consumer that applies the activation on
+ * load.  N <= 4096.                                                                                                        */
+int p2m_act_bound(const float* scale, const float* shift, int32_t N, const void* y_amax, void* word, void* stream);
 /* Binades of headroom that cover the Chebyshev planes of a level: ceil(log2(max(1, max_v sum_u |L_vu|, max_v sum_u
  * |L2_vu|))) for plan 0 / 1 (|L x|, |L2 x| <= 2^bits max |x|), one more for plan 2 (the pair sums).                */
 int32_t p2m_graph_plane_bits(p2m_graph_t g, int32_t plan);

@@ -41,7 +41,7 @@ HIP_SYMBOLS = {
                                         _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
-                                    _i32, _vp, _vp, _i32, _vp]),
+                                    _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "p2m_weight_eff": (_c.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "p2m_weight_grad_unpack2": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _i32, _i32, _i32,
                                            _i32, _vp]),
@@ -51,7 +51,8 @@ HIP_SYMBOLS = {
                                          _vp]),
     "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
     "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
-                                      _vp, _i32, _vp, _i32, _vp]),
+                                      _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "p2m_act_bound": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "p2m_graph_plane_bits": (_i32, [_vp, _i32]),
     "p2m_amax": (_c.c_int, [_vp, _i64, _vp, _vp]),
     "p2m_conv_weights_prepare": (_c.c_int, [_vp, _i32, _i32, _vp]),

@@ -987,7 +987,14 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
       const long rows_per_block = (long)(256 / F4) * ACT_UNROLL * ACT_PASSES;
       RowMap m;
       long Mlog;
-      if (real_rows_only) {               // inference on the real rows: the other rows of y hold no data
+      if (real_rows_only == 2) {          // the fake vertices only (row set 2: class representatives once declared)
+        const Graph& g = *reinterpret_cast<const Graph*>(classes);
+        const RowSet rs = row_set_of(g, 2);
+        P2M_CHECK_ARG(M % g.V == 0 && M < (1LL << 32), "M is not a multiple of the level's vertex count");
+        if (rs.n == 0) return P2M_OK;
+        m.w = nullptr; m.ids = rs.ids; m.n = (unsigned)rs.n; m.V = (unsigned)g.V;
+        Mlog = (M / g.V) * (long)rs.n;
+      } else if (real_rows_only) {        // inference on the real rows: the other rows of y hold no data
         const Graph& g = *reinterpret_cast<const Graph*>(classes);
         P2M_CHECK_ARG(M % g.V == 0 && M < (1LL << 32) && g.n_real > 0, "M is not a multiple of the level's vertex count");
         m.w = nullptr; m.ids = g.real_ids; m.n = (unsigned)g.n_real; m.V = (unsigned)g.V;
@@ -1010,6 +1017,23 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
                        Fres, res_shift, x, (long)M, F);
   }
   return check_launch("bn_act_fwd");
+}
+
+// bound of max(fma(y, scale, shift), 0) given amax(y): one block, atomic max into the word (include/p2m.h)
+__global__ __launch_bounds__(256) void k_act_bound(const float* __restrict__ scale, const float* __restrict__ shift, int N,
+                                                   const unsigned* __restrict__ y_amax, unsigned* __restrict__ word) {
+  const float A = __uint_as_float(*y_amax);
+  float v = 0.f;
+  for (int f = threadIdx.x; f < N; f += 256) v = fmaxf(v, fmaf(A, fabsf(scale[f]), fmaxf(shift[f], 0.f)));
+  amax_commit(word, v);
+}
+
+extern "C" int p2m_act_bound(const float* scale, const float* shift, int32_t N, const void* y_amax, void* word,
+                             void* stream) {
+  P2M_CHECK_ARG(scale && shift && y_amax && word && N > 0, "null pointer or empty shape");
+  hipLaunchKernelGGL(k_act_bound, dim3(1), dim3(256), 0, (hipStream_t)stream, scale, shift, N,
+                     static_cast<const unsigned*>(y_amax), static_cast<unsigned*>(word));
+  return check_launch("act_bound");
 }
 
 extern "C" int32_t p2m_bn_bwd_blocks(int64_t M, int32_t F) {

@@ -71,6 +71,9 @@ struct TileGemmArgs {
   const float* addend;         // [B][c_rows][N] or null
   const float* act_scale;      // optional fused eval-mode BatchNorm (+ ReLU), the two roundings of p2m_bn_act_fwd
   const float* act_shift;
+  const float* in_scale;       // optional activation ON LOAD (k_cheb_mg_gemm): X and A0 hold the RAW output y of the previous
+  const float* in_shift;       // conv and the operand is x = max(fma(y, in_scale[f], in_shift[f]), 0) - its BatchNorm + ReLU,
+                               // the two roundings of p2m_bn_act_fwd - so that x is never written to / read from HBM
   float* C;                    // [B][c_rows][N]
   float* stats;                // [B][ntiles][2][N] (sum, M2 about the tile mean) or null
   float* E1;                   // [B * nset][Ka] compact planes out, or null
@@ -680,7 +683,27 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       for (int k = 0; k < NPI; k++) p0[k] = *reinterpret_cast<const f32x4*>(ba + a0off[k]);
       if (++lfc == nchunks) { lfc = 0; lg++; }
     };
+    // activation on load (in_scale != nullptr): applied to the registers of a unit when they are stored, a unit after their
+    // loads were issued; the unit's feature chunk is tracked per store kind (both walk units 0, 1, 2, ...)
+    int sfc_x = 0, sfc_p = 0;
+    auto act_chunk = [&](int fc, f32x4& sc, f32x4& sh) {
+      sc = *reinterpret_cast<const f32x4*>(g.in_scale + fc * CT_CF + q * 4);
+      sh = *reinterpret_cast<const f32x4*>(g.in_shift + fc * CT_CF + q * 4);
+    };
+    auto act4 = [](f32x4& v, const f32x4& sc, const f32x4& sh) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
+    };
     auto store_xu = [&]() {
+      if (g.in_scale != nullptr) {
+        f32x4 sc, sh;
+        act_chunk(sfc_x, sc, sh);
+#pragma unroll
+        for (int k = 0; k < NXI; k++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) act4(xr[k][j], sc, sh);
+        if (++sfc_x == nchunks) sfc_x = 0;
+      }
 #pragma unroll
       for (int k = 0; k < NXI; k++) {
         const int uq = ((uhi + k * NPW) << 1) | ulo;
@@ -695,6 +718,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       }
     };
     auto store_p0 = [&]() {
+      if (g.in_scale != nullptr) {
+        f32x4 sc, sh;
+        act_chunk(sfc_p, sc, sh);
+#pragma unroll
+        for (int k = 0; k < NPI; k++) act4(p0[k], sc, sh);
+        if (++sfc_p == nchunks) sfc_p = 0;
+      }
 #pragma unroll
       for (int k = 0; k < NPI; k++) {
         u32x2 ph, pl2;
@@ -967,8 +997,11 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
                                   const void* Bx, int32_t arith, const void* x_amax, const float* bias,
                                   const float* addend, float* C, int32_t N, float* stats, float* E1, float* E2,
                                   const float* act_scale, const float* act_shift, int32_t act_relu, void* amax_out,
-                                  int32_t B, void* stream) {
+                                  const float* in_scale, const float* in_shift, int32_t B, void* stream) {
   P2M_CHECK_ARG(gh && X && A0 && Bx && C, "null pointer");
+  P2M_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must both be given or both NULL");
+  P2M_CHECK_ARG(in_scale == nullptr || (arith == P2M_ARITH_F16X2 && N <= 128 && (E1 == nullptr)),
+                "activation on load exists in the matrix-core-gather kernel only (P2M_ARITH_F16X2, N <= 128, no planes out)");
   P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || x_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of X / A0");
   P2M_CHECK_ARG(plan >= 0 && plan <= 2, "plan must be 0 (level), 1 (un-pooled input) or 2 (paired operator)");
@@ -997,6 +1030,8 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   a.act_scale = act_scale;
   a.act_shift = act_shift;
   a.act_relu = act_relu;
+  a.in_scale = in_scale;
+  a.in_shift = in_shift;
   a.C = C;
   a.stats = stats;
   a.E1 = E1;

@@ -713,6 +713,9 @@ struct TnArgs {
   const unsigned* a_amax;
   const unsigned* g_amax;
   int a_bits, g_bits;
+  // activation on load of A plane 0 (k_gemm_tn_ws): the operand is max(fma(A, a_scale[k], a_shift[k]), 0); or null
+  const float* a_scale;
+  const float* a_shift;
   int nchunks;           // k_gemm_tn_ws: one-dimensional grid of ceil(nchunks / 8) * 8 * nkt * ntn blocks (XCD-aware mapping)
 };
 
@@ -970,6 +973,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     }
   }
   const int buf_stride = is_a ? A_BUF : G_BUF;
+  // activation on load (A staging waves only; wave-uniform): the coefficients of this thread's four columns
+  const bool a_act = __builtin_amdgcn_readfirstlane((int)(is_a && g.a_scale != nullptr)) != 0;
+  f32x4 act_sc = {1.f, 1.f, 1.f, 1.f}, act_sh = {0.f, 0.f, 0.f, 0.f};
+  if (a_act) {
+    int kk = kk0 + c4 * 4;
+    if (kk >= g.Ktot) kk = 0;
+    act_sc = *reinterpret_cast<const f32x4*>(g.a_scale + kk);
+    act_sh = *reinterpret_cast<const f32x4*>(g.a_shift + kk);
+  }
   float my_sc = 1.f;                     // two-fp16-slice mode: this staging wave's operand is staged times 2^s
   int descale = 0;
   if (NS == 2) {
@@ -1011,6 +1023,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) asm volatile("" : "+v"(x[ps]));     // see k_gemm_planes_bx
+    if (a_act) {                                                        // (before the tail's zeroing: act(0) != 0)
+#pragma unroll
+      for (int ps = 0; ps < 4; ps++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[ps][e] = fmaxf(fmaf(x[ps][e], act_sc[e], act_sh[e]), 0.f);
+    }
     if (TAIL) {
       const int rlast = nrows_m1 + 1 - (kc * RK + rq * 4);             // rows of this quad that exist
 #pragma unroll
@@ -1632,6 +1650,7 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   g.ids = nullptr; g.nset = 0; g.V = 0; g.splits = 1; g.compact = 0;
   g.a_amax = static_cast<const unsigned*>(a_amax); g.g_amax = static_cast<const unsigned*>(g_amax);
   g.a_bits = a_bits; g.g_bits = g_bits;
+  g.a_scale = g.a_shift = nullptr;
   const int nchunks = cdiv(M, chunk_rows);
   g.nchunks = nchunks;
   hipStream_t s = (hipStream_t)stream;
@@ -1665,8 +1684,11 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
 extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, const float* A, int32_t Ka,
                                 int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
                                 int32_t Gc, int32_t planes_compact, int32_t splits, float* P, float* Pdb,
-                                int32_t arith, const void* a_amax, const void* g_amax, int32_t g_bits, void* stream) {
+                                int32_t arith, const void* a_amax, const void* g_amax, int32_t g_bits,
+                                const float* a_scale, const float* a_shift, void* stream) {
   P2M_CHECK_ARG(gh && A && G0 && P, "null pointer");
+  P2M_CHECK_ARG((a_scale == nullptr) == (a_shift == nullptr), "a_scale / a_shift must both be given or both NULL");
+  P2M_CHECK_ARG(a_scale == nullptr || arith != P2M_ARITH_F32, "activation on load exists in the slice arithmetics only");
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || (a_amax && g_amax), "P2M_ARITH_F16X2 needs the amax words of both operands");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
@@ -1687,6 +1709,7 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.splits = splits; g.compact = planes_compact;
   g.a_amax = static_cast<const unsigned*>(a_amax); g.g_amax = static_cast<const unsigned*>(g_amax);
   g.a_bits = 0; g.g_bits = g_bits;
+  g.a_scale = a_scale; g.a_shift = a_shift;
   const int nchunks = B * splits;
   g.nchunks = nchunks;
   hipStream_t s = (hipStream_t)stream;

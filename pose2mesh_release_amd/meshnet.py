@@ -212,6 +212,8 @@ class _MeshNetFn(torch.autograd.Function):
         nblk = len(net.CL_F)
         block_in, block_in_shift, block_in_F = None, 0, 0
         fc_saved = None
+        fold = None        # activation on load: (raw output y, scale, shift) of the previous conv when `cur` holds only its
+                           # activated FAKE rows (ops.fold_act_ok) - consumed by the very next conv
         for L in net._layers:
             g = graphs[L.graph]
             M = B * g.V
@@ -230,7 +232,7 @@ class _MeshNetFn(torch.autograd.Function):
                 out = ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
                 del Pm
                 if keep:
-                    saved.append((cur, cur_shift, None, None, None, None, Wp))
+                    saved.append((cur, cur_shift, None, None, None, None, Wp, None))
                 cur, cur_shift = out, 0
                 continue
             need_stats = L.has_bn and training
@@ -252,8 +254,14 @@ class _MeshNetFn(torch.autograd.Function):
                 opf = cws.fwd(L.ci, W) if batched else wc.get(
                     (L.ci, "split_fwd"), W, lambda: ops.split_operands(Wt, L.Fin, L.Fout, g.fake_a, g.fake_b,
                                                                       wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
+                # does the NEXT conv take this one's activation on load?  Then y's amax word is needed for the bound
+                Ln = net._layers[L.ci + 1] if L.ci + 1 < len(net._layers) else None
+                fold_out = (L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
+                            and not _narrow(Ln) and _bwd_forward_form(Ln) and ops.fold_act_ok(g, Ln.Fin, Ln.Fout, B))
+                yword = ops.new_amax(cur.device) if fold_out else None
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
-                                                        g.fake_b, need_stats, operands=opf, want_planes=False)
+                                                        g.fake_b, need_stats, operands=opf, want_planes=False,
+                                                        amax_out=yword, in_act=fold)
                 tile_rows = ("tiles", cur_shift) if tiled else "rows"
             else:
                 T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
@@ -262,6 +270,8 @@ class _MeshNetFn(torch.autograd.Function):
                 (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats, Bx=Wtx,
                                            amax=ops.amax_of(cur), amax_bits=g.plane_bits)
                 tile_rows = None
+                fold_out, yword = False, None
+            fold_in, fold = fold, None
             co = None
             if L.has_bn:
                 bn = net.bn[L.ci]
@@ -283,8 +293,15 @@ class _MeshNetFn(torch.autograd.Function):
                 resid = None
                 if L.last_in_block and 1 <= L.block <= nblk - 2:       # meshnet.py:108-115
                     resid = block_in
-                out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout,
-                                     classes=g if (g.classes and split) else None)
+                if fold_out:
+                    # only the fake rows of x are materialised (the effective-weight contraction and its weight gradient
+                    # read them); the real rows are recomputed from y where they are loaded.  The word bounds both.
+                    out = ops.bn_act_fwd(y, co, True, None, 0, 0, M, L.Fout, fake_rows=g)
+                    ops.act_bound(co[2], co[3], yword, ops.amax_of(out))
+                    fold = (y, co[2], co[3])
+                else:
+                    out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout,
+                                         classes=g if (g.classes and split) else None)
                 if net._tap is not None:          # test hook: raw conv output + BN scale/shift of every ReLU layer
                     yt = y
                     if g.classes and g.split:     # holes are never computed: show the class value, as the full net has it
@@ -296,7 +313,7 @@ class _MeshNetFn(torch.autograd.Function):
             if keep:
                 if bwd_fwdform:
                     T1 = T2 = None          # the backward never needs the basis of X (dW = X^T [g|Lg|L2g])
-                saved.append((cur, cur_shift, T1, T2, y, co, W3 if bwd_fwdform else W2))
+                saved.append((cur, cur_shift, T1, T2, y, co, W3 if bwd_fwdform else W2, fold_in))
             cur, cur_shift = out, 0
             if L.last_in_block:
                 if L.block == 0:                                      # fc lift (:104-106)
@@ -385,7 +402,7 @@ class _MeshNetFn(torch.autograd.Function):
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
-            X, x_shift, T1, T2, y, co, W2 = saved[L.ci]
+            X, x_shift, T1, T2, y, co, W2, fold_in = saved[L.ci]
             if L.last_in_block:
                 if L.block == 0:
                     # fc backward (meshnet.py:105-106): G is d(fc out) as [B*Vc, 64]
@@ -515,9 +532,13 @@ class _MeshNetFn(torch.autograd.Function):
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
-                with side_ctx(keep, X, gy, E1, E2):
-                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True,
-                                                   g_amax=ops.amax_of(gy, gph, B), g_bits=gph.plane_bits)
+                # X with the activation folded into its consumers (forward: ops.fold_act_ok): the real rows are read from the
+                # raw output of the previous conv, activated on load; X itself holds the fake rows and the bounding word
+                Xr, xact = (fold_in[0], (fold_in[1], fold_in[2])) if fold_in is not None else (X, None)
+                with side_ctx(keep, X, Xr, gy, E1, E2):
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, Xr, L.Fin, x_shift, [gy, E1, E2], L.Fout, True,
+                                                   a_amax=ops.amax_of(X) if xact is not None else None,
+                                                   g_amax=ops.amax_of(gy, gph, B), g_bits=gph.plane_bits, a_act=xact)
                     Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,

@@ -120,6 +120,11 @@ CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 # contraction on MI355X - forward-form launches (no planes written out) of the level's own / un-pooled plans on the big
 # levels; "1": wherever supported (the A/B form of the parity tests); "0": never.  DESIGN.md section 6 has the numbers:
 # 157 KB of LDS per block leave one block per CU, so the kernel only wins where the plane traffic it removes is large.
+# BatchNorm + ReLU applied WHERE THE CONSUMER LOADS (include/p2m.h "activation on load"): between the two convs of a block on
+# the levels the matrix-core tile kernel owns, the activated tensor x = relu(bn(y)) of the real vertices is never written:
+# the second conv's tile kernel and its weight gradient read the raw y and apply fma + max on the way into LDS; only the
+# (few) fake-vertex rows of x are still materialised for the effective-weight contraction.  0 = the separate pass (A/B form).
+FOLD_ACT = _os.environ.get("P2M_FOLD_ACT", "1") == "1"
 TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
 if TILE_GEMM not in ("auto", "0", "1"):
     raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
@@ -672,11 +677,14 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
 
 
 def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None,
-                   amax=None, amax_out=None):
+                   amax=None, amax_out=None, in_act=None):
     """C[rows of the plan] = [A0 | L X | L2 X] W (+bias)(+addend) in one kernel (include/p2m.h).  Returns
     (stats [B*ntiles, 2, N] or None, (E1, E2) compact planes or None).  f16x2: amax = the word bounding X and A0 (default:
-    X's own); amax_out: a zeroed word that receives the bound of what is stored."""
+    X's own); amax_out: a zeroed word that receives the bound of what is stored.  in_act = (scale[Ka], shift[Ka]):
+    activation on load - X / A0 hold a raw conv output y, the operand is relu(y * scale + shift); amax must bound THAT."""
     nset = g.n_pair_real if plan == 2 else g.n_real
+    if in_act is not None and amax is None:
+        raise P2MError("cheb_tile_gemm: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2() and amax is None:
         amax = amax_of(X, g if plan != 1 else None, B)
     st = torch.empty((B * g.plan_tiles[plan], 2, N), device=C.device, dtype=torch.float32) if stats else None
@@ -692,7 +700,9 @@ def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, w
                                             _p(addend if addend is None else _req(addend, "addend")), _p(C), N, _p(st),
                                             _p(E1), _p(E2), _p(None if act is None else act[0]),
                                             _p(None if act is None else act[1]), int(bool(act and act[2])),
-                                            _p(amax_out), B, _stream()), "p2m_cheb_tile_gemm")
+                                            _p(amax_out), _p(None if in_act is None else _req(in_act[0], "in_scale")),
+                                            _p(None if in_act is None else _req(in_act[1], "in_shift")), B, _stream()),
+              "p2m_cheb_tile_gemm")
     return st, ((E1, E2) if want_planes else None)
 
 
@@ -727,16 +737,40 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, amax_out=None):
     return P0, P1c, P2c
 
 
+def fold_act_ok(g, Ka, N, B):
+    """True when a conv with input width Ka and output width N on the (split) level g can take its input as a RAW conv
+    output with the activation applied on load (FOLD_ACT): its real rows run through the matrix-core tile kernel on the
+    level's own plan, without planes out (the weight gradient re-applies the activation itself)."""
+    return bool(FOLD_ACT and f16x2() and g.split and N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B))
+
+
+def act_bound(scale, shift, y_amax, word):
+    """word = max(word, bound of relu(y * scale + shift) given the amax word of y) (include/p2m.h p2m_act_bound)."""
+    check(_lib.hip().p2m_act_bound(_p(_req(scale, "scale")), _p(_req(shift, "shift")), scale.shape[0], _p(y_amax),
+                                   _p(word), _stream()), "p2m_act_bound")
+    return word
+
+
 def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, want_planes=True,
-               amax_out=None):
+               amax_out=None, in_act=None):
     """One split contraction: the real-vertex rows [X | L X | L2 X] Bm (K = 3*Ka), then the fake-vertex GEMM (K = Ka,
     W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's basis on a side
     stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
     planes of the real vertices (None unless want_planes), the BatchNorm partials of the two launches, and whether
     st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
-    (p2m_bn_finalize_split)."""
+    (p2m_bn_finalize_split).  in_act = (Y, scale, shift) - activation on load (fold_act_ok): the real rows read the raw conv
+    output Y and apply relu(y * scale + shift) in the tile kernel; X then only holds the activated FAKE rows and carries the
+    amax word that bounds the whole activated tensor."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
     xa = amax_of(X, g if a0_shift == 0 else None, B)
+    if in_act is not None:
+        if a0_shift != 0 or want_planes or not tile_gemm_ok(g, 0, Ka, N, False, B=B):
+            raise P2MError("conv_split: activation on load needs the tile kernel on the level's own plan (fold_act_ok)")
+        st1, _ = cheb_tile_gemm(g, 0, in_act[0], in_act[0], Ka, Bx, bias, addend, C, N, B, stats=stats, amax=xa,
+                                amax_out=amax_out, in_act=(in_act[1], in_act[2]))
+        st2 = gemm_planes_rows(g, 2, B, [X], Ka, 0, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
+                               amax_out=amax_out)
+        return None, None, st1, st2, True
     if tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
                                      want_planes=want_planes, amax=xa, amax_out=amax_out)
@@ -757,10 +791,13 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 TN_TARGET_BLOCKS = 768
 
 
-def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_amax=None, g_bits=0):
+def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_amax=None, g_bits=0, a_act=None):
     """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks).  f16x2: the amax
-    words of A and of the G planes (after g_bits binades); default: the tensors' own."""
+    words of A and of the G planes (after g_bits binades); default: the tensors' own.  a_act = (scale[Ka], shift[Ka]):
+    activation on load of A (a raw conv output); a_amax must then bound the activated operand."""
     n = g.set_size(row_set)
+    if a_act is not None and a_amax is None:
+        raise P2MError("gemm_tn_rows: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2():
         if a_amax is None:
             a_amax = amax_of(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
@@ -777,7 +814,9 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_
     with _timed("gemm_tn_mfma", (2.0 * B * n * Ka * N, 2.0 * B * n * Ka * N, 4.0 * B * n * (Ka + N))):
         check(_lib.hip().p2m_gemm_tn_rows(g.handle, row_set, B, _p(_req(A, "A")), Ka, a0_shift, gp[0], gp[1], gp[2],
                                           len(G), Gc, int(compact), splits, _p(P), _p(Pdb), arith_code(),
-                                          _p(a_amax), _p(g_amax), int(g_bits), _stream()),
+                                          _p(a_amax), _p(g_amax), int(g_bits),
+                                          _p(None if a_act is None else _req(a_act[0], "a_scale")),
+                                          _p(None if a_act is None else _req(a_act[1], "a_shift")), _stream()),
               "p2m_gemm_tn_rows")
     return P, Pdb, nch
 
@@ -936,7 +975,7 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_rows=None):
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_rows=None, fake_rows=None):
     """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped); real_rows: the level's
     DeviceGraph when only the REAL rows of y hold data (inference on the real rows): only those are walked.  f16x2: the
     output comes back tagged with the amax word of what was written."""
@@ -946,10 +985,13 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_row
     cls = classes.handle if (classes is not None and classes.classes) else None
     if real_rows is not None:
         cls = real_rows.handle
+    mode = 1 if real_rows is not None else 0
+    if fake_rows is not None:      # only the level's fake vertices (row set 2): what a consumer with activation on load reads
+        cls, mode = fake_rows.handle, 2
     word = new_amax(y.device) if (f16x2() and F % 4 == 0) else None
     check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
                                     _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),
-                                    _p(x), M, F, cls, int(real_rows is not None), _p(word), _stream()), "p2m_bn_act_fwd")
+                                    _p(x), M, F, cls, mode, _p(word), _stream()), "p2m_bn_act_fwd")
     if word is not None:
         tag_amax(x, word)
     return x
