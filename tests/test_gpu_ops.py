@@ -672,3 +672,69 @@ def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkey
     ops.cheb_tile_gemm(g, shift, X, X, Fin, Bx, bias, None, y, Fout, B)
     err = (y.view(B, V, Fout)[:, real].double() - yd[:, real]).abs().max().item()
     assert err < 2e-5 * max(1.0, yd.abs().max().item()), err
+
+
+@pytest.mark.parametrize("V,Fin,Fout,B", [(736, 128, 128, 5), (1472, 128, 64, 3), (2944, 64, 128, 2)])
+def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fin, Fout, B):
+    """include/p2m.h "activation on load" (lib/models/backbones/cheby_graph_conv.py:39 + lib/models/meshnet.py:100 folded into the
+    next conv's loads): the tile kernel and the weight-gradient contraction reading the RAW conv output y with
+    relu(y * scale + shift) applied between the global load and the LDS image give, bit for bit, what they give on the
+    tensor x that p2m_bn_act_fwd materialises (same two roundings, same amax word); the fake-rows-only activation pass
+    writes exactly the fake rows; p2m_act_bound really bounds the activated tensor."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
+    monkeypatch.setattr(ops, "TILE_GEMM", True)
+    L = _band_graph(V, 11 + V)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert ops.fold_act_ok(g, Fin, Fout, B)
+    gen = torch.Generator().manual_seed(V + Fin)
+    M = B * V
+    y = (torch.randn(M, Fin, generator=gen) * 3.0 + 0.7).cuda()
+    scale = (torch.randn(Fin, generator=gen) * 0.8).cuda()          # both signs, as trained BatchNorm weights may have
+    shift = torch.randn(Fin, generator=gen).cuda()
+    co = torch.stack((torch.zeros_like(scale), torch.ones_like(scale), scale, shift)).contiguous()
+    x = ops.bn_act_fwd(y, co, True, None, 0, 0, M, Fin)            # the separate pass: every row
+    real = torch.as_tensor(_real_ids(L), device="cuda")
+    fake = torch.ones(V, dtype=torch.bool, device="cuda")
+    fake[real] = False
+    # fake-rows-only pass: exactly the fake rows of x, nothing else written
+    xf = torch.full((M, Fin), float("nan"), device="cuda")
+    check = ops._lib.hip().p2m_bn_act_fwd
+    w_f = ops.new_amax("cuda:0")
+    ops.check(check(ops._p(y), ops._p(co[2]), ops._p(co[3]), 1, None, 0, 0, ops._p(xf), M, Fin, g.handle, 2, ops._p(w_f),
+                    ops._stream()), "p2m_bn_act_fwd")
+    assert torch.equal(xf.view(B, V, Fin)[:, fake], x.view(B, V, Fin)[:, fake])
+    assert torch.isnan(xf.view(B, V, Fin)[:, real]).all()
+    xf2 = ops.bn_act_fwd(y, co, True, None, 0, 0, M, Fin, fake_rows=g)
+    assert torch.equal(xf2.view(B, V, Fin)[:, fake], x.view(B, V, Fin)[:, fake])
+    # the bound: >= the true maximum, and not absurdly loose on this input
+    yw = ops.amax_of(y)
+    word = ops.amax_of(xf2)
+    ops.act_bound(co[2], co[3], yw, word)
+    bound = word.view(torch.float32).item()
+    true_max = x.abs().max().item()
+    assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
+    # forward: tile kernel on x vs on y with the activation on load, SAME amax word -> same slices -> same bits
+    Wt = (torch.randn(3 * Fin, Fout, generator=gen) / (3 * Fin) ** 0.5).cuda()
+    bias = torch.randn(Fout, generator=gen).cuda()
+    Bx = ops.weight_split(Wt)
+    c_ref = torch.zeros((M, Fout), device="cuda")
+    st_ref, _ = ops.cheb_tile_gemm(g, 0, x, x, Fin, Bx, bias, None, c_ref, Fout, B, stats=True, amax=word)
+    c = torch.zeros((M, Fout), device="cuda")
+    st, _ = ops.cheb_tile_gemm(g, 0, y, y, Fin, Bx, bias, None, c, Fout, B, stats=True, amax=word,
+                               in_act=(co[2], co[3]))
+    torch.cuda.synchronize()
+    assert torch.equal(c, c_ref) and torch.equal(st, st_ref)
+    # weight gradient: X^T [g | E1 | E2] over the real rows
+    gy = torch.randn(M, Fout, generator=gen).cuda()
+    E1, E2 = ops.cheb_basis_fwd_real(g, gy, B, Fout, 0)
+    ga = ops.amax_of(gy, g, B)
+    P_ref, Pb_ref, n_ref = ops.gemm_tn_rows(g, 1, B, x, Fin, 0, [gy, E1, E2], Fout, True, a_amax=word, g_amax=ga,
+                                            g_bits=g.plane_bits)
+    P, Pb, n = ops.gemm_tn_rows(g, 1, B, y, Fin, 0, [gy, E1, E2], Fout, True, a_amax=word, g_amax=ga,
+                                g_bits=g.plane_bits, a_act=(co[2], co[3]))
+    torch.cuda.synchronize()
+    assert n == n_ref and torch.equal(P, P_ref) and torch.equal(Pb, Pb_ref)
+    # the activation on load is refused where no kernel implements it
+    from pose2mesh_release_amd._lib import P2MError
+    with pytest.raises(P2MError):
+        ops.cheb_tile_gemm(g, 0, y, y, Fin, Bx, bias, None, c, Fout, B, want_planes=True, amax=word, in_act=(co[2], co[3]))

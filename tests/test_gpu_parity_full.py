@@ -297,12 +297,15 @@ def test_baseline_sizes_train_forward_vs_oracle(hip_libs, joint_set, B, seeds):
 
 
 @pytest.mark.parametrize("env,fwd_bitwise", [({"P2M_CLASSES": "0"}, False), ({"P2M_PAIR_BWD": "0"}, True),
-                                             ({"P2M_TILE_GEMM": "1"}, False), ({"P2M_TILE_GEMM": "0"}, False)])
+                                             ({"P2M_TILE_GEMM": "1"}, False), ({"P2M_TILE_GEMM": "0"}, False),
+                                             ({"P2M_FOLD_ACT": "0"}, False)])
 def test_algebraic_shortcuts_against_their_plain_forms(hip_libs, tmp_path, env, fwd_bitwise):
     """The default path's exact algebraic shortcuts -- classes of identical fake rows (only one representative of a run of
     identical padding rows is computed), the backward of un-pooled convs at the coarse resolution -- and the opt-in
     basis-inside-the-contraction kernel everywhere (1) / nowhere (0) instead of on the big levels' forward only (auto),
-    each against the same network with the knob flipped (child process; human36, B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
+    the BatchNorm + ReLU between the two convs of a block as its own pass (P2M_FOLD_ACT=0) instead of applied where the second
+    conv loads its input (same operand values, but the amax word of the folded operand is a bound, not the exact maximum:
+    the fp16 slices are cut at another binade) - each against the same network with the knob flipped (child process; human36, B=3, train).  P2M_PAIR_BWD=0 also switches the classes off (they need the paired operator)."""
     out = str(tmp_path / "plain.npz")
     r = subprocess.run([sys.executable, os.path.join(HERE, "_child_meshnet_run.py"), out, "human36", "3", "train",
                         "13", "21", "5"], env=dict(os.environ, P2M_TEST_TAP="1", **env), capture_output=True,
