@@ -212,6 +212,7 @@ class _MeshNetFn(torch.autograd.Function):
         nblk = len(net.CL_F)
         block_in, block_in_shift, block_in_F = None, 0, 0
         fc_saved = None
+        nbt = []           # num_batches_tracked of every BatchNorm that ran on batch statistics: incremented in ONE launch
         fold = None        # activation on load: (raw output y, scale, shift) of the previous conv when `cur` holds only its
                            # activated FAKE rows (ops.fold_act_ok) - consumed by the very next conv
         for L in net._layers:
@@ -238,11 +239,12 @@ class _MeshNetFn(torch.autograd.Function):
             need_stats = L.has_bn and training
             bwd_fwdform = _bwd_forward_form(L)
             split = g.split and bwd_fwdform
-            batched = split and cws is not None and L.ci in cws.images
-            # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache); the split
+            images = cws is not None and L.ci in cws.images      # this conv's slice images come from the batched set
+            batched = split and images
+            # packed / transposed weights: constant between optimizer steps -> cached per layer (ops.WeightCache); the
             # convs of the slice arithmetics read nothing but the images of `cws`: W stands in for the fp32 operands
             want_w3 = bwd_fwdform
-            if batched:
+            if images:
                 Wt, W2, W3 = W, None, W
             else:
                 Wt, W2, W3 = wc.get((L.ci, "pack"), W, lambda: ops.weight_pack(W, L.Fin, K_CHEB, need_w2=not want_w3,
@@ -265,8 +267,11 @@ class _MeshNetFn(torch.autograd.Function):
                 tile_rows = ("tiles", cur_shift) if tiled else "rows"
             else:
                 T1, T2 = ops.cheb_basis_fwd(g, cur, B, L.Fin, cur_shift)
-                Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W)))) \
-                    if (L.Fin % 32 == 0 and L.Fout % 32 == 0) else None
+                if images:
+                    Wtx = cws.images[L.ci][0]
+                else:
+                    Wtx = wc.get((L.ci, "wtx"), W, lambda: ops.weight_split(Wt, wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W)))) \
+                        if (L.Fin % 32 == 0 and L.Fout % 32 == 0) else None
                 (y,), st = ops.gemm_planes([cur, T1, T2], L.Fin, cur_shift, Wt, bvec, M, L.Fout, 1, need_stats, Bx=Wtx,
                                            amax=ops.amax_of(cur), amax_bits=g.plane_bits)
                 tile_rows = None
@@ -279,15 +284,15 @@ class _MeshNetFn(torch.autograd.Function):
                 if training and isinstance(tile_rows, tuple):
                     co = ops.bn_finalize_tiles(g, tile_rows[1], B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
                                                bn_momentum(bn), bn.eps)
-                    bn.num_batches_tracked.add_(1)
+                    nbt.append(bn.num_batches_tracked)
                 elif training and tile_rows == "rows":
                     co = ops.bn_finalize_rows(g, B, st, st2, gamma, beta, bn.running_mean, bn.running_var,
                                               bn_momentum(bn), bn.eps)
-                    bn.num_batches_tracked.add_(1)
+                    nbt.append(bn.num_batches_tracked)
                 elif training:
                     co = ops.bn_finalize(st, M, gamma, beta, bn.running_mean, bn.running_var, bn_momentum(bn), bn.eps,
                                          tile_rows)
-                    bn.num_batches_tracked.add_(1)
+                    nbt.append(bn.num_batches_tracked)
                 else:
                     co = ops.bn_eval_coeffs(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
                 resid = None
@@ -327,6 +332,8 @@ class _MeshNetFn(torch.autograd.Function):
                     cur = ops.view_tagged(u, B * net._Vc, net.CL_F[1][0])
                 elif L.block < nblk - 2:                              # virtual x2 un-pool (:111)
                     cur_shift = 1
+        if nbt:
+            torch._foreach_add_(nbt, 1)      # nn.BatchNorm1d.forward's `num_batches_tracked += 1`, 20 launches as one
         V0 = graphs[0].V
         ctx.net, ctx.saved, ctx.fc_saved, ctx.B, ctx.training, ctx.cws = net, saved, fc_saved, B, training, cws
         ctx.n_params = len(params)
@@ -555,8 +562,11 @@ class _MeshNetFn(torch.autograd.Function):
                 # gather (12.5 rows/row) replaces the two-source gather of p2m_cheb_basis_bwd (25 rows/row).
                 E1, E2 = ops.cheb_basis_fwd(gph, gy, B, L.Fout, 0)
                 Wl = params[P[f"cl.{L.ci}.weight"]]
-                W3x = wc.get((L.ci, "w3x"), Wl, lambda: ops.weight_split(
-                    W2, wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
+                if cws is not None and L.ci in cws.images:
+                    W3x = cws.images[L.ci][2]
+                else:
+                    W3x = wc.get((L.ci, "w3x"), Wl, lambda: ops.weight_split(
+                        W2, wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
                 (dX,), _ = ops.gemm_planes([gy, E1, E2], L.Fout, 0, W2, None, M, L.Fin, 1, False,
                                            addend=G if fuse_res else None, pair_out=bool(x_shift), Bx=W3x,
                                            amax=ops.amax_of(gy), amax_bits=gph.plane_bits)
@@ -717,8 +727,11 @@ class Pose2Mesh(nn.Module):
         cws = self._conv_weight_sets.get(key)
         if cws is None:
             P = self._param_index
+            # every conv whose contractions read slice images: the split convs (four images each) and the unsplit
+            # MFMA-shaped ones of the coarse levels (they use the forward / backward image; their effective-weight images
+            # are computed along and never read - cheaper than ~4 extra launches per layer and step)
             ent = [(L.ci, params[P[f"cl.{L.ci}.weight"]], graphs[L.graph].fake_a, graphs[L.graph].fake_b)
-                   for L in self._layers if graphs[L.graph].split and _bwd_forward_form(L) and not _narrow(L)]
+                   for L in self._layers if _bwd_forward_form(L) and not _narrow(L)]
             cws = ops.ConvWeightSet(ent, device) if ent else False
             self._conv_weight_sets[key] = cws
         if cws is False:
