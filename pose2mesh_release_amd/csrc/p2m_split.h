@@ -75,15 +75,25 @@ __device__ __forceinline__ float exp2_int(int s) { return __uint_as_float((unsig
 __device__ __forceinline__ unsigned pack_f16_rne(float a, float b) {      // v_cvt_pk_f16_f32 (round to nearest even)
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
 }
-// Four consecutive-k values -> their two slices, packed.  12 VALU instructions per 4 values: 4 v_mul, 2 v_cvt_pk_f16_f32,
-// 4 v_fma_mix_f32 (x sc - float(h) in one exact fma), 2 v_cvt_pk_f16_f32 - against 22 for split3_pack4.
+// Four consecutive-k values -> their two slices, packed.  8 VALU instructions per 4 values (round 4; 12 before: 4 v_mul,
+// 2 v_cvt_pk_f16_f32, 4 v_fma_mix_f32, 2 v_cvt_pk_f16_f32): the mixed-precision fma writes its f16 result straight into one
+// half of the destination, so   h = fp16(x sc)          is v_fma_mixlo_f16 / v_fma_mixhi_f16 (x, sc, 0)   and
+//                               l = fp16(x sc - h)      is v_fma_mixlo_f16 / v_fma_mixhi_f16 (x, sc, -h as an f16 source)
+// - the same values bit for bit: x sc is exact (sc is a power of two), the fp32 fma x sc - h is exact (h carries the top 11
+// bits of x sc), and each result is rounded to fp16 once, to nearest even.  The contractions are issue-bound (every
+// staging instruction delays an MFMA of the co-resident wave): a third fewer split instructions in every producer.
 __device__ __forceinline__ void split2_pack4(float x0, float x1, float x2, float x3, float sc, u32x2& ph, u32x2& pl) {
-  const float y0 = x0 * sc, y1 = x1 * sc, y2 = x2 * sc, y3 = x3 * sc;
-  const unsigned h01 = pack_f16_rne(y0, y1), h23 = pack_f16_rne(y2, y3);
-  const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
-  const float r0 = y0 - (float)a[0], r1 = y1 - (float)a[1], r2 = y2 - (float)b[0], r3 = y3 - (float)b[1];
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h01) : "v"(x0), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h01) : "v"(x1), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h23) : "v"(x2), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h23) : "v"(x3), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(x0), "v"(sc), "v"(h01));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(x1), "v"(sc), "v"(h01));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(x2), "v"(sc), "v"(h23));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(x3), "v"(sc), "v"(h23));
   ph = u32x2{h01, h23};
-  pl = u32x2{pack_f16_rne(r0, r1), pack_f16_rne(r2, r3)};
+  pl = u32x2{l01, l23};
 }
 // both cuts behind one name: sl[0] = high slice ... sl[NS - 1] = low slice
 template <int NS>

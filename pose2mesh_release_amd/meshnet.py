@@ -258,7 +258,9 @@ class _MeshNetFn(torch.autograd.Function):
                                                                       wc.get((L.ci, "amax"), W, lambda: ops.param_amax(W))))
                 # does the NEXT conv take this one's activation on load?  Then y's amax word is needed for the bound
                 Ln = net._layers[L.ci + 1] if L.ci + 1 < len(net._layers) else None
-                fold_out = (L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
+                # (train mode only: the folded operand is scaled from a BOUND of its maximum, the separate pass from the exact
+                #  maximum - in eval() the general path stays bitwise the real-rows-only inference path, tests/test_gpu_infer.py)
+                fold_out = (training and L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
                             and not _narrow(Ln) and _bwd_forward_form(Ln) and ops.fold_act_ok(g, Ln.Fin, Ln.Fout, B))
                 yword = ops.new_amax(cur.device) if fold_out else None
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,

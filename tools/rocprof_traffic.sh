@@ -13,7 +13,7 @@ TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$REPO/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-ARGS="${*:---steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing}"
+ARGS="${*:---steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-arith-ab --also none}"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_${TAG}_$C
   timeout -k 5 ${PMC_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/tr_${TAG}_$C -o $TAG -- python "$REPO/bench.py" $ARGS > "$REPO/gpurun_out/${TAG}_traffic_$C.log" 2>&1
