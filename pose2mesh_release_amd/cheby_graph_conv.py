@@ -97,6 +97,44 @@ class _ChebConvFn(torch.autograd.Function):
         return dX.view(xshape), dW, db, dgamma, dbeta, None, None, None
 
 
+class _LApplyFn(torch.autograd.Function):
+    """y = L x on the vertex axis (the L plane of p2m_cheb_basis_fwd); L is symmetric (lib/coarsening.py:23), so the
+    backward is the same product."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        B, V, F = x.shape
+        ctx.g, ctx.B, ctx.F = g, B, F
+        with torch.cuda.device(x.device):
+            T1, _ = ops.cheb_basis_fwd(g, x.contiguous().float().view(B * V, F), B, F, 0)
+        return T1.view(B, V, F)
+
+    @staticmethod
+    def backward(ctx, gout):
+        with torch.cuda.device(gout.device):
+            T1, _ = ops.cheb_basis_fwd(ctx.g, gout.contiguous().float().view(-1, ctx.F), ctx.B, ctx.F, 0)
+        return T1.view_as(gout), None
+
+
+def _graph_conv_cheby_any_order(x, cl, bn, g, Fout, K):
+    """Chebyshev orders K > 3 (lib/models/backbones/cheby_graph_conv.py:27-30 is generic in K; Pose2Mesh itself uses K = 3
+    everywhere, which is what the fused kernels are built for): the recurrence T_k = 2 L T_(k-1) - T_(k-2) on the HIP
+    L-product, then the reference's own (B*V, Fin*K) layout, column fin*K + k (:32-34), through nn.Linear / BatchNorm1d."""
+    B, V, Fin = x.shape
+    x0 = x.float()
+    planes = [x0]
+    x1 = _LApplyFn.apply(x0, g)
+    planes.append(x1)
+    for _ in range(2, K):
+        x2 = 2 * _LApplyFn.apply(x1, g) - x0
+        planes.append(x2)
+        x0, x1 = x1, x2
+    y = cl(torch.stack(planes, dim=3).reshape(B * V, Fin * K))
+    if bn is not None:
+        y = bn(y)
+    return y.view(B, V, Fout)
+
+
 def graph_conv_cheby(x, cl, bn, L, Fout, K):
     if not x.is_cuda:
         raise P2MError("graph_conv_cheby (HIP) needs GPU tensors; this package has no CPU path")
@@ -104,10 +142,14 @@ def graph_conv_cheby(x, cl, bn, L, Fout, K):
     if cl.weight.shape != (Fout, Fin * K):
         raise P2MError(f"cl.weight is {tuple(cl.weight.shape)}, expected {(Fout, Fin * K)}")
     g = _device_graph(L, x.device)
+    if V != g.V:
+        raise P2MError(f"x has {V} vertices but the graph has {g.V}")
     weight = cl.weight
+    if K > 3:
+        return _graph_conv_cheby_any_order(x, cl, bn, g, Fout, K)
     if K != 3:
         if K not in (1, 2):
-            raise NotImplementedError("Chebyshev order K > 3 is not implemented (Pose2Mesh uses K = 3 everywhere)")
+            raise P2MError(f"Chebyshev order K must be a positive integer, not {K}")
         pad = weight.new_zeros(Fout, Fin, 3)
         weight = torch.cat((weight.view(Fout, Fin, K), pad[:, :, K:]), dim=2).reshape(Fout, Fin * 3)
     bias = cl.bias if cl.bias is not None else x.new_zeros(Fout)

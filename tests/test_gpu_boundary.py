@@ -242,3 +242,32 @@ def test_demo_single_pose_plumbing(hip_libs):
     assert mesh.shape == (1, 6890, 3)
     assert helpers.max_vertex_l2(mesh.cpu(), z["mesh"]) <= 1e-4
     assert np.abs(joints.cpu().numpy() - z["joints"]).max() <= 1e-4
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (nn.DataParallel replicas on different devices)")
+def test_data_parallel_two_gpus_tile_kernels_on_both_devices(hip_libs):
+    """nn.DataParallel (lib/core/base.py:108) runs one host thread per GPU through the library.  The 152 KB-LDS
+    tile kernels need hipFuncSetAttribute(MaxDynamicSharedMemorySize) PER DEVICE (chebtile.hip DeviceOnce), the graph
+    handles, weight images and amax chunks are per device: a train-mode forward + backward of the SMPL-like network split
+    over two devices runs and matches, per half, the bare module on the same samples (per-replica BatchNorm statistics, as
+    DataParallel replicas have)."""
+    from pose2mesh_release_amd import meshnet
+    gL, _, _ = helpers.golden_graphs("human36")
+    J = gL[-1].shape[0]
+    net = meshnet.get_model(5, 3, gL, mano=False)
+    sd = helpers.numpy_state(net.state_dict(), 3)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    x = helpers.meshnet_input(4, J, seed=12).cuda()
+    dp = torch.nn.DataParallel(net, device_ids=[0, 1])
+    out = dp(x)
+    out.square().sum().backward()
+    g_dp = {k: p.grad.clone() for k, p in net.named_parameters()}
+    assert out.shape == (4, gL[0].shape[0], 3) and all(torch.isfinite(v).all() for v in g_dp.values())
+    halves = []
+    for dev, sl in ((0, slice(0, 2)), (1, slice(2, 4))):
+        ref = meshnet.get_model(5, 3, gL, mano=False)
+        ref.load_state_dict(sd)
+        ref = ref.to(f"cuda:{dev}").train()
+        halves.append(ref(x[sl].to(f"cuda:{dev}")).detach().to("cuda:0"))
+    assert helpers.max_vertex_l2(out.detach().cpu(), torch.cat(halves).cpu()) <= 1e-5

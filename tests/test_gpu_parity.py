@@ -114,8 +114,36 @@ def test_graph_conv_cheby_low_orders_and_inputs(hip_libs):
         ref = mo.graph_conv_cheby(x, cl.weight.detach(), cl.bias.detach(), None, Lt, K, False)
         y = graph_conv_cheby(x.cuda(), cl.cuda(), None, Lt, 64, K)
         assert (y.cpu() - ref).abs().max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        graph_conv_cheby(torch.zeros(1, L.shape[0], 4).cuda(), torch.nn.Linear(16, 8).cuda(), None, Lt, 8, 4)
+
+
+@pytest.mark.parametrize("K", [4, 6])
+def test_graph_conv_cheby_higher_orders_vs_oracle(hip_libs, K):
+    """cheby_graph_conv.py:27-30 is generic in K: orders above 3 (which Pose2Mesh never uses) run the recurrence on the HIP
+    L-product; forward, BatchNorm statistics and every gradient against the oracle's sparse-mm form."""
+    from pose2mesh_release_amd.cheby_graph_conv import graph_conv_cheby
+    gL, _, _ = helpers.golden_graphs("mano")
+    L = gL[3]
+    Lt = mo.scipy_to_torch_coo(L)
+    gen = torch.Generator().manual_seed(40 + K)
+    x = torch.randn(3, L.shape[0], 16, generator=gen)
+    cl = torch.nn.Linear(16 * K, 24)
+    bn = torch.nn.BatchNorm1d(24)
+    w = torch.randn(3, L.shape[0], 24, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    wr, br = cl.weight.detach().clone().requires_grad_(True), cl.bias.detach().clone().requires_grad_(True)
+    bnd = {"weight": bn.weight.detach().clone().requires_grad_(True), "bias": bn.bias.detach().clone().requires_grad_(True),
+           "running_mean": bn.running_mean.clone(), "running_var": bn.running_var.clone()}
+    ref = mo.graph_conv_cheby(xr, wr, br, bnd, Lt, K, True)
+    (ref * w).sum().backward()
+    cl, bn = cl.cuda(), bn.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    y = graph_conv_cheby(xg, cl, bn, Lt, 24, K)
+    (y * w.cuda()).sum().backward()
+    assert (y.detach().cpu() - ref.detach()).abs().max() < 2e-5
+    assert helpers.rel_l2(xg.grad.cpu(), xr.grad) < 1e-4
+    assert helpers.rel_l2(cl.weight.grad.cpu(), wr.grad) < 1e-4
+    assert helpers.rel_l2(bn.weight.grad.cpu(), bnd["weight"].grad) < 1e-4
+    assert (bn.running_var.cpu() - bnd["running_var"]).abs().max() < 1e-5
 
 
 @pytest.mark.parametrize("joint_set,B", [("mano", 5), ("human36", 3)])
