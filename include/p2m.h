@@ -215,10 +215,8 @@ int p2m_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  * act = ReLU if relu!=0; scale/shift may be NULL (identity); resid may be NULL.
  * lerp_F is F.interpolate(mode='linear', align_corners=False) along the FEATURE axis
  * (meshnet.py:109,114).  Rows: all M; with `classes` (a level's handle) the live rows of a level with declared
- * classes (holes are skipped); with real_rows_only = 1 only the handle's real vertices (inference on the real rows:
- * the other rows of y hold no data and x's stay untouched); real_rows_only = 2: only the handle's FAKE vertices (row set 2:
- * one representative per class once classes are declared) - the rows a consumer with activation on load still reads from x.
- * amax_out (optional, F % 4 == 0): atomic max of |x stored|
+ * classes (holes are skipped); with real_rows_only != 0 only the handle's real vertices (inference on the real rows:
+ * the other rows of y hold no data and x's stay untouched).  amax_out (optional, F % 4 == 0): atomic max of |x stored|
  * into a zeroed amax word (P2M_ARITH_F16X2 above) - the bound for the contraction that consumes x.                  */
 int p2m_bn_act_fwd(const float* y, const float* scale, const float* shift, int32_t relu,
                    const float* resid, int32_t Fres, int32_t res_shift,
@@ -266,7 +264,7 @@ int p2m_lerp_bwd_add(const float* g, float* dst, int64_t M, int32_t F, int32_t F
  * rows (the reference includes fake vertices, cheby_graph_conv.py:39): p2m_bn_finalize_rows merges both launches. */
 int p2m_graph_split_info(p2m_graph_t g, int32_t counts[2] /* n_real, n_fake */, float coef[2] /* a, b */);
 int p2m_cheb_basis_fwd_real(p2m_graph_t g, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
-                            int32_t in_shift, void* stream);
+                            int32_t in_shift, const float* act_scale /* or NULL */, const float* act_shift, void* stream);
 /* ---- paired operator: the backward of an un-pooled conv at the COARSE resolution ------------------------------
  * A conv whose input was un-pooled x2 (meshnet.py:71-78,111) sees X_fine[r] = X_coarse[r >> 1], so with S = the
  * pair-sum (the un-pool's transpose) and L symmetric:
@@ -282,13 +280,16 @@ int p2m_graph_pair_info(p2m_graph_t g, int32_t counts[2] /* n_pair_real, n_pair_
 int p2m_graph_plan_info(p2m_graph_t g, int32_t ntiles[3]);
 int p2m_cheb_basis_pair(p2m_graph_t g, const float* G, float* P1c, float* P2c, int32_t B, int32_t F, void* stream);
 /* C[b*V + ids[i], :] = [A0[..] | A1 | A2] Bm + bias (+ addend): A0 is read at the actual row (>> a0_shift), A1/A2 at
- * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.                  */
+ * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.  in_scale / in_shift [Ka]
+ * (optional; slice arithmetics, Ka <= 256): activation on load of PLANE 0, as in p2m_cheb_tile_gemm - A0 holds the raw
+ * output y of the previous conv and the operand is max(fma(y, in_scale[k], in_shift[k]), 0) (A1 / A2 are then the planes
+ * p2m_cheb_basis_fwd_real formed with the same act_scale / act_shift); a_amax must bound the activated operand.      */
 int p2m_gemm_planes_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A0, const float* A1,
                          const float* A2, int32_t nplanesA, int32_t Ka, int32_t a0_shift, int32_t planes_compact,
                          const float* Bm, const void* Bsplit, int32_t arith, const void* a_amax, int32_t a_bits,
                          const float* bias, const float* addend, float* C,
                          int32_t N, float* stats, const float* act_scale, const float* act_shift, int32_t act_relu,
-                         void* amax_out, void* stream);
+                         void* amax_out, const float* in_scale /* or NULL */, const float* in_shift, void* stream);
 int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.  a_scale / a_shift [Ka] (optional, slice

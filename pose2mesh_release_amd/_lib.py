@@ -33,12 +33,12 @@ HIP_SYMBOLS = {
     "p2m_weight_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_weight_grad_unpack": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "p2m_graph_split_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2), _c.POINTER(_f32 * 2)]),
-    "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "p2m_cheb_basis_fwd_real": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "p2m_graph_pair_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 2)]),
     "p2m_graph_plan_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_cheb_basis_pair": (_c.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "p2m_gemm_planes_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32,
-                                        _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
+                                        _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "p2m_rows_tiles_per_sample": (_i32, [_vp, _i32]),
     "p2m_gemm_tn_rows": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp,
                                     _i32, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -476,7 +476,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int LPR>
 __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float* __restrict__ X,
                                                         float* __restrict__ T1, float* __restrict__ T2, int B, int F,
-                                                        long x_rows, int nset, int spb) {
+                                                        long x_rows, int nset, int spb,
+                                                        const float* __restrict__ in_scale = nullptr,
+                                                        const float* __restrict__ in_shift = nullptr) {
   constexpr int NT = 512;
   constexpr int FB = LPR * 4;                 // features per slice
   constexpr int RPI = NT / LPR;               // rows the block touches per instruction
@@ -521,13 +523,25 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
 #pragma unroll
     for (int q = 0; q < NPF; q++) pf[q] = *reinterpret_cast<const f32x4v*>(Xb + xoff[q]);
   };
+  // activation on load (include/p2m.h): X holds a raw conv output y, the gathered operand is max(fma(y, scale, shift), 0) -
+  // applied to the union rows on their way into LDS; this lane's four features are fixed for the whole kernel
+  f32x4v asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+  if (in_scale != nullptr) {
+    asc = *reinterpret_cast<const f32x4v*>(in_scale + l4);
+    ash = *reinterpret_cast<const f32x4v*>(in_shift + l4);
+  }
   issue(b0);
   for (int b = b0; b < b1; b++) {
     __syncthreads();                          // tables ready / the previous sample's LDS reads are done
 #pragma unroll
     for (int q = 0; q < NPF; q++) {
       const int u = grp + q * RPI;
-      if (u < U) *reinterpret_cast<f32x4v*>(&xs[u * FB + lf]) = pf[q];
+      f32x4v v = pf[q];
+      if (in_scale != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = fmaxf(fmaf(v[c], asc[c], ash[c]), 0.f);
+      }
+      if (u < U) *reinterpret_cast<f32x4v*>(&xs[u * FB + lf]) = v;
     }
     __syncthreads();
     issue(b + 1 < b1 ? b + 1 : b);            // unconditional (the last one re-reads sample b: harmless)
@@ -572,7 +586,8 @@ __global__ __launch_bounds__(512, 2) void k_basis_tile(TilePlan pl, const float*
 }  // namespace p2m
 
 static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,
-                            int32_t in_shift, int real_only, void* stream) {
+                            int32_t in_shift, int real_only, void* stream, const float* act_sc = nullptr,
+                            const float* act_sh = nullptr) {
   const Graph& g = *reinterpret_cast<const Graph*>(gh);
   hipStream_t s = (hipStream_t)stream;
   const int* ids = real_only ? g.real_ids : nullptr;
@@ -583,10 +598,15 @@ static int basis_fwd_launch(p2m_graph_t gh, const float* X, float* T1, float* T2
     const int spb = basis_spb();
     const long x_rows = g.V >> in_shift;
     const dim3 grid(cdiv((long)pl.ntiles * cdiv(B, spb) * (F >= 128 ? F / 128 : 1), 8) * 8);
-    if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
-    else if (F == 64) hipLaunchKernelGGL(k_basis_tile<16>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
-    else hipLaunchKernelGGL(k_basis_tile<32>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb);
+    if (F == 32) hipLaunchKernelGGL(k_basis_tile<8>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb, act_sc, act_sh);
+    else if (F == 64) hipLaunchKernelGGL(k_basis_tile<16>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb, act_sc, act_sh);
+    else hipLaunchKernelGGL(k_basis_tile<32>, grid, dim3(512), 0, s, pl, X, T1, T2, B, F, x_rows, nset, spb, act_sc, act_sh);
     return check_launch("cheb_basis_fwd(tiled)");
+  }
+  if (act_sc != nullptr) {
+    set_error("p2m_cheb_basis_fwd_real: activation on load exists in the tile-plan kernel only (this level / width / "
+              "P2M_BASIS_TILED setting takes the row kernel)");
+    return P2M_ERR_INVALID;
   }
   const int tps = cdiv(nset, ROWS_PER_BLOCK);
   auto grid = [&](int lpr) { return dim3(cdiv(B, 64 / lpr) * tps); };
@@ -622,11 +642,12 @@ extern "C" int p2m_cheb_basis_pair(p2m_graph_t gh, const float* G, float* P1c, f
 }
 
 extern "C" int p2m_cheb_basis_fwd_real(p2m_graph_t gh, const float* X, float* T1c, float* T2c, int32_t B, int32_t F,
-                                       int32_t in_shift, void* stream) {
+                                       int32_t in_shift, const float* act_scale, const float* act_shift, void* stream) {
   P2M_CHECK_ARG(gh && X && T1c && T2c && F > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(in_shift == 0 || in_shift == 1, "in_shift must be 0 or 1");
+  P2M_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "act_scale / act_shift must both be given or both NULL");
   if (B <= 0) return P2M_OK;
-  return basis_fwd_launch(gh, X, T1c, T2c, B, F, in_shift, 1, stream);
+  return basis_fwd_launch(gh, X, T1c, T2c, B, F, in_shift, 1, stream, act_scale, act_shift);
 }
 
 extern "C" int p2m_cheb_basis_fwd(p2m_graph_t gh, const float* X, float* T1, float* T2, int32_t B, int32_t F,

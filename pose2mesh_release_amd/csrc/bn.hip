@@ -987,14 +987,7 @@ extern "C" int p2m_bn_act_fwd(const float* y, const float* scale, const float* s
       const long rows_per_block = (long)(256 / F4) * ACT_UNROLL * ACT_PASSES;
       RowMap m;
       long Mlog;
-      if (real_rows_only == 2) {          // the fake vertices only (row set 2: class representatives once declared)
-        const Graph& g = *reinterpret_cast<const Graph*>(classes);
-        const RowSet rs = row_set_of(g, 2);
-        P2M_CHECK_ARG(M % g.V == 0 && M < (1LL << 32), "M is not a multiple of the level's vertex count");
-        if (rs.n == 0) return P2M_OK;
-        m.w = nullptr; m.ids = rs.ids; m.n = (unsigned)rs.n; m.V = (unsigned)g.V;
-        Mlog = (M / g.V) * (long)rs.n;
-      } else if (real_rows_only) {        // inference on the real rows: the other rows of y hold no data
+      if (real_rows_only) {               // inference on the real rows: the other rows of y hold no data
         const Graph& g = *reinterpret_cast<const Graph*>(classes);
         P2M_CHECK_ARG(M % g.V == 0 && M < (1LL << 32) && g.n_real > 0, "M is not a multiple of the level's vertex count");
         m.w = nullptr; m.ids = g.real_ids; m.n = (unsigned)g.n_real; m.V = (unsigned)g.V;

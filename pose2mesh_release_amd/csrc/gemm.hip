@@ -58,6 +58,9 @@ struct GemmArgs {
   const unsigned* b_amax;
   int a_bits;
   unsigned* amax_out;    // optional: receives max |value stored| (atomic max; the caller zeroes it)
+  // activation on load of A plane 0 (k_gemm_planes_ws, Ka <= 256): the operand is max(fma(A0, in_scale[k], in_shift[k]), 0)
+  const float* in_scale;
+  const float* in_shift;
 };
 
 // blockIdx -> (m tile, n tile).  Blocks b, b+8, b+16.. share an XCD (observed dispatch: b % 8);
@@ -362,12 +365,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   constexpr int B_BUF = NS * BN * LDX;
   constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0);
   __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
+  __shared__ __attribute__((aligned(16))) float actco[2 * 256];        // activation on load: scale | shift of plane 0's columns
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);
   unsigned short* Bs = As + NBUF * A_BUF;
   int* rowtab = reinterpret_cast<int*>(smem + NBUF * (A_BUF + B_BUF) / 2);
 
   int mt, nt;
   if (!tile_of_block(blockIdx.x, g.ntm, g.ntn, mt, nt)) return;
+  const bool in_act = g.in_scale != nullptr;                             // block-uniform
+  if (in_act) {
+    if (threadIdx.x < g.Ka) {
+      actco[threadIdx.x] = g.in_scale[threadIdx.x];
+      actco[256 + threadIdx.x] = g.in_shift[threadIdx.x];
+    }
+    __syncthreads();            // (LDS, not a second global load per chunk: the staging waves' vmcnt bookkeeping stays as it is)
+  }
   const long m0 = (long)mt * BM;
   const int n0 = nt * BN;
   const int t = threadIdx.x;
@@ -466,6 +478,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
       unsigned short* as = As + buf * A_BUF;
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) asm volatile("" : "+v"(a[ps]));
+      if (in_act && kc < cpp) {                  // plane 0 (chunks 0 .. cpp - 1): BatchNorm + ReLU of the previous conv on load
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&actco[kc * KB + a_k4]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&actco[256 + kc * KB + a_k4]);
+#pragma unroll
+        for (int ps = 0; ps < APASS; ps++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) a[ps][e] = fmaxf(fmaf(a[ps][e], sc[e], sh[e]), 0.f);
+      }
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
         u32x2 sl[NS];
@@ -1548,6 +1568,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.Bx = nullptr; g.Npad = 0; g.Ktot = 0;
   g.a_amax = g.b_amax = nullptr; g.a_bits = 0;
   g.amax_out = static_cast<unsigned*>(amax_out);
+  g.in_scale = g.in_shift = nullptr;
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % BK == 0) && (g.N % 32 == 0) && (Nc % 32 == 0);
   if (!mfma_ok) {
@@ -1584,8 +1605,12 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
                                     int32_t planes_compact, const float* Bm, const void* Bsplit, int32_t arith,
                                     const void* a_amax, int32_t a_bits, const float* bias,
                                     const float* addend, float* C, int32_t N, float* stats, const float* act_scale,
-                                    const float* act_shift, int32_t act_relu, void* amax_out, void* stream) {
+                                    const float* act_shift, int32_t act_relu, void* amax_out, const float* in_scale,
+                                    const float* in_shift, void* stream) {
   P2M_CHECK_ARG(gh && A0 && Bm && C, "null pointer");
+  P2M_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must both be given or both NULL");
+  P2M_CHECK_ARG(in_scale == nullptr || (arith != P2M_ARITH_F32 && Ka <= 256),
+                "activation on load exists in the slice arithmetics only, for Ka <= 256");
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || Bsplit != nullptr, "the slice arithmetics need the pre-split weight (p2m_weight_split)");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || a_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of the A planes");
@@ -1616,6 +1641,7 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
     g.b_amax = weight_amax_word(Bsplit, arith, g.Npad, g.Ktot);
   }
   g.amax_out = static_cast<unsigned*>(amax_out);
+  g.in_scale = in_scale; g.in_shift = in_shift;
   g.M = (long)B * g.tps * BM;       // logical (padded) rows; validity comes from the row table
   g.ntm = B * g.tps;
   launch_gemm_planes<true>(g, addend != nullptr, (hipStream_t)stream);

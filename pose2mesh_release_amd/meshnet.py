@@ -213,8 +213,9 @@ class _MeshNetFn(torch.autograd.Function):
         block_in, block_in_shift, block_in_F = None, 0, 0
         fc_saved = None
         nbt = []           # num_batches_tracked of every BatchNorm that ran on batch statistics: incremented in ONE launch
-        fold = None        # activation on load: (raw output y, scale, shift) of the previous conv when `cur` holds only its
-                           # activated FAKE rows (ops.fold_act_ok) - consumed by the very next conv
+        fold = None        # activation on load: (scale, shift) when `cur` IS the raw output y of the previous conv (tagged with the
+                           # bound of its activated form, ops.fold_act_ok) - consumed by the very next conv, which applies
+                           # relu(y * scale + shift) wherever it loads its input
         for L in net._layers:
             g = graphs[L.graph]
             M = B * g.V
@@ -227,14 +228,15 @@ class _MeshNetFn(torch.autograd.Function):
                 if g.classes:       # holes of `cur` hold no data: project the live rows only; the combine fills the holes
                     Pm = torch.empty((M, 32), device=cur.device, dtype=torch.float32)
                     for rs in (1, 2):
-                        ops.gemm_planes_rows(g, rs, B, [cur], L.Fin, cur_shift, False, Wp, None, None, Pm, 32, Bx=Wpx)
+                        ops.gemm_planes_rows(g, rs, B, [cur], L.Fin, cur_shift, False, Wp, None, None, Pm, 32, Bx=Wpx,
+                                             amax=ops.amax_of(cur) if fold is not None else None, in_act=fold)
                 else:
                     (Pm,), _ = ops.gemm_planes([cur], L.Fin, cur_shift, Wp, None, M, 32, 1, False, Bx=Wpx)
                 out = ops.cheb_combine_small(g, Pm, L.Fout, bvec, B)
                 del Pm
                 if keep:
-                    saved.append((cur, cur_shift, None, None, None, None, Wp, None))
-                cur, cur_shift = out, 0
+                    saved.append((cur, cur_shift, None, None, None, None, Wp, fold))
+                cur, cur_shift, fold = out, 0, None
                 continue
             need_stats = L.has_bn and training
             bwd_fwdform = _bwd_forward_form(L)
@@ -260,8 +262,9 @@ class _MeshNetFn(torch.autograd.Function):
                 Ln = net._layers[L.ci + 1] if L.ci + 1 < len(net._layers) else None
                 # (train mode only: the folded operand is scaled from a BOUND of its maximum, the separate pass from the exact
                 #  maximum - in eval() the general path stays bitwise the real-rows-only inference path, tests/test_gpu_infer.py)
-                fold_out = (training and L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
-                            and not _narrow(Ln) and _bwd_forward_form(Ln) and ops.fold_act_ok(g, Ln.Fin, Ln.Fout, B))
+                fold_out = bool(training and L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
+                                and (ops.fold_act_ok(g, Ln.Fin, 32, B, narrow=True) if _narrow(Ln) else
+                                     (_bwd_forward_form(Ln) and ops.fold_act_ok(g, Ln.Fin, Ln.Fout, B))))
                 yword = ops.new_amax(cur.device) if fold_out else None
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
                                                         g.fake_b, need_stats, operands=opf, want_planes=False,
@@ -301,11 +304,12 @@ class _MeshNetFn(torch.autograd.Function):
                 if L.last_in_block and 1 <= L.block <= nblk - 2:       # meshnet.py:108-115
                     resid = block_in
                 if fold_out:
-                    # only the fake rows of x are materialised (the effective-weight contraction and its weight gradient
-                    # read them); the real rows are recomputed from y where they are loaded.  The word bounds both.
-                    out = ops.bn_act_fwd(y, co, True, None, 0, 0, M, L.Fout, fake_rows=g)
-                    ops.act_bound(co[2], co[3], yword, ops.amax_of(out))
-                    fold = (y, co[2], co[3])
+                    # x = relu(bn(y)) is not materialised at all: the next conv's kernels (tile kernel / basis kernel +
+                    # plane 0 of the contraction / fake-row contraction / narrow projection) and its weight gradients read y
+                    # and apply the activation on load.  `out` is y under a second tensor object that carries the bound of
+                    # the ACTIVATED tensor as its amax word.
+                    out = ops.tag_amax(y.view(M, L.Fout), ops.act_bound(co[2], co[3], yword, ops.new_amax(y.device)))
+                    fold = (co[2], co[3])
                 else:
                     out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout,
                                          classes=g if (g.classes and split) else None)
@@ -438,7 +442,8 @@ class _MeshNetFn(torch.autograd.Function):
                 if gph.classes:     # live rows only (row sets 1 / 2): the holes of X and E hold no data
                     dW32 = db32 = None
                     for rs in (1, 2):
-                        Pw, Pb, nch = ops.gemm_tn_rows(gph, rs, B, X, L.Fin, x_shift, [E], 32, False)
+                        Pw, Pb, nch = ops.gemm_tn_rows(gph, rs, B, X, L.Fin, x_shift, [E], 32, False,
+                                                       a_amax=ops.amax_of(X) if fold_in is not None else None, a_act=fold_in)
                         dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1, dW=dW32, db=db32)
                 else:
                     Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
@@ -541,14 +546,14 @@ class _MeshNetFn(torch.autograd.Function):
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers
-                # X with the activation folded into its consumers (forward: ops.fold_act_ok): the real rows are read from the
-                # raw output of the previous conv, activated on load; X itself holds the fake rows and the bounding word
-                Xr, xact = (fold_in[0], (fold_in[1], fold_in[2])) if fold_in is not None else (X, None)
-                with side_ctx(keep, X, Xr, gy, E1, E2):
-                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, Xr, L.Fin, x_shift, [gy, E1, E2], L.Fout, True,
-                                                   a_amax=ops.amax_of(X) if xact is not None else None,
-                                                   g_amax=ops.amax_of(gy, gph, B), g_bits=gph.plane_bits, a_act=xact)
-                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False)
+                # fold_in (forward: ops.fold_act_ok): X is the RAW output of the previous conv, tagged with the bound of its
+                # activated form; both weight-gradient launches apply the activation on load
+                xa_w = ops.amax_of(X) if fold_in is not None else None
+                with side_ctx(keep, X, gy, E1, E2):
+                    Pw, Pb, nch = ops.gemm_tn_rows(gph, 1, B, X, L.Fin, x_shift, [gy, E1, E2], L.Fout, True, a_amax=xa_w,
+                                                   g_amax=ops.amax_of(gy, gph, B), g_bits=gph.plane_bits, a_act=fold_in)
+                    Pw2, Pb2, nch2 = ops.gemm_tn_rows(gph, 2, B, X, L.Fin, x_shift, [gy], L.Fout, False, a_amax=xa_w,
+                                                      a_act=fold_in)
                     tg = tgt(f"cl.{L.ci}.weight", f"cl.{L.ci}.bias")
                     dW, db = ops.weight_grad_unpack2(Pw, Pb, nch, Pw2, Pb2, nch2, gph.fake_a, gph.fake_b, L.Fout,
                                                      L.Fin, *(tg or ()))

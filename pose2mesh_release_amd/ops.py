@@ -121,9 +121,9 @@ CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 # levels; "1": wherever supported (the A/B form of the parity tests); "0": never.  DESIGN.md section 6 has the numbers:
 # 157 KB of LDS per block leave one block per CU, so the kernel only wins where the plane traffic it removes is large.
 # BatchNorm + ReLU applied WHERE THE CONSUMER LOADS (include/p2m.h "activation on load"): between the two convs of a block on
-# the levels the matrix-core tile kernel owns, the activated tensor x = relu(bn(y)) of the real vertices is never written:
-# the second conv's tile kernel and its weight gradient read the raw y and apply fma + max on the way into LDS; only the
-# (few) fake-vertex rows of x are still materialised for the effective-weight contraction.  0 = the separate pass (A/B form).
+# the split levels, in train mode, the activated tensor x = relu(bn(y)) is never written - the second conv's kernels (tile
+# kernel, or LDS-staged basis kernel + plane 0 of the contraction; the fake-row contraction; the narrow final conv's
+# projection) and its weight gradients read the raw y and apply fma + max on the way into LDS.  0 = the separate pass (A/B form).
 FOLD_ACT = _os.environ.get("P2M_FOLD_ACT", "1") == "1"
 TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
 if TILE_GEMM not in ("auto", "0", "1"):
@@ -322,13 +322,16 @@ def cheb_expand_small(g, G, nc, lde, B):
 
 
 # ---- fake-vertex split (row-set launches) ---------------------------------------------------
-def cheb_basis_fwd_real(g, X, B, F, in_shift):
-    """Basis planes of the REAL vertices only, compact [B*n_real, F]."""
+def cheb_basis_fwd_real(g, X, B, F, in_shift, in_act=None):
+    """Basis planes of the REAL vertices only, compact [B*n_real, F].  in_act = (scale[F], shift[F]): activation on load - X
+    is a raw conv output, the planes are those of relu(X * scale + shift) (tile-plan kernel only)."""
     T1 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
     T2 = torch.empty((B * g.n_real, F), device=X.device, dtype=torch.float32)
     # bytes moved: real rows only (the fake rows' planes are folded into the effective weight); SURVEY 8(d) counts all V
     with _timed("cheb_basis_fwd", (4.0 * B * g.n_real * F * (2.0 + 1.0 / (1 << in_shift)), 12.0 * B * g.V * F)):
-        check(_lib.hip().p2m_cheb_basis_fwd_real(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift, _stream()),
+        check(_lib.hip().p2m_cheb_basis_fwd_real(g.handle, _p(_req(X, "X")), _p(T1), _p(T2), B, F, in_shift,
+                                                 _p(None if in_act is None else _req(in_act[0], "act_scale")),
+                                                 _p(None if in_act is None else _req(in_act[1], "act_shift")), _stream()),
               "p2m_cheb_basis_fwd_real")
     return T1, T2
 
@@ -531,12 +534,15 @@ def eff_bits(a, b):
 
 
 def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, C, N, stats=False, Bx=None, act=None,
-                     amax=None, amax_bits=0, amax_out=None):
+                     amax=None, amax_bits=0, amax_out=None, in_act=None):
     """Row-set contraction into the rows of C selected by row_set (1 real, 2 fake, 3 / 4 the paired sets).  Returns stats
     or None.  Bx: the pre-split copy of Bm (weight_split) when the caller has it cached.  f16x2: amax = the word
     bounding the A planes after amax_bits binades (default: A[0]'s own); amax_out: a zeroed word that receives the
-    bound of what is stored."""
+    bound of what is stored.  in_act = (scale[Ka], shift[Ka]): activation on load of plane 0 (A[0] is a raw conv output);
+    amax must then bound the activated operand."""
     n = g.set_size(row_set)
+    if in_act is not None and amax is None:
+        raise P2MError("gemm_planes_rows: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2() and amax is None:
         amax = _amax_planes(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
     st = None
@@ -556,7 +562,9 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
                                               _p(None if weighted else st), _p(None if act is None else act[0]),
                                               _p(None if act is None else act[1]), int(bool(act and act[2])),
-                                              _p(amax_out), _stream()), "p2m_gemm_planes_rows")
+                                              _p(amax_out), _p(None if in_act is None else _req(in_act[0], "in_scale")),
+                                              _p(None if in_act is None else _req(in_act[1], "in_shift")), _stream()),
+              "p2m_gemm_planes_rows")
     if weighted and n > 0:
         check(_lib.hip().p2m_stats_rows_w(g.handle, _p(C), B, N, _p(st), _stream()), "p2m_stats_rows_w")
     return st
@@ -737,11 +745,23 @@ def conv_pair(g, B, Gy, Ka, Bm, addend, C, N, operands, P0=None, amax_out=None):
     return P0, P1c, P2c
 
 
-def fold_act_ok(g, Ka, N, B):
+BASIS_TILED = _os.environ.get("P2M_BASIS_TILED", "1") == "1"     # (the library reads the same variable: INTEGRATION.md section 7)
+
+
+def fold_act_ok(g, Ka, N, B, narrow=False):
     """True when a conv with input width Ka and output width N on the (split) level g can take its input as a RAW conv
-    output with the activation applied on load (FOLD_ACT): its real rows run through the matrix-core tile kernel on the
-    level's own plan, without planes out (the weight gradient re-applies the activation itself)."""
-    return bool(FOLD_ACT and f16x2() and g.split and N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B))
+    output with the activation applied on load (FOLD_ACT).  Three consumer forms implement it: the matrix-core tile kernel
+    on the level's own plan (N <= 128); the LDS-staged basis kernel + plane contraction (needs the level's tile plan, Ka <=
+    256); the narrow final conv's projection (row-set contractions: needs declared classes).  The fake-vertex rows and every
+    weight gradient read the raw tensor through the same on-load activation."""
+    if not (FOLD_ACT and f16x2() and g.split and Ka <= 256 and Ka % 32 == 0):
+        return False
+    if narrow:
+        return bool(g.classes)
+    if N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B):
+        return True
+    return bool(BASIS_TILED and g.plan_tiles[0] > 0 and (Ka in (32, 64) or Ka % 128 == 0) and N % 32 == 0
+                and not tile_gemm_ok(g, 0, Ka, N, False, B=B))
 
 
 def act_bound(scale, shift, y_amax, word):
@@ -758,19 +778,27 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
     planes of the real vertices (None unless want_planes), the BatchNorm partials of the two launches, and whether
     st_real is in per-(sample, tile) form (p2m_bn_finalize_tiles, plan = a0_shift) or per 128-row tile
-    (p2m_bn_finalize_split).  in_act = (Y, scale, shift) - activation on load (fold_act_ok): the real rows read the raw conv
-    output Y and apply relu(y * scale + shift) in the tile kernel; X then only holds the activated FAKE rows and carries the
-    amax word that bounds the whole activated tensor."""
+    (p2m_bn_finalize_split).  in_act = (scale, shift) - activation on load (fold_act_ok): X is the RAW output of the previous
+    conv, tagged with the amax word that bounds relu(X * scale + shift), and every reader applies that on load."""
     Bx, We, Wex = operands if operands is not None else split_operands(Bm, Ka, N, fake_a, fake_b)
     xa = amax_of(X, g if a0_shift == 0 else None, B)
     if in_act is not None:
-        if a0_shift != 0 or want_planes or not tile_gemm_ok(g, 0, Ka, N, False, B=B):
-            raise P2MError("conv_split: activation on load needs the tile kernel on the level's own plan (fold_act_ok)")
-        st1, _ = cheb_tile_gemm(g, 0, in_act[0], in_act[0], Ka, Bx, bias, addend, C, N, B, stats=stats, amax=xa,
-                                amax_out=amax_out, in_act=(in_act[1], in_act[2]))
+        # X IS the raw output of the previous conv (tagged with the bound of its activated form); every reader applies
+        # relu(y * scale + shift) on load: tile kernel / basis kernel + plane 0 of the contraction / fake-row contraction
+        if a0_shift != 0 or want_planes:
+            raise P2MError("conv_split: activation on load needs the level's own plan and no planes out (fold_act_ok)")
+        if N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B):
+            st1, _ = cheb_tile_gemm(g, 0, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats, amax=xa, amax_out=amax_out,
+                                    in_act=in_act)
+            tiled = True
+        else:
+            T1c, T2c = cheb_basis_fwd_real(g, X, B, Ka, 0, in_act=in_act)
+            st1 = gemm_planes_rows(g, 1, B, [X, T1c, T2c], Ka, 0, True, Bm, bias, addend, C, N, stats, Bx=Bx, amax=xa,
+                                   amax_bits=g.plane_bits, amax_out=amax_out, in_act=in_act)
+            tiled = False
         st2 = gemm_planes_rows(g, 2, B, [X], Ka, 0, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
-                               amax_out=amax_out)
-        return None, None, st1, st2, True
+                               amax_out=amax_out, in_act=in_act)
+        return None, None, st1, st2, tiled
     if tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
                                      want_planes=want_planes, amax=xa, amax_out=amax_out)
@@ -975,7 +1003,7 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
-def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_rows=None, fake_rows=None):
+def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_rows=None):
     """classes: the level's DeviceGraph when the holes of y hold no data (they are then skipped); real_rows: the level's
     DeviceGraph when only the REAL rows of y hold data (inference on the real rows): only those are walked.  f16x2: the
     output comes back tagged with the amax word of what was written."""
@@ -986,8 +1014,6 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_row
     if real_rows is not None:
         cls = real_rows.handle
     mode = 1 if real_rows is not None else 0
-    if fake_rows is not None:      # only the level's fake vertices (row set 2): what a consumer with activation on load reads
-        cls, mode = fake_rows.handle, 2
     word = new_amax(y.device) if (f16x2() and F % 4 == 0) else None
     check(_lib.hip().p2m_bn_act_fwd(_p(_req(y, "y")), _p(sc), _p(sh), int(relu),
                                     _p(resid if resid is None else _req(resid, "resid")), int(Fres), int(res_shift),

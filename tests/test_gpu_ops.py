@@ -679,8 +679,9 @@ def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fi
     """include/p2m.h "activation on load" (lib/models/backbones/cheby_graph_conv.py:39 + lib/models/meshnet.py:100 folded into the
     next conv's loads): the tile kernel and the weight-gradient contraction reading the RAW conv output y with
     relu(y * scale + shift) applied between the global load and the LDS image give, bit for bit, what they give on the
-    tensor x that p2m_bn_act_fwd materialises (same two roundings, same amax word); the fake-rows-only activation pass
-    writes exactly the fake rows; p2m_act_bound really bounds the activated tensor."""
+    tensor x that p2m_bn_act_fwd materialises (same two roundings, same amax word) - tile kernel, LDS-staged basis kernel,
+    plane contraction over the real and the fake rows, both weight-gradient launches; p2m_act_bound really bounds the
+    activated tensor."""
     monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
     monkeypatch.setattr(ops, "TILE_GEMM", True)
     L = _band_graph(V, 11 + V)
@@ -696,20 +697,9 @@ def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fi
     real = torch.as_tensor(_real_ids(L), device="cuda")
     fake = torch.ones(V, dtype=torch.bool, device="cuda")
     fake[real] = False
-    # fake-rows-only pass: exactly the fake rows of x, nothing else written
-    xf = torch.full((M, Fin), float("nan"), device="cuda")
-    check = ops._lib.hip().p2m_bn_act_fwd
-    w_f = ops.new_amax("cuda:0")
-    ops.check(check(ops._p(y), ops._p(co[2]), ops._p(co[3]), 1, None, 0, 0, ops._p(xf), M, Fin, g.handle, 2, ops._p(w_f),
-                    ops._stream()), "p2m_bn_act_fwd")
-    assert torch.equal(xf.view(B, V, Fin)[:, fake], x.view(B, V, Fin)[:, fake])
-    assert torch.isnan(xf.view(B, V, Fin)[:, real]).all()
-    xf2 = ops.bn_act_fwd(y, co, True, None, 0, 0, M, Fin, fake_rows=g)
-    assert torch.equal(xf2.view(B, V, Fin)[:, fake], x.view(B, V, Fin)[:, fake])
     # the bound: >= the true maximum, and not absurdly loose on this input
     yw = ops.amax_of(y)
-    word = ops.amax_of(xf2)
-    ops.act_bound(co[2], co[3], yw, word)
+    word = ops.act_bound(co[2], co[3], yw, ops.new_amax("cuda:0"))
     bound = word.view(torch.float32).item()
     true_max = x.abs().max().item()
     assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
@@ -734,6 +724,26 @@ def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fi
                                 g_bits=g.plane_bits, a_act=(co[2], co[3]))
     torch.cuda.synchronize()
     assert n == n_ref and torch.equal(P, P_ref) and torch.equal(Pb, Pb_ref)
+    # the two-kernel form (LDS-staged basis kernel + plane contraction, what the N = 256 levels run) and the fake-row /
+    # narrow-projection contractions: planes and C bitwise those on the materialised x
+    T1r, T2r = ops.cheb_basis_fwd_real(g, x, B, Fin, 0)
+    T1a, T2a = ops.cheb_basis_fwd_real(g, y, B, Fin, 0, in_act=(co[2], co[3]))
+    assert torch.equal(T1a, T1r) and torch.equal(T2a, T2r)
+    We = ops.weight_eff(Wt, Fin, Fout, g.fake_a, g.fake_b)
+    Wex = ops.weight_split(We)
+    for rs, planes_x, planes_y, Bm, Bxx, compact in ((1, [x, T1r, T2r], [y, T1a, T2a], Wt, Bx, True),
+                                                     (2, [x], [y], We, Wex, False)):
+        c_ref = torch.zeros((M, Fout), device="cuda")
+        st_ref = ops.gemm_planes_rows(g, rs, B, planes_x, Fin, 0, compact, Bm, bias, None, c_ref, Fout, True, Bx=Bxx,
+                                      amax=word, amax_bits=g.plane_bits if rs == 1 else 0)
+        c = torch.zeros((M, Fout), device="cuda")
+        st = ops.gemm_planes_rows(g, rs, B, planes_y, Fin, 0, compact, Bm, bias, None, c, Fout, True, Bx=Bxx,
+                                  amax=word, amax_bits=g.plane_bits if rs == 1 else 0, in_act=(co[2], co[3]))
+        torch.cuda.synchronize()
+        assert torch.equal(c, c_ref) and torch.equal(st, st_ref), rs
+    P2r, Pb2r, n2r = ops.gemm_tn_rows(g, 2, B, x, Fin, 0, [gy], Fout, False, a_amax=word, g_amax=ga)
+    P2, Pb2, n2 = ops.gemm_tn_rows(g, 2, B, y, Fin, 0, [gy], Fout, False, a_amax=word, g_amax=ga, a_act=(co[2], co[3]))
+    assert n2 == n2r and torch.equal(P2, P2r) and torch.equal(Pb2, Pb2r)
     # the activation on load is refused where no kernel implements it
     from pose2mesh_release_amd._lib import P2MError
     with pytest.raises(P2MError):
