@@ -23,7 +23,50 @@ namespace p2m {
 // N/8 blocks only: ~35 us per call for the fine levels, 40 calls per step.
 constexpr int FIN_COLS = 32;    // columns per stage-1 block
 constexpr int FIN_RG = 8;       // tile-row groups per stage-1 block
-constexpr int FIN_SPLITS = 48;  // slices of the tile range
+constexpr int FIN_SPLITS = 48;  // slices of the tile range: the minimum ...
+constexpr int FIN_SPLITS_MAX = 192;   // ... and what a long tile range is cut into (round 4: the stage-1 launches of the fine
+                                      // levels read 56 MB from 4 x 48 = 192 blocks: 150 us; stage 2 walked its partials with
+                                      // one dependent load per iteration: 25-30 us under load)
+static inline int fin_splits(long nrows) {            // a function of the sizes only: results stay deterministic
+  return nrows >= 16384 ? FIN_SPLITS_MAX : (nrows >= 4096 ? 96 : FIN_SPLITS);
+}
+// sum of the nsplits stage-1 partials of column n (layout part[(split * 2 + which) * N + n]) in a FIXED order, with the loads
+// of 12 splits in flight at a time (independent accumulators, combined in order)
+// Stage 2 runs 64 columns x FIN_Q quarter-ranges of the splits per block: thread (q, col) sums its quarter, the quarters are
+// combined through LDS in the order 0..3 - one round of 12 loads in flight per thread at 48 splits instead of four.
+constexpr int FIN_Q = 4;
+__device__ __forceinline__ void fin_sum(const double* __restrict__ part, int nsplits, int N, int n, bool live, double& t1,
+                                        double& t2) {
+  __shared__ double q1[FIN_Q][64], q2[FIN_Q][64];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int per = nsplits / FIN_Q;                     // nsplits is 48, 96 or 192: per is a multiple of 12
+  t1 = 0.0;
+  t2 = 0.0;
+  if (live)
+  for (int sp0 = q * per; sp0 < (q + 1) * per; sp0 += 12) {
+    double a[12], b[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      a[k] = part[((long)(sp0 + k) * 2) * N + n];
+      b[k] = part[((long)(sp0 + k) * 2 + 1) * N + n];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      t1 += a[k];
+      t2 += b[k];
+    }
+  }
+  q1[q][col] = t1;
+  q2[q][col] = t2;
+  __syncthreads();
+  t1 = q1[0][col];
+  t2 = q2[0][col];
+#pragma unroll
+  for (int k = 1; k < FIN_Q; k++) {
+    t1 += q1[k][col];
+    t2 += q2[k][col];
+  }
+}
 // Up to two segments of partials (e.g. the real-vertex and the fake-vertex launch of one conv); inside a segment the
 // tiles repeat with period `tps` over `seg_rows` rows (row-set launches tile every sample separately).
 struct StatSeg {
@@ -33,7 +76,7 @@ struct StatSeg {
   const float* tile_w;   // optional [tps]: total weight of each tile (weighted partials of class representatives)
 };
 __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, StatSeg sg1, int tile_rows, int N,
-                                                                  double* __restrict__ part) {
+                                                                  double* __restrict__ part, int nsplits) {
   __shared__ double s1[FIN_RG][FIN_COLS];
   __shared__ double s2[FIN_RG][FIN_COLS];
   const int c = threadIdx.x % FIN_COLS, rg = threadIdx.x / FIN_COLS;
@@ -44,7 +87,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, S
     for (int sgi = 0; sgi < 2; sgi++) {
       const StatSeg sg = sgi == 0 ? sg0 : sg1;
       if (sg.stats == nullptr) continue;
-      const int per = (sg.ntiles + FIN_SPLITS - 1) / FIN_SPLITS;
+      const int per = (sg.ntiles + nsplits - 1) / nsplits;
       const int i0 = split * per;
       int i1 = i0 + per;
       if (i1 > sg.ntiles) i1 = sg.ntiles;
@@ -73,17 +116,15 @@ __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_partial(StatSeg sg0, S
   }
 }
 
-__global__ __launch_bounds__(64) void k_bn_finalize(const double* __restrict__ part, long M,
+__global__ __launch_bounds__(64 * FIN_Q) void k_bn_finalize(const double* __restrict__ part, long M,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* running_mean, float* running_var, float momentum, float eps,
-                                                    float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int N) {
-  const int n = blockIdx.x * 64 + threadIdx.x;
-  if (n >= N) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int sp = 0; sp < FIN_SPLITS; sp++) {
-    t1 += part[((long)sp * 2) * N + n];
-    t2 += part[((long)sp * 2 + 1) * N + n];
-  }
+                                                    float* mean_o, float* invstd_o, float* scale_o, float* shift_o, int N,
+                                                    int nsplits) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  double t1, t2;
+  fin_sum(part, nsplits, N, n, n < N, t1, t2);
+  if (n >= N || threadIdx.x >= 64) return;
   const double mean = t1 / (double)M;
   double var = t2 / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -538,13 +579,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
 // Two stages like the forward finalize.  Stage 1: block = 32 adjacent columns of BOTH partial kinds (128-byte coalesced
 // reads) x 8 row groups, one of FIN_SPLITS slices of the nblk partial rows; stage 2: one thread per column.
 __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_bwd_partial(const float* __restrict__ part, int nblk, int F,
-                                                                      double* __restrict__ out) {
+                                                                      double* __restrict__ out, int nsplits) {
   __shared__ double s0[FIN_RG][FIN_COLS];
   __shared__ double s1[FIN_RG][FIN_COLS];
   const int cc = threadIdx.x % FIN_COLS, rg = threadIdx.x / FIN_COLS;
   const int c = blockIdx.x * FIN_COLS + cc;
   const int split = blockIdx.y;
-  const int per = (nblk + FIN_SPLITS - 1) / FIN_SPLITS;
+  const int per = (nblk + nsplits - 1) / nsplits;
   const int i0 = split * per;
   int i1 = i0 + per;
   if (i1 > nblk) i1 = nblk;
@@ -570,15 +611,12 @@ __global__ __launch_bounds__(FIN_COLS * FIN_RG) void k_bn_bwd_partial(const floa
   }
 }
 
-__global__ __launch_bounds__(64) void k_bn_bwd_finalize(const double* __restrict__ part, long M, float* dgamma,
-                                                        float* dbeta, float* coef, int accumulate, int F) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= F) return;
-  double t0 = 0.0, t1 = 0.0;
-  for (int sp = 0; sp < FIN_SPLITS; sp++) {
-    t0 += part[((long)sp * 2) * F + c];
-    t1 += part[((long)sp * 2 + 1) * F + c];
-  }
+__global__ __launch_bounds__(64 * FIN_Q) void k_bn_bwd_finalize(const double* __restrict__ part, long M, float* dgamma,
+                                                        float* dbeta, float* coef, int accumulate, int F, int nsplits) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double t0, t1;
+  fin_sum(part, nsplits, F, c, c < F, t0, t1);
+  if (c >= F || threadIdx.x >= 64) return;
   const float db = (float)t0, dg = (float)t1;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
@@ -875,7 +913,7 @@ double* fin_scratch(int N, void* stream) {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(g_fin_mu);
   double*& buf = g_fin[{dev, stream}];
-  if (buf == nullptr && hipMalloc((void**)&buf, sizeof(double) * 2 * FIN_SPLITS * FIN_MAXN) != hipSuccess) buf = nullptr;
+  if (buf == nullptr && hipMalloc((void**)&buf, sizeof(double) * 2 * FIN_SPLITS_MAX * FIN_MAXN) != hipSuccess) buf = nullptr;
   return buf;
 }
 int finalize_launch(const StatSeg& a, const StatSeg& b, long M, int tile_rows, const float* gamma, const float* beta,
@@ -886,10 +924,11 @@ int finalize_launch(const StatSeg& a, const StatSeg& b, long M, int tile_rows, c
     set_error("%s: no scratch for %d columns (max %d) or hipMalloc failed", what, N, FIN_MAXN);
     return P2M_ERR_NOMEM;
   }
-  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(N, FIN_COLS), FIN_SPLITS), dim3(FIN_COLS * FIN_RG), 0, s, a, b, tile_rows, N,
-                     part);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, part, M, gamma, beta, running_mean, running_var,
-                     momentum, eps, mean, invstd, scale, shift, N);
+  const int nsplits = fin_splits((long)a.ntiles + (b.stats != nullptr ? b.ntiles : 0));
+  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(N, FIN_COLS), nsplits), dim3(FIN_COLS * FIN_RG), 0, s, a, b, tile_rows, N,
+                     part, nsplits);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(N, 64)), dim3(64 * FIN_Q), 0, s, part, M, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, invstd, scale, shift, N, nsplits);
   return check_launch(what);
 }
 }  // namespace
@@ -1071,10 +1110,11 @@ extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, f
     set_error("p2m_bn_bwd_finalize: no scratch for %d columns (max %d) or hipMalloc failed", F, FIN_MAXN);
     return P2M_ERR_NOMEM;
   }
-  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(cdiv(F, FIN_COLS), FIN_SPLITS), dim3(FIN_COLS * FIN_RG), 0, s, part, nblk, F,
-                     scratch);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(F, 64)), dim3(64), 0, s, scratch, (long)M, dgamma, dbeta, coef,
-                     accumulate, F);
+  const int nsplits = fin_splits(nblk);
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(cdiv(F, FIN_COLS), nsplits), dim3(FIN_COLS * FIN_RG), 0, s, part, nblk, F,
+                     scratch, nsplits);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(F, 64)), dim3(64 * FIN_Q), 0, s, scratch, (long)M, dgamma, dbeta, coef,
+                     accumulate, F, nsplits);
   return check_launch("bn_bwd_finalize");
 }
 
