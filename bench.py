@@ -6,6 +6,12 @@
          bench.py --gpus N --steps K --warmup W
   python bench.py --mode infer            (BASELINE.json configs[1]: batch 64, J=17, eval forward + Tester epilogue)
 
+Protocol: 20 warm-up + 50 timed steps by default; `value` / `ms_per_step` are wall-clock over the timed region,
+`ms_per_step_stats` the per-step median / p10 / p90 from one HIP event per step.  The default 1-GPU train run also reports, from
+the same process and after the timed region: `arith_ab` (the same step in the other two contraction arithmetics: bf16x3 = exact
+fp32 emulation, f32 = native MFMA), `also` (configs[1] inference and configs[4] MANO B=512 train; `--also none` to skip), and for
+N > 1 `multi_gpu` (ranks seen over the job's backend, per-rank per-bucket all-reduce timings and the hidden fraction).
+
 One "step" (train mode) = one full reference train step (lib/core/base.py:122-148) on one synthetic batch that is
 already resident in HBM: FlatPose2Mesh forward (PoseNet + coarse-to-fine GCN), perm-reverse gather, joint regression,
 the five reference losses, backward, [gradient all-reduce], Adam.  Weak scaling: every rank owns `--batch` samples.
