@@ -109,3 +109,26 @@ def test_conv_weights_descriptor_layout():
     body = hdr[hdr.index("typedef struct p2m_conv_weights {"):hdr.index("} p2m_conv_weights;")]
     order = [m for m in re.findall(r"\b(W|Fout|Fin|fake_a|fake_b|eff_bits|reserved|Bx_f|Bx_ef|Bx_b|Bx_eb|amax)\b", body)]
     assert order == [n for n, _ in d._fields_]
+
+
+def test_bench_line_helpers_and_cli():
+    """bench.py's reporting helpers (no GPU): the per-step statistics, a `dtype` string for every contraction arithmetic that
+    spells out the emulation (the line must say what it measured), and the flags the driver's one command relies on."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("p2m_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    st = b.step_stats([10.0, 12.0, 11.0, 13.0, 50.0])
+    assert st["median"] == 12.0 and st["min"] == 10.0 and st["max"] == 50.0 and st["p10"] <= st["median"] <= st["p90"]
+    assert set(b.DTYPE_NOTE) == {"f16x2", "bf16x3", "f32"}
+    assert "2 scaled fp16 slices" in b.DTYPE_NOTE["f16x2"] and "22-bit" in b.DTYPE_NOTE["f16x2"]
+    assert "3 exact bf16 slices" in b.DTYPE_NOTE["bf16x3"] and b.DTYPE_NOTE["f32"].startswith("f32 (native")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--also", "--no-arith-ab", "--mode", "--train-graph"):
+        assert flag in r.stdout, flag
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--also", "nonsense"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "unknown leg" in r.stderr
