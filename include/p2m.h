@@ -119,7 +119,9 @@ int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, int32_t Fou
 /* Sums `nchunks` partial gradients P[chunk][k*Fin+fin][Fout], Pdb[chunk][Fout] produced by
  * p2m_gemm_tn and writes dW in nn.Linear layout [Fout][fin*K+k] and db[Fout].
  * accumulate!=0 adds into dW/db instead of overwriting.  layout 1: P[chunk][fin][k*Fout+fout] (the
- * gradient taken as X^T [g|Lg|L2g]).  pdb_stride = row stride of Pdb (the N of the p2m_gemm_tn call).  */
+ * gradient taken as X^T [g|Lg|L2g]); layout 2 (K = 1): P[chunk][fout][fin] - a plain Linear's gradient taken as G^T X (the
+ * operands of p2m_gemm_tn swapped), already in nn.Linear layout: coalesced on both sides (Pdb is then the wrong column sum:
+ * pass NULL and reduce the bias gradient separately).  pdb_stride = row stride of Pdb (the N of the p2m_gemm_tn call).  */
 int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t nchunks, float* dW, float* db,
                            int32_t Fout, int32_t Fin, int32_t K, int32_t accumulate, int32_t layout,
                            int32_t pdb_stride, void* stream);

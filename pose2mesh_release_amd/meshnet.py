@@ -330,9 +330,19 @@ class _MeshNetFn(torch.autograd.Function):
                 if L.block == 0:                                      # fc lift (:104-106)
                     h = ops.view_tagged(cur, B, J * L.Fout)
                     fw, fb = params[P["fc.weight"]], params[P["fc.bias"]]
-                    fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw))))
-                    (u,), _ = ops.gemm_planes([h], fw.shape[1], 0, fwt, fb, B, fw.shape[0], 1, False, Bx=fwx,
-                                              want_amax=True)
+                    Nf, Kf = fw.shape
+                    if ops.GEMM_ARITH != "f32" and B % 4 == 0 and B >= 32 and Nf % 32 == 0 and Kf % 32 == 0:
+                        # a batch-sized Linear as a reduction over its K input columns with both operands row-major over K
+                        # (the weight-gradient-shaped contraction, split over K): h^T [K, B] and the transposed weight - a
+                        # plane contraction would put 2 x N/128 blocks on 256 CUs (see the backward)
+                        fwt = wc.get("fc_t", fw, lambda: ops.weight_pack(fw, Kf, 1, need_w2=False)[0])
+                        ha = ops.amax_of(h)
+                        Pu, _, nchu = ops.gemm_tn([ops.tag_amax(h.t().contiguous(), ha)], B, 0, fwt, Kf, Nf, a_amax=ha,
+                                                  g_amax=wc.get("fc_amax", fw, lambda: ops.param_amax(fw)))
+                        u = (Pu[0] if nchu == 1 else Pu.sum(0)).add_(fb)
+                    else:
+                        fwt, fwx = wc.get("fc", fw, lambda: _fc_operands(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw))))
+                        (u,), _ = ops.gemm_planes([h], Kf, 0, fwt, fb, B, Nf, 1, False, Bx=fwx, want_amax=True)
                     if keep:
                         fc_saved = h
                     cur = ops.view_tagged(u, B * net._Vc, net.CL_F[1][0])
@@ -422,18 +432,41 @@ class _MeshNetFn(torch.autograd.Function):
                     fw = params[P["fc.weight"]]
                     dU = ops.view_tagged(G, B, fw.shape[0])
                     h = ctx.fc_saved
-                    Pw, Pb, nch = ops.gemm_tn([h], fw.shape[1], 0, dU, B, fw.shape[0])
+                    Nf, Kf = fw.shape
                     tg = tgt("fc.weight", "fc.bias")
-                    if tg is not None:
-                        ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1, dW=tg[0], db=tg[1])
-                        ready("fc.weight", "fc.bias")
+                    if ops.GEMM_ARITH != "f32" and Nf % 32 == 0 and Kf % 32 == 0:
+                        # A batch-sized Linear (M = B rows) is two more weight-gradient-shaped contractions (reductions over a
+                        # long index with both operands row-major over it), not plane contractions - those would put
+                        # 2 x N/128 blocks on 256 CUs:
+                        #   dW[n, k] = sum_m dU[m, n] h[m, k]: the operands of p2m_gemm_tn swapped, so that the partials
+                        #       come out in nn.Linear layout and the unpack is coalesced on both sides (layout 2);
+                        #   dh[m, k] = sum_n dU^T[n, m] W[n, k]: W exactly as nn.Linear stores it - no packed / split copy.
+                        dUa = ops.amax_of(dU)
+                        Pw, _, nch = ops.gemm_tn([dU], Nf, 0, h, B, Kf, a_amax=dUa, g_amax=ops.amax_of(h))
+                        dbv = dU.sum(0)
+                        if tg is not None:
+                            if nch == 1:      # one chunk (the reduction index is the batch): already THE gradient
+                                tg[0].add_(Pw[0])
+                            else:
+                                ops.weight_grad_unpack(Pw, None, nch, Nf, Kf, 1, dW=tg[0], db=None, layout=2)
+                            tg[1].add_(dbv)
+                            ready("fc.weight", "fc.bias")
+                        else:
+                            grads[P["fc.weight"]] = Pw[0] if nch == 1 else \
+                                ops.weight_grad_unpack(Pw, None, nch, Nf, Kf, 1, layout=2)[0]
+                            grads[P["fc.bias"]] = dbv
+                        dUt = ops.tag_amax(dU.t().contiguous(), dUa)
+                        Ph, _, nch2 = ops.gemm_tn([dUt], B, 0, fw, Nf, Kf, a_amax=dUa,
+                                                  g_amax=wc.get("fc_amax", fw, lambda: ops.param_amax(fw)))
+                        dh = Ph[0] if nch2 == 1 else Ph.sum(0)
                     else:
-                        grads[P["fc.weight"]], grads[P["fc.bias"]] = \
-                            ops.weight_grad_unpack(Pw, Pb, nch, fw.shape[0], fw.shape[1], 1)
-                    fwx = wc.get("fc_bwd", fw,
-                                 lambda: ops.weight_split(fw, wc.get("fc_amax", fw, lambda: ops.param_amax(fw)))
-                                 if fw.shape[0] % 32 == 0 and fw.shape[1] % 32 == 0 else None)
-                    (dh,), _ = ops.gemm_planes([dU], fw.shape[0], 0, fw, None, B, fw.shape[1], 1, False, Bx=fwx)
+                        Pw, Pb, nch = ops.gemm_tn([h], Kf, 0, dU, B, Nf)
+                        if tg is not None:
+                            ops.weight_grad_unpack(Pw, Pb, nch, Nf, Kf, 1, dW=tg[0], db=tg[1])
+                            ready("fc.weight", "fc.bias")
+                        else:
+                            grads[P["fc.weight"]], grads[P["fc.bias"]] = ops.weight_grad_unpack(Pw, Pb, nch, Nf, Kf, 1)
+                        (dh,), _ = ops.gemm_planes([dU], Nf, 0, fw, None, B, Kf, 1, False)
                     G = dh.view(B * J, L.Fout)
                 g_cur = G
             if _narrow(L):

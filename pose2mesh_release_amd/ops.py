@@ -969,13 +969,15 @@ def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits
 
 
 def weight_grad_unpack(P, Pdb, nchunks, Fout, Fin, K, dW=None, db=None, layout=0):
-    """layout 0: P[c][k*Fin+fin][fout]; layout 1: P[c][fin][k*Fout+fout].  Output in nn.Linear layout."""
+    """layout 0: P[c][k*Fin+fin][fout]; layout 1: P[c][fin][k*Fout+fout]; layout 2 (K = 1): P[c][fout][fin].  Output in
+    nn.Linear layout.  Pdb = None: no bias gradient (returned / left as it is)."""
     acc = 1 if dW is not None else 0
     if dW is None:
         dW = torch.empty((Fout, Fin * K), device=P.device, dtype=torch.float32)
-        db = torch.empty((Fout,), device=P.device, dtype=torch.float32)
-    check(_lib.hip().p2m_weight_grad_unpack(_p(P), _p(Pdb), nchunks, _p(dW), _p(db), Fout, Fin, K, acc, layout,
-                                            Pdb.shape[1], _stream()), "p2m_weight_grad_unpack")
+        db = torch.empty((Fout,), device=P.device, dtype=torch.float32) if Pdb is not None else None
+    check(_lib.hip().p2m_weight_grad_unpack(_p(P), _p(Pdb), nchunks, _p(dW), _p(db if Pdb is not None else None), Fout, Fin,
+                                            K, acc, layout, Pdb.shape[1] if Pdb is not None else 0, _stream()),
+          "p2m_weight_grad_unpack")
     return dW, db
 
 
