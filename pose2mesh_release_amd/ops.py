@@ -949,12 +949,14 @@ def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits
     Gc = N // len(Gl)
     Ktot = len(A) * Ka
     ntiles = ((Ktot + 127) // 128) * ((N + 127) // 128)
-    chunk_rows = pick_chunk_rows(M, ntiles)
+    mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32 and Gc % 4 == 0
+    # the scalar fall-back (the first conv's 15 x 32 gradient) walks a chunk's rows one dependent load at a time: short
+    # chunks (32 rows: 94 -> 15 us per step for the 4 864 joint rows of a batch of 256), the unpack sums them
+    chunk_rows = pick_chunk_rows(M, ntiles) if mfma else 32
     nchunks = (M + chunk_rows - 1) // chunk_rows
     P = torch.empty((nchunks, Ktot, N), device=G.device, dtype=torch.float32)
     Pdb = torch.empty((nchunks, N), device=G.device, dtype=torch.float32)
     a = [_p(_req(t, "A plane")) for t in A] + [None] * (3 - len(A))
-    mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32 and Gc % 4 == 0
     gp = [_p(_req(t, "G plane")) for t in Gl] + [None] * (3 - len(Gl))
     if mfma and f16x2():
         if a_amax is None:
