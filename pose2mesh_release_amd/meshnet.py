@@ -472,11 +472,16 @@ class _MeshNetFn(torch.autograd.Function):
             if _narrow(L):
                 Wp = W2
                 E = ops.cheb_expand_small(gph, g_cur, L.Fout, 32, B)
+                # E = [G | L G | L2 G | 0] is bounded by 2^plane_bits max |G|: one small pass over the 3-wide G instead of a pass
+                # over the 32-wide E (holes of a class-reduced G are zero)
+                ew = ops.amax_of(g_cur.view(-1)) if (gph.classes and g_cur.numel() % 4 == 0) else None
+                ebits = gph.plane_bits if ew is not None else 0
                 if gph.classes:     # live rows only (row sets 1 / 2): the holes of X and E hold no data
                     dW32 = db32 = None
                     for rs in (1, 2):
                         Pw, Pb, nch = ops.gemm_tn_rows(gph, rs, B, X, L.Fin, x_shift, [E], 32, False,
-                                                       a_amax=ops.amax_of(X) if fold_in is not None else None, a_act=fold_in)
+                                                       a_amax=ops.amax_of(X) if fold_in is not None else None, a_act=fold_in,
+                                                       g_amax=ew, g_bits=ebits)
                         dW32, db32 = ops.weight_grad_unpack(Pw, Pb, nch, 32, L.Fin, 1, dW=dW32, db=db32)
                 else:
                     Pw, Pb, nch = ops.gemm_tn([X], L.Fin, x_shift, E, M, 32)
@@ -497,7 +502,8 @@ class _MeshNetFn(torch.autograd.Function):
                 if gph.classes:
                     dX = torch.empty((M, L.Fin), device=E.device, dtype=torch.float32)
                     for rs in (1, 2):
-                        ops.gemm_planes_rows(gph, rs, B, [E], 32, 0, False, Wpt, None, None, dX, L.Fin, Bx=Wptx)
+                        ops.gemm_planes_rows(gph, rs, B, [E], 32, 0, False, Wpt, None, None, dX, L.Fin, Bx=Wptx, amax=ew,
+                                             amax_bits=ebits)
                 else:
                     (dX,), _ = ops.gemm_planes([E], 32, 0, Wpt, None, M, L.Fin, 1, False, Bx=Wptx)
                 saved[L.ci] = None
