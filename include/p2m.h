@@ -282,7 +282,9 @@ int p2m_graph_pair_info(p2m_graph_t g, int32_t counts[2] /* n_pair_real, n_pair_
 int p2m_graph_plan_info(p2m_graph_t g, int32_t ntiles[3]);
 int p2m_cheb_basis_pair(p2m_graph_t g, const float* G, float* P1c, float* P2c, int32_t B, int32_t F, void* stream);
 /* C[b*V + ids[i], :] = [A0[..] | A1 | A2] Bm + bias (+ addend): A0 is read at the actual row (>> a0_shift), A1/A2 at
- * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles.  in_scale / in_shift [Ka]
+ * the compact row b*n + i when planes_compact.  stats: [B * ceil(n/128)][2][N] per-sample tiles; for row_set 2 of a handle
+ * with classes (p2m_graph_set_classes) every representative counts once per class member, as p2m_stats_rows_w would
+ * count it (the tile weights for p2m_bn_finalize_split are the handle's).  in_scale / in_shift [Ka]
  * (optional; slice arithmetics, Ka <= 256): activation on load of PLANE 0, as in p2m_cheb_tile_gemm - A0 holds the raw
  * output y of the previous conv and the operand is max(fma(y, in_scale[k], in_shift[k]), 0) (A1 / A2 are then the planes
  * p2m_cheb_basis_fwd_real formed with the same act_scale / act_shift); a_amax must bound the activated operand.      */
@@ -371,7 +373,8 @@ int p2m_bn_finalize_tiles(p2m_graph_t g, int32_t plan, const float* stats_real, 
  * knows how many un-pool steps lie above a level, declares these runs with rep_of[V] (host array: the first row of the
  * run for its members, v itself for everything else).  Afterwards the handle's fake row sets (2 and 4) list only the
  * representatives, the other members ("holes") are never written nor read:
- *   forward   BatchNorm statistics count a representative once per member (p2m_stats_rows_w + p2m_bn_finalize_split);
+ *   forward   BatchNorm statistics count a representative once per member (the `stats` of p2m_gemm_planes_rows, or
+ *             p2m_stats_rows_w over a finished tensor; then p2m_bn_finalize_split);
  *             p2m_cheb_combine_small (the final conv) fills the holes of its OUTPUT with the representative's value;
  *   backward  a representative carries the SUM of its class's gradients -- everything downstream (BatchNorm backward,
  *             contractions, pair-sums, the weight gradient) is linear in it; p2m_class_reduce forms that sum from the

@@ -50,6 +50,9 @@ struct GemmArgs {
   // (tps tiles per sample); planes 1,2 of A are COMPACT ([B*nset, Ka]) when `compact`
   const int* ids;
   int nset, V, tps, compact;
+  // optional weights of the logical rows (aligned with ids): the BatchNorm partials count row i row_w[i] times (class
+  // representatives stand for their whole class); NULL = every row once
+  const float* row_w;
   // split-bf16 mode (k_gemm_planes_bx): Bx[k / 16][s][n][k % 16], s < 3, n < Npad, k < Ktot = nplanesA * Ka
   const unsigned short* Bx;
   int Npad, Ktot;
@@ -75,6 +78,19 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& mt
 }
 
 // Epilogue shared by the native-fp32 and the split-bf16 kernels: bias (+ addend), store (or pair-sum store), and the
+// ROWS kernels keep, behind the BM row indices, the BM row weights and the two per-wave weight totals (threads 0..BM-1 =
+// waves 0, 1 fill them; the k loop's barriers order the fill before the epilogue reads it)
+constexpr int ROWTAB_WORDS = 2 * BM + 2;
+__device__ __forceinline__ void rows_weights_fill(const GemmArgs& g, int* rowtab, int i, int t) {
+  float* wtab = reinterpret_cast<float*>(rowtab + BM);
+  const float w = (i < g.nset) ? g.row_w[i] : 0.f;
+  wtab[t] = w;
+  float s = w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((t & 63) == 0) wtab[BM + (t >> 6)] = s;
+}
+
 // per-tile BatchNorm partials (sum, centred M2).  `red` is block LDS that is free once the k loop is over.
 template <int BN, bool EXTRA, bool ROWS>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)[2][BN / 64], float* smem,
@@ -95,6 +111,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
   }
   float csum[TN];
   float vmax = 0.f;
+  const bool wst = ROWS && g.row_w != nullptr && g.stats != nullptr;      // weighted partials (block-uniform)
+  const float* wtab = reinterpret_cast<const float*>(rowtab + BM);
 #pragma unroll
   for (int j = 0; j < TN; j++) csum[j] = 0.f;
 #pragma unroll
@@ -117,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         acc[i][j][r] = rok ? v : 0.f;
         if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
           Cq[row * g.Nc + c] = v;
-          csum[j] += v;
+          csum[j] += wst ? wtab[ml] * v : v;
           vmax = fmaxf(vmax, amax_abs(v));
         }
       }
@@ -151,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
   for (int j = 0; j < TN; j++) {
     const int cl = wn * WTN + j * 32 + l31;
     const float tot = red[cl] + red[BN + cl];
-    const float mean = tot / (float)rows_valid;
+    const float mean = tot / (wst ? wtab[BM] + wtab[BM + 1] : (float)rows_valid);
     float m2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -159,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
       for (int r = 0; r < 16; r++) {
         const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         float d = acc[i][j][r] - mean;
-        if (ROWS ? (rowtab[ml] >= 0) : (m0 + ml < g.M)) m2 += d * d;
+        if (ROWS ? (rowtab[ml] >= 0) : (m0 + ml < g.M)) m2 += wst ? wtab[ml] * d * d : d * d;
       }
     m2 += __shfl_xor(m2, 32);
     cm2[j] = m2;
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   constexpr int AROWS = 256 / (KB / 4);           // rows of A covered per pass
   constexpr int BPASS = KB * BN / 4 / 256;        // float4 B loads per thread per chunk
   constexpr int BROWS = 256 / (BN / 4);           // rows of B covered per pass
-  __shared__ float smem[2 * BM * LDA + 2 * KB * BN + (ROWS ? BM : 0)];
+  __shared__ float smem[2 * BM * LDA + 2 * KB * BN + (ROWS ? ROWTAB_WORDS : 0)];
   float* As = smem;
   float* Bs = smem + 2 * BM * LDA;
   int* rowtab = reinterpret_cast<int*>(smem + 2 * BM * LDA + 2 * KB * BN);   // ROWS: actual row of each tile row, -1 = none
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
   if (ROWS && t < BM) {
     const int i = rs_i0 + t;
     rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
+    if (g.row_w != nullptr) rows_weights_fill(g, rowtab, i, t);
   }
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   constexpr int AROWS = 256 / (KB / 4);
   constexpr int A_BUF = NS * BM * LDX;
   constexpr int B_BUF = NS * BN * LDX;
-  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? BM : 0);
+  constexpr int SM_WORDS = NBUF * (A_BUF + B_BUF) / 2 + (ROWS ? ROWTAB_WORDS : 0);
   __shared__ __attribute__((aligned(16))) float smem[SM_WORDS];
   __shared__ __attribute__((aligned(16))) float actco[2 * 256];        // activation on load: scale | shift of plane 0's columns
   unsigned short* As = reinterpret_cast<unsigned short*>(smem);
@@ -390,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
   if (ROWS && t < BM) {
     const int i = rs_i0 + t;
     rowtab[t] = (i < g.nset) ? rs_b * g.V + g.ids[i] : -1;
+    if (g.row_w != nullptr) rows_weights_fill(g, rowtab, i, t);
   }
   const int lane = t & 63, wave = (t >> 6) & 3;
   const int wm = wave >> 1, wn = wave & 1;
@@ -1593,7 +1613,7 @@ extern "C" int p2m_gemm_planes(const float* A0, const float* A1, const float* A2
   g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift;
   g.N = nplanesC * Nc; g.Nc = Nc;
-  g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0;
+  g.ids = nullptr; g.nset = 0; g.V = 0; g.tps = 0; g.compact = 0; g.row_w = nullptr;
   g.Bx = nullptr; g.Npad = 0; g.Ktot = 0;
   g.a_amax = g.b_amax = nullptr; g.a_bits = 0;
   g.amax_out = static_cast<unsigned*>(amax_out);
@@ -1660,6 +1680,7 @@ extern "C" int p2m_gemm_planes_rows(p2m_graph_t gh, int32_t row_set, int32_t B, 
   g.act_scale = act_scale; g.act_shift = act_shift; g.act_relu = act_relu;
   g.nplanesA = nplanesA; g.Ka = Ka; g.a0_shift = a0_shift; g.N = N; g.Nc = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.tps = cdiv(rs.n, BM); g.compact = planes_compact;
+  g.row_w = (stats != nullptr && row_set == 2) ? gr.fake_wts : nullptr;   // representatives count once per class member
   g.Bx = arith == P2M_ARITH_F32 ? nullptr : static_cast<const unsigned short*>(Bsplit);
   g.Npad = cdiv(N, 128) * 128;
   g.Ktot = nplanesA * Ka;

@@ -546,7 +546,6 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     if f16x2() and amax is None:
         amax = _amax_planes(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
     st = None
-    weighted = stats and row_set == 2 and g.classes     # representatives count once per class member: separate pass
     if stats:
         tps = int(_lib.hip().p2m_rows_tiles_per_sample(g.handle, row_set))
         st = torch.empty((B * tps, 2, N), device=C.device, dtype=torch.float32)
@@ -560,13 +559,11 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
                                               int(amax_bits),
                                               _p(bias if bias is None else _req(bias, "bias")),
                                               _p(addend if addend is None else _req(addend, "addend")), _p(C), N,
-                                              _p(None if weighted else st), _p(None if act is None else act[0]),
+                                              _p(st), _p(None if act is None else act[0]),
                                               _p(None if act is None else act[1]), int(bool(act and act[2])),
                                               _p(amax_out), _p(None if in_act is None else _req(in_act[0], "in_scale")),
                                               _p(None if in_act is None else _req(in_act[1], "in_shift")), _stream()),
               "p2m_gemm_planes_rows")
-    if weighted and n > 0:
-        check(_lib.hip().p2m_stats_rows_w(g.handle, _p(C), B, N, _p(st), _stream()), "p2m_stats_rows_w")
     return st
 
 

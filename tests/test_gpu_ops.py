@@ -543,6 +543,16 @@ def test_classes_of_identical_fake_rows(ops):
     from pose2mesh_release_amd import _lib
     _lib.check(_lib.hip().p2m_stats_rows_w(g.handle, y_hole.data_ptr(), B, F, st_fake.data_ptr(), None), "stats_rows_w")
     gamma, beta = (torch.rand(F, generator=gen) + 0.5).cuda(), (torch.randn(F, generator=gen) * 0.1).cuda()
+    # the representatives' contraction emits the same weighted partials from its epilogue (both tile widths, N = 64 / 128)
+    for Fout in (64, 128):
+        Wt = (torch.randn(F, Fout, generator=gen) / 11).cuda()
+        bias = torch.randn(Fout, generator=gen).cuda()
+        c = torch.full((M, Fout), float("nan"), device="cuda")
+        st_epi = ops.gemm_planes_rows(g, 2, B, [y_hole.view(M, F)], F, 0, False, Wt, bias, None, c, Fout, True)
+        st_sep = torch.empty(B * ntf, 2, Fout, device="cuda")
+        _lib.check(_lib.hip().p2m_stats_rows_w(g.handle, c.data_ptr(), B, Fout, st_sep.data_ptr(), None), "stats_rows_w")
+        assert st_epi.shape == st_sep.shape and torch.isfinite(st_epi).all()
+        assert (st_epi - st_sep).abs().max().item() < 2e-5 * st_sep.abs().max().item()
     co = ops.bn_finalize_rows(g, B, st_real, st_fake, gamma, beta, None, None, 0.1, 1e-5)
     yd = y_full.view(M, F).double()
     assert (co[0].double() - yd.mean(0)).abs().max() < 1e-6
