@@ -384,7 +384,8 @@ def test_three_adam_steps_vs_oracle(hip_libs):
     loss.backward()
     g_ref = {k: (sd[k].grad.clone() if sd[k].grad is not None else None) for k in names}
     opt.step()
-    assert abs(hip_loss - float(loss)) <= 1e-5 * abs(float(loss)), (hip_loss, float(loss))
+    ref_loss = float(loss.detach())
+    assert abs(hip_loss - ref_loss) <= 1e-5 * abs(ref_loss), (hip_loss, ref_loss)
     got = dict(step.model.named_parameters())
     n_checked, worst = 0, 0.0
     def zero_grad_param(k):          # exactly-zero true gradient (a bias in front of a train-mode BatchNorm): pure noise
