@@ -9,7 +9,8 @@
     returns (B, V, Fout); no activation inside (the caller applies ReLU, meshnet.py:100).
 
 Differentiable w.r.t. x, cl.weight, cl.bias, bn.weight, bn.bias.  K = 3 is the native kernel path
-(every Pose2Mesh layer); K = 1, 2 reuse it with zero-padded weight planes; K > 3 is not implemented.
+(every Pose2Mesh layer); K = 1, 2 reuse it with zero-padded weight planes; K > 3 runs the recurrence on the HIP basis
+kernel (both of its planes used per launch) and the stock nn.Linear / BatchNorm1d.
 """
 import threading
 
@@ -97,39 +98,52 @@ class _ChebConvFn(torch.autograd.Function):
         return dX.view(xshape), dW, db, dgamma, dbeta, None, None, None
 
 
-class _LApplyFn(torch.autograd.Function):
-    """y = L x on the vertex axis (the L plane of p2m_cheb_basis_fwd); L is symmetric (lib/coarsening.py:23), so the
-    backward is the same product."""
+class _LL2Fn(torch.autograd.Function):
+    """(L x, L2 x) on the vertex axis, L2 = 2 L L - I: BOTH planes of one p2m_cheb_basis_fwd launch.  L and L2 are symmetric
+    (lib/coarsening.py:23), so the backward is gx = L g1 + L2 g2 - one launch per incoming gradient that is not None."""
 
     @staticmethod
     def forward(ctx, x, g):
         B, V, F = x.shape
         ctx.g, ctx.B, ctx.F = g, B, F
+        ctx.set_materialize_grads(False)        # an unused plane arrives as None in backward, not as a zero tensor
         with torch.cuda.device(x.device):
-            T1, _ = ops.cheb_basis_fwd(g, x.contiguous().float().view(B * V, F), B, F, 0)
-        return T1.view(B, V, F)
+            T1, T2 = ops.cheb_basis_fwd(g, x.contiguous().float().view(B * V, F), B, F, 0)
+        return T1.view(B, V, F), T2.view(B, V, F)
 
     @staticmethod
-    def backward(ctx, gout):
-        with torch.cuda.device(gout.device):
-            T1, _ = ops.cheb_basis_fwd(ctx.g, gout.contiguous().float().view(-1, ctx.F), ctx.B, ctx.F, 0)
-        return T1.view_as(gout), None
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None, None
+        gx = None
+        with torch.cuda.device((g1 if g1 is not None else g2).device):
+            if g1 is not None:
+                gx, _ = ops.cheb_basis_fwd(ctx.g, g1.contiguous().float().view(-1, ctx.F), ctx.B, ctx.F, 0)
+            if g2 is not None:
+                _, t2 = ops.cheb_basis_fwd(ctx.g, g2.contiguous().float().view(-1, ctx.F), ctx.B, ctx.F, 0)
+                gx = t2 if gx is None else gx + t2
+        return gx.view(ctx.B, -1, ctx.F), None
 
 
 def _graph_conv_cheby_any_order(x, cl, bn, g, Fout, K):
     """Chebyshev orders K > 3 (lib/models/backbones/cheby_graph_conv.py:27-30 is generic in K; Pose2Mesh itself uses K = 3
-    everywhere, which is what the fused kernels are built for): the recurrence T_k = 2 L T_(k-1) - T_(k-2) on the HIP
-    L-product, then the reference's own (B*V, Fin*K) layout, column fin*K + k (:32-34), through nn.Linear / BatchNorm1d."""
+    everywhere, which is what the fused kernels are built for).  Every launch of the HIP basis kernel yields L x and
+    (2 L L - I) x, and both are used: x_1, x_2 come from x_0 as in the K = 3 path, then one launch on x_(k-1) gives
+        x_k     = 2 L x_(k-1) - x_(k-2)                       (the reference's recurrence, :28)
+        x_(k+1) = 2 (2 L L - I) x_(k-1) - x_(k-3)             (T_(n+2) = 2 T_2 T_n - T_(n-2): the same polynomial)
+    - half the launches of a plane-by-plane recurrence and no discarded plane.  Then the reference's own (B*V, Fin*K)
+    layout, column fin*K + k (:32-34), through nn.Linear / BatchNorm1d."""
     B, V, Fin = x.shape
     x0 = x.float()
-    planes = [x0]
-    x1 = _LApplyFn.apply(x0, g)
-    planes.append(x1)
-    for _ in range(2, K):
-        x2 = 2 * _LApplyFn.apply(x1, g) - x0
-        planes.append(x2)
-        x0, x1 = x1, x2
-    y = cl(torch.stack(planes, dim=3).reshape(B * V, Fin * K))
+    x1, x2 = _LL2Fn.apply(x0, g)
+    planes = [x0, x1, x2]
+    while len(planes) < K:
+        k = len(planes)
+        a, b = _LL2Fn.apply(planes[k - 1], g)
+        planes.append(2 * a - planes[k - 2])
+        if k + 1 < K:
+            planes.append(2 * b - planes[k - 3])
+    y = cl(torch.stack(planes[:K], dim=3).reshape(B * V, Fin * K))
     if bn is not None:
         y = bn(y)
     return y.view(B, V, Fout)

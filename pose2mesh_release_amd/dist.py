@@ -44,9 +44,13 @@ def ranks_seen(device=None):
         return {"backend": None, "world": 1, "ranks": [0]}
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
+    if device is not None:
+        device = torch.device(device)                  # "cuda:1", torch.device("cuda") ... all accepted
     if device is None and torch.cuda.is_available():
         device = torch.device("cuda", torch.cuda.current_device())
-    local = device.index if (device is not None and torch.device(device).type == "cuda") else -1
+    if device is not None and device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    local = device.index if (device is not None and device.type == "cuda") else -1
     # the exchange itself runs where the backend can run it: RCCL on the GPU, gloo on the host
     mine = torch.tensor([rank, local], dtype=torch.int64, device=device if backend == "nccl" else torch.device("cpu"))
     out = [torch.zeros_like(mine) for _ in range(world)]

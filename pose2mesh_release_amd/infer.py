@@ -24,7 +24,9 @@ class GraphedInference:
     users of the same module object see that layout too.  The captured graph holds raw pointers to the derived weight
     operands (packed / split weights, eval BatchNorm coefficients) that existed at capture time; the instance keeps
     those tensors alive, and when the weights change afterwards (optimizer steps, load_state_dict, a train-mode forward:
-    ops.WEIGHT_EPOCH or a parameter's version moves) the next call re-captures instead of replaying stale operands."""
+    ops.WEIGHT_EPOCH, or the (pointer, version) of ANY parameter or buffer moves - checked on every call) the next call
+    re-captures instead of replaying stale operands.  (Edits made through `tensor.data` do not move Tensor._version - torch
+    gives `.data` its own counter -: a caller that writes weights that way calls ops.bump_weight_epoch() afterwards.)"""
 
     def __init__(self, model, perm_reverse, nv, joint_regressor, batch, scale=1000.0, use_graph=True, warmup=3):
         p = next(model.parameters())
@@ -43,24 +45,23 @@ class GraphedInference:
         self.captures = 0
         self._capture()
 
-    # The full walk over every parameter / buffer (pointer, version) costs ~0.2 ms of host time - a tenth of a batch-64
-    # replay.  Checked on EVERY call: ops.WEIGHT_EPOCH (bumped by the flat optimizers, every train-mode forward and
-    # GraphedTrainStep) and a few SENTINEL tensors (first / last parameter, first / last buffer: any optimizer step or
-    # load_state_dict moves all of them).  The full walk - which also catches an in-place edit of one arbitrary tensor -
-    # runs on the first call after a capture and then every FULL_CHECK_EVERY calls.
-    FULL_CHECK_EVERY = 16
-
+    # Checked on EVERY call, exactly: ops.WEIGHT_EPOCH (bumped by the flat optimizers, every train-mode forward and
+    # GraphedTrainStep, which move weights by raw pointer) and the (pointer, version) of EVERY parameter and buffer - an
+    # in-place edit of one interior tensor (`net.cl[7].weight.data.copy_(...)`, a partial load_state_dict) moves nothing
+    # else.  The tensor list is cached at capture time, so the check is one pass of two attribute reads per tensor (~40 us
+    # for the ~190 tensors of FlatPose2Mesh; the 0.2 ms a naive check costs is the model.parameters() walk, not this).
     def _weights_tag(self):
         return (_ops.WEIGHT_EPOCH,) + tuple((t.data_ptr(), t._version) for t in self._tensors)
 
     def _weights_moved(self):
         if _ops.WEIGHT_EPOCH != self._tag[0]:
             return True
-        if any((t.data_ptr(), t._version) != self._tag[1 + i] for i, t in self._sentinels):
-            return True
-        self._calls += 1
-        if self._calls == 1 or self._calls % self.FULL_CHECK_EVERY == 0:
-            return self._weights_tag() != self._tag
+        tag = self._tag
+        i = 1
+        for t in self._tensors:
+            if (t.data_ptr(), t._version) != tag[i]:
+                return True
+            i += 1
         return False
 
     def _capture(self):
@@ -72,9 +73,6 @@ class GraphedInference:
             self.graph = None
             params, bufs = list(self.model.parameters()), list(self.model.buffers())
             self._tensors = params + bufs
-            idx = sorted({0, len(params) - 1, len(params), len(self._tensors) - 1} & set(range(len(self._tensors))))
-            self._sentinels = [(i, self._tensors[i]) for i in idx]
-            self._calls = 0
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):              # warm-up: graph handles, weight packs, allocator pools

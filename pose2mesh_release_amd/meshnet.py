@@ -434,7 +434,9 @@ class _MeshNetFn(torch.autograd.Function):
                     h = ctx.fc_saved
                     Nf, Kf = fw.shape
                     tg = tgt("fc.weight", "fc.bias")
-                    if ops.GEMM_ARITH != "f32" and Nf % 32 == 0 and Kf % 32 == 0:
+                    if ops.GEMM_ARITH != "f32" and B % 4 == 0 and B >= 32 and Nf % 32 == 0 and Kf % 32 == 0:
+                        # (the forward's gate: small / odd batches keep the plane contraction - their dh reduction would
+                        #  have Ka = B and fall to the scalar kernel)
                         # A batch-sized Linear (M = B rows) is two more weight-gradient-shaped contractions (reductions over a
                         # long index with both operands row-major over it), not plane contractions - those would put
                         # 2 x N/128 blocks on 256 CUs:

@@ -377,7 +377,8 @@ def new_amax(device):
     """One zeroed amax word.  A chunk belongs to the capture state it was created in: a chunk made before a stream capture
     is never re-zeroed by the graph's replays (its words would only grow), and one made INSIDE a capture is graph-private
     memory (zeroed by every replay, uninitialised before the first) - so the chunk is dropped whenever that state flips.
-    A chunk is zeroed on the stream that created it; any other stream that draws a word from it first waits for that."""
+    A chunk is zeroed on the stream that created it; any other stream that draws a word from it first waits for that
+    (inside a capture the record / wait pair becomes a dependency edge of the graph)."""
     key = torch.device(device).index
     if key is None:
         key = torch.cuda.current_device()
@@ -387,10 +388,10 @@ def new_amax(device):
         with torch.cuda.device(key):
             buf = torch.zeros(256, dtype=torch.int32, device=torch.device("cuda", key))
             st = torch.cuda.current_stream()
-            ev = None
-            if not cap:
-                ev = torch.cuda.Event()
-                ev.record(st)
+            # also inside a stream capture: event record / wait are capturable and become an EDGE of the graph - a chunk
+            # that rolls over on the weight-gradient side stream is then zeroed before the main stream's later atomics on it
+            ev = torch.cuda.Event()
+            ev.record(st)
         ent = [buf, 0, cap, ev, {st.cuda_stream}]
         _amax_chunks[key] = ent
     elif ent[3] is not None:

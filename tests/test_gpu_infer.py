@@ -125,6 +125,40 @@ def test_graphed_inference_recaptures_when_the_weights_change(hip_libs):
     assert torch.equal(m1, ref)
 
 
+def test_graphed_inference_recaptures_on_an_interior_in_place_edit(hip_libs):
+    """ADVICE r4 (infer.py:127): an in-place edit of ONE interior tensor (a middle conv's weight, one layer's BatchNorm
+    statistics) bumps neither ops.WEIGHT_EPOCH nor the first / last parameter or buffer.  The very next call must still
+    re-capture (the check walks every parameter and buffer on every call) and return the new weights' result."""
+    from pose2mesh_release_amd import infer, loss as L, synth
+    net, sd, gL, rev, J = _flat("mano")
+    nv, B = 778, 3
+    jreg = synth.synthetic_regressor(J, nv)
+    x = synth.pose2d_batch(B, J, seed=6).cuda()
+    step = infer.GraphedInference(net, rev, nv, jreg, B, scale=1000.0)
+    for _ in range(3):                                          # (any position in a would-be check period)
+        m0 = step(x)[0].clone()
+    assert step.captures == 1
+    mid = len(net.pose2mesh.cl) // 2
+    with torch.no_grad():
+        net.pose2mesh.cl[mid].weight.mul_(1.25)                 # interior parameter, in place, no epoch bump
+        # (edits through `.data` do not move Tensor._version - torch gives `.data` its own counter - and are invisible to
+        #  every cache of this package as they are to autograd: such callers say so with ops.bump_weight_epoch())
+    m1 = step(x)[0].clone()
+    assert step.captures == 2, "an interior in-place weight edit must re-capture on the very next call"
+    assert not torch.equal(m0, m1)
+    with torch.no_grad():
+        net.pose2mesh.bn[mid].running_var.mul_(2.0)             # interior buffer
+    m2 = step(x)[0].clone()
+    assert step.captures == 3 and not torch.equal(m1, m2)
+    step(x)
+    assert step.captures == 3                                   # nothing moved: plain replay
+    net.set_inference(real_only=False)
+    with torch.no_grad():
+        cam, _ = net(x)
+    ref = L.MeshEpilogue(rev, nv, jreg, scale=1000.0)(cam)[0]
+    assert torch.equal(m2, ref)
+
+
 def test_graphed_inference_at_configs1_size_vs_oracle(hip_libs):
     """BASELINE configs[1] on the bench's own path: batch 64, J=17, the captured hipGraph of the real-vertices-only
     forward + Tester epilogue; 4 samples of that batch against the oracle (eval-mode samples are independent)."""
