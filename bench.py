@@ -352,7 +352,16 @@ def main():
                          "`none` switches them off")
     ap.add_argument("--no-arith-ab", action="store_true",
                     help="skip the same-process A/B of the other contraction arithmetics (`arith_ab`)")
+    ap.add_argument("--arith", default=None, choices=["bf16x3", "f16x2", "f32"],
+                    help="contraction arithmetic of the MAIN measurement (`value`).  Default: $P2M_GEMM_ARITH if set, else "
+                         "bf16x3 - the exact fp32 emulation (24-bit operands): the reference computes in fp32, so the headline "
+                         "is quoted on an fp32-equivalent arithmetic; the package's fast mode f16x2 (22-bit operands, its "
+                         "import-time default) is measured beside it under `arith_ab`, at the same protocol")
     args = ap.parse_args()
+    main_arith = args.arith or os.environ.get("P2M_GEMM_ARITH") or "bf16x3"
+    if main_arith != ops.GEMM_ARITH:
+        ops.GEMM_ARITH = main_arith
+        ops.bump_weight_epoch()
     infer = args.mode == "infer"
     default_run = (not infer and args.batch is None and args.joint_set is None and not args.train_graph
                    and not args.stock_losses and args.optimizer == "adam")
@@ -373,10 +382,31 @@ def main():
 
     rank, world, local = p2m_dist.init_from_env()
     if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}: using WORLD_SIZE", file=sys.stderr)
+        # a line that says n_gpus = N must come from N ranks: `--gpus N` without torchrun (WORLD_SIZE unset) or with another
+        # world size is refused instead of silently measuring something else
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with `python -m "
+                         f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {args.gpus} ...` (no line printed)")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    seen, functional_only = None, False
+    if world > 1:
+        # every rank sees every rank over the job's backend, which must be RCCL ("nccl") with one distinct GPU per rank -
+        # else no line: a 1-rank fallback or two ranks on one GPU cannot pass for a scaling point.  The one exception is
+        # spelled out by the caller: P2M_DIST_BACKEND=gloo (tests/test_gpu_dist.py: two ranks sharing the only GPU),
+        # and the line then says `valid_scaling_point: false`.
+        seen = p2m_dist.ranks_seen(device)
+        functional_only = os.environ.get("P2M_DIST_BACKEND", "") not in ("", "nccl")
+        problems = []
+        if seen["world"] != args.gpus or sorted(seen["ranks"]) != list(range(args.gpus)):
+            problems.append(f"ranks seen {seen['ranks']} (world {seen['world']}) != 0..{args.gpus - 1}")
+        if not functional_only:
+            if seen["backend"] != "nccl":
+                problems.append(f"backend {seen['backend']!r} is not nccl (RCCL)")
+            if len(set(seen["local_devices"])) != args.gpus or min(seen["local_devices"]) < 0:
+                problems.append(f"local devices {seen['local_devices']}: not {args.gpus} distinct GPUs")
+        if problems:
+            raise SystemExit("[bench] refusing to print a line: " + "; ".join(problems))
     if infer:
         step = InferStep(device, args.batch, args.joint_set, path=args.infer_path)
     else:
@@ -396,8 +426,6 @@ def main():
         step = p2m_train.GraphedTrainStep(eager_step.model, eager_step.opt, eager_step.loss_fn, warmup=2)
         args.warmup = max(args.warmup, 4)              # 2 eager steps, the capture, one replay before the clock starts
         graphed = True
-    if world > 1:
-        seen = p2m_dist.ranks_seen(device)            # every rank sees every rank over the job's backend (RCCL)
     dt, per_step_ms = timed_run(step, args.warmup, args.steps, barrier)
     ksteps = min(args.steps, 10)          # steps of the per-kernel timing pass (untimed; ~1 200 HIP events per step)
     if not args.no_kernel_timing:
@@ -457,18 +485,21 @@ def main():
     arith_ab = None
     if world == 1 and not infer and not args.no_arith_ab and not train_graph:
         arith_ab = {}
-        main_arith = ops.GEMM_ARITH
-        for ar in ("bf16x3", "f32"):
+        for ar in ("bf16x3", "f16x2", "f32"):
             if ar == main_arith:
                 continue
+            # the two matrix-pipe arithmetics at the protocol of the main leg; the native-f32 reference point briefly
+            w2, k2 = (args.warmup, args.steps) if ar != "f32" else (3, 10)
             ops.GEMM_ARITH = ar
             ops.bump_weight_epoch()
             try:
                 st2 = TrainStep(device, args.batch, args.joint_set, world, edge_loss=not args.no_edge_loss,
                                 stock_losses=args.stock_losses, optimizer=args.optimizer)
-                d2, ps2 = timed_run(st2, 3, 10, barrier)
-                arith_ab[ar] = {"value": round(args.batch * 10 / d2, 2), "unit": "meshes/s", "steps": 10, "warmup": 3,
-                                "ms_per_step_median": step_stats(ps2)["median"], "dtype": DTYPE_NOTE[ar]}
+                d2, ps2 = timed_run(st2, w2, k2, barrier)
+                stt = step_stats(ps2)
+                arith_ab[ar] = {"value": round(args.batch * k2 / d2, 2), "unit": "meshes/s", "steps": k2, "warmup": w2,
+                                "ms_per_step_median": stt["median"], "ms_per_step_p10_p90": [stt["p10"], stt["p90"]],
+                                "dtype": DTYPE_NOTE[ar]}
                 del st2
             finally:
                 ops.GEMM_ARITH = main_arith
@@ -478,29 +509,38 @@ def main():
     # ---- the other single-GPU configurations of BASELINE.json, measured by the same command (`--also`)
     also_out = {}
     if world == 1 and also:
-        for leg in also:
+        def also_leg(leg):
             if leg == "infer":
                 st3 = InferStep(device, 64, "human36", path="graph")
                 d3, ps3 = timed_run(st3, 20, 100, barrier)
-                also_out["configs[1]_infer"] = {
-                    "metric": "SMPL meshes/sec fwd at batch 64", "value": round(64 * 100 / d3, 2), "unit": "meshes/s",
-                    "steps": 100, "warmup": 20, "ms_per_step": round(1000 * d3 / 100, 3),
-                    "ms_per_step_stats": step_stats(ps3),
-                    "workload": f"configs[1]: batch=64 synthetic human36 2D poses (J={st3.J}), SMPL-like hull mesh {st3.nv} "
-                                f"verts (padded {st3.V0}), FlatPose2Mesh eval forward + Tester epilogue, captured hipGraph of "
-                                f"the real-vertices-only inference path (python bench.py --mode infer)"}
-            else:
-                st3 = TrainStep(device, 512, "mano", 1, edge_loss=not args.no_edge_loss)
-                d3, ps3 = timed_run(st3, 5, 20, barrier)
-                also_out["configs[4]_mano"] = {
-                    "metric": "MANO meshes/sec fwd+bwd", "value": round(512 * 20 / d3, 2), "unit": "meshes/s",
+                return {"metric": "SMPL meshes/sec fwd at batch 64", "value": round(64 * 100 / d3, 2), "unit": "meshes/s",
+                        "steps": 100, "warmup": 20, "ms_per_step": round(1000 * d3 / 100, 3),
+                        "ms_per_step_stats": step_stats(ps3), "dtype": DTYPE_NOTE[ops.GEMM_ARITH],
+                        "workload": f"configs[1]: batch=64 synthetic human36 2D poses (J={st3.J}), SMPL-like hull mesh {st3.nv} "
+                                    f"verts (padded {st3.V0}), FlatPose2Mesh eval forward + Tester epilogue, captured hipGraph of "
+                                    f"the real-vertices-only inference path (python bench.py --mode infer)"}
+            st3 = TrainStep(device, 512, "mano", 1, edge_loss=not args.no_edge_loss)
+            d3, ps3 = timed_run(st3, 5, 20, barrier)
+            return {"metric": "MANO meshes/sec fwd+bwd", "value": round(512 * 20 / d3, 2), "unit": "meshes/s",
                     "steps": 20, "warmup": 5, "ms_per_step": round(1000 * d3 / 20, 3),
-                    "ms_per_step_stats": step_stats(ps3),
+                    "ms_per_step_stats": step_stats(ps3), "dtype": DTYPE_NOTE[ops.GEMM_ARITH],
                     "workload": f"configs[4]: batch=512 synthetic mano 2D poses (J={st3.J}), MANO-like hull mesh {st3.nv} "
                                 f"verts (padded {st3.V0}), FlatPose2Mesh fwd + 5 reference losses + bwd + Adam "
                                 f"(python bench.py --joint-set mano --batch 512)"}
-            del st3
+        for leg in also:
+            key = "configs[1]_infer" if leg == "infer" else "configs[4]_mano"
+            also_out[key] = also_leg(leg)                    # in the arithmetic of the main measurement
             torch.cuda.empty_cache()
+            if main_arith != "f16x2":                        # ... and in the package's fast mode, beside it
+                ops.GEMM_ARITH = "f16x2"
+                ops.bump_weight_epoch()
+                try:
+                    fast = also_leg(leg)
+                finally:
+                    ops.GEMM_ARITH = main_arith
+                    ops.bump_weight_epoch()
+                also_out[key]["fast_mode_f16x2"] = {k: fast[k] for k in ("value", "unit", "ms_per_step", "dtype")}
+                torch.cuda.empty_cache()
     if train_graph:
         step = eager_step                    # the attributes the report reads live on the TrainStep
 
@@ -539,6 +579,8 @@ def main():
                                                "native f32 MFMA's (tests/test_gpu_ops.py::test_f16x2_error_is_fp32_class)",
                                       "f32": "native f32 MFMA"}[ops.GEMM_ARITH],
                        "grad_allreduce_MB": round(step.opt.numel * 4 / 1e6, 1) if (world > 1 and not infer) else 0,
+                       **({"backend": seen["backend"], "local_devices": seen["local_devices"],
+                           "valid_scaling_point": not functional_only} if seen is not None else {}),
                        **({"train_step": "one captured hipGraph (train.GraphedTrainStep); kernel timings from the same "
                                          "launches issued one by one after the timed region"} if train_graph else {})},
         }
@@ -687,10 +729,12 @@ def main():
                                         "warmup": args.warmup, "ms_per_step_median": line["ms_per_step_stats"]["median"],
                                         "dtype": DTYPE_NOTE[ops.GEMM_ARITH], "note": "the main measurement of this line"}
             line["arith_ab"] = dict(arith_ab, note="same process, same box, same synthetic batch: a fresh TrainStep per "
-                                                    "contraction arithmetic (P2M_GEMM_ARITH), 3 warm-up + 10 timed steps "
-                                                    "for the two that are not the default; bf16x3 is the exact-fp32 "
-                                                    "emulation (24-bit operands), f32 the native f32 MFMA (which also "
-                                                    "switches the tile kernels off: they exist in the slice arithmetics "
+                                                    "contraction arithmetic; `value` of this line is bf16x3 = the exact fp32 "
+                                                    "emulation (24-bit operands, what the reference's fp32 arithmetic maps to); "
+                                                    "f16x2 = the package's tolerance-compliant FAST MODE (22-bit operands, "
+                                                    "vertex L2 vs float64 1.4e-5 at this batch - NOT the headline), measured at "
+                                                    "the same warm-up / step counts; f32 = native f32 MFMA, 3 + 10 steps (it "
+                                                    "also switches the tile kernels off: they exist in the slice arithmetics "
                                                     "only)")
         if also_out:
             line["also"] = also_out

@@ -71,7 +71,7 @@ struct TileGemmArgs {
   const float* addend;         // [B][c_rows][N] or null
   const float* act_scale;      // optional fused eval-mode BatchNorm (+ ReLU), the two roundings of p2m_bn_act_fwd
   const float* act_shift;
-  const float* in_scale;       // optional activation ON LOAD (k_cheb_mg_gemm): X and A0 hold the RAW output y of the previous
+  const float* in_scale;       // optional activation ON LOAD (both kernels): X and A0 hold the RAW output y of the previous
   const float* in_shift;       // conv and the operand is x = max(fma(y, in_scale[f], in_shift[f]), 0) - its BatchNorm + ReLU,
                                // the two roundings of p2m_bn_act_fwd - so that x is never written to / read from HBM
   float* C;                    // [B][c_rows][N]
@@ -406,7 +406,25 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       for (int ps = 0; ps < NRP; ps++) p0[ps] = *reinterpret_cast<const f32x4*>(base + a0off[ps]);
       if (++pfc == nchunks) { pfc = 0; pg++; }
     };
+    // activation on load (in_scale != nullptr; round 5: also in this kernel, i.e. in both slice arithmetics): X / A0 hold the
+    // RAW output y of the previous conv; the union rows get max(fma(y, scale, shift), 0) on their way into LDS, plane 0 in
+    // front of its split - the two roundings of p2m_bn_act_fwd.  store_xs walks the units 0, 1, 2, ... : own chunk counter.
+    const bool in_act = g.in_scale != nullptr;          // block-uniform
+    int sfc_x = 0;
+    auto act_coeffs = [&](int fc, f32x4& sc, f32x4& sh) {
+      sc = *reinterpret_cast<const f32x4*>(g.in_scale + fc * CT_CF + q * 4);
+      sh = *reinterpret_cast<const f32x4*>(g.in_shift + fc * CT_CF + q * 4);
+    };
     auto store_xs = [&]() {
+      if (in_act) {
+        f32x4 sc, sh;
+        act_coeffs(sfc_x, sc, sh);
+#pragma unroll
+        for (int ps = 0; ps < NPU; ps++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) pf[ps][c] = fmaxf(fmaf(pf[ps][c], sc[c], sh[c]), 0.f);
+        if (++sfc_x == nchunks) sfc_x = 0;
+      }
 #pragma unroll
       for (int ps = 0; ps < NPU; ps++) {
         const int u = lu + ps * RPP;
@@ -422,6 +440,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     for (int w = 0; w < nunits; w++) {
       u32x2 sp[NRP][3][NS];                             // [row][plane][slice]: the A operand of this unit, held until the
                                                         // MFMA waves release the image
+      if (in_act) {                                     // plane 0 of unit w = (grp, fc)
+        f32x4 sc, sh;
+        act_coeffs(fc, sc, sh);
+#pragma unroll
+        for (int ps = 0; ps < NRP; ps++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) p0[ps][c] = fmaxf(fmaf(p0[ps][c], sc[c], sh[c]), 0.f);
+      }
 #pragma unroll
       for (int ps = 0; ps < NRP; ps++) {
         f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
@@ -1000,8 +1026,7 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
                                   const float* in_scale, const float* in_shift, int32_t B, void* stream) {
   P2M_CHECK_ARG(gh && X && A0 && Bx && C, "null pointer");
   P2M_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must both be given or both NULL");
-  P2M_CHECK_ARG(in_scale == nullptr || (arith == P2M_ARITH_F16X2 && N <= 128 && (E1 == nullptr)),
-                "activation on load exists in the matrix-core-gather kernel only (P2M_ARITH_F16X2, N <= 128, no planes out)");
+  P2M_CHECK_ARG(in_scale == nullptr || E1 == nullptr, "activation on load excludes the planes out");
   P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || x_amax != nullptr, "P2M_ARITH_F16X2 needs the amax word of X / A0");
   P2M_CHECK_ARG(plan >= 0 && plan <= 2, "plan must be 0 (level), 1 (un-pooled input) or 2 (paired operator)");

@@ -265,7 +265,7 @@ class _MeshNetFn(torch.autograd.Function):
                 fold_out = bool(training and L.has_bn and not L.last_in_block and Ln is not None and Ln.graph == L.graph
                                 and (ops.fold_act_ok(g, Ln.Fin, 32, B, narrow=True) if _narrow(Ln) else
                                      (_bwd_forward_form(Ln) and ops.fold_act_ok(g, Ln.Fin, Ln.Fout, B))))
-                yword = ops.new_amax(cur.device) if fold_out else None
+                yword = ops.new_amax(cur.device) if (fold_out and ops.f16x2()) else None
                 T1, T2, st, st2, tiled = ops.conv_split(g, B, cur, L.Fin, cur_shift, Wt, bvec, None, y, L.Fout, g.fake_a,
                                                         g.fake_b, need_stats, operands=opf, want_planes=False,
                                                         amax_out=yword, in_act=fold)
@@ -308,7 +308,9 @@ class _MeshNetFn(torch.autograd.Function):
                     # plane 0 of the contraction / fake-row contraction / narrow projection) and its weight gradients read y
                     # and apply the activation on load.  `out` is y under a second tensor object that carries the bound of
                     # the ACTIVATED tensor as its amax word.
-                    out = ops.tag_amax(y.view(M, L.Fout), ops.act_bound(co[2], co[3], yword, ops.new_amax(y.device)))
+                    out = y.view(M, L.Fout)
+                    if yword is not None:     # (f16x2; the exact bf16 slices need no bound)
+                        ops.tag_amax(out, ops.act_bound(co[2], co[3], yword, ops.new_amax(y.device)))
                     fold = (co[2], co[3])
                 else:
                     out = ops.bn_act_fwd(y, co, True, resid, block_in_F, block_in_shift, M, L.Fout,

@@ -542,7 +542,7 @@ def gemm_planes_rows(g, row_set, B, A, Ka, a0_shift, compact, Bm, bias, addend, 
     bound of what is stored.  in_act = (scale[Ka], shift[Ka]): activation on load of plane 0 (A[0] is a raw conv output);
     amax must then bound the activated operand."""
     n = g.set_size(row_set)
-    if in_act is not None and amax is None:
+    if in_act is not None and amax is None and f16x2():
         raise P2MError("gemm_planes_rows: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2() and amax is None:
         amax = _amax_planes(A, g if (a0_shift == 0 and row_set <= 2) else None, B)
@@ -689,7 +689,7 @@ def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, w
     X's own); amax_out: a zeroed word that receives the bound of what is stored.  in_act = (scale[Ka], shift[Ka]):
     activation on load - X / A0 hold a raw conv output y, the operand is relu(y * scale + shift); amax must bound THAT."""
     nset = g.n_pair_real if plan == 2 else g.n_real
-    if in_act is not None and amax is None:
+    if in_act is not None and amax is None and f16x2():
         raise P2MError("cheb_tile_gemm: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2() and amax is None:
         amax = amax_of(X, g if plan != 1 else None, B)
@@ -748,11 +748,12 @@ BASIS_TILED = _os.environ.get("P2M_BASIS_TILED", "1") == "1"     # (the library 
 
 def fold_act_ok(g, Ka, N, B, narrow=False):
     """True when a conv with input width Ka and output width N on the (split) level g can take its input as a RAW conv
-    output with the activation applied on load (FOLD_ACT).  Three consumer forms implement it: the matrix-core tile kernel
-    on the level's own plan (N <= 128); the LDS-staged basis kernel + plane contraction (needs the level's tile plan, Ka <=
+    output with the activation applied on load (FOLD_ACT; both slice arithmetics since round 5 - bf16x3 needs no amax
+    bound).  Three consumer forms implement it: the tile kernels on the level's own plan (N <= 128: the matrix-core gather
+    in f16x2, the VALU gather in bf16x3); the LDS-staged basis kernel + plane contraction (needs the level's tile plan, Ka <=
     256); the narrow final conv's projection (row-set contractions: needs declared classes).  The fake-vertex rows and every
     weight gradient read the raw tensor through the same on-load activation."""
-    if not (FOLD_ACT and f16x2() and g.split and Ka <= 256 and Ka % 32 == 0):
+    if not (FOLD_ACT and GEMM_ARITH != "f32" and g.split and Ka <= 256 and Ka % 32 == 0):
         return False
     if narrow:
         return bool(g.classes)
@@ -822,7 +823,7 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_
     words of A and of the G planes (after g_bits binades); default: the tensors' own.  a_act = (scale[Ka], shift[Ka]):
     activation on load of A (a raw conv output); a_amax must then bound the activated operand."""
     n = g.set_size(row_set)
-    if a_act is not None and a_amax is None:
+    if a_act is not None and a_amax is None and f16x2():
         raise P2MError("gemm_tn_rows: activation on load needs the amax word of the activated operand (act_bound)")
     if f16x2():
         if a_amax is None:

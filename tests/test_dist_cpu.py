@@ -129,3 +129,66 @@ def test_two_backward_calls_share_one_reducer(tmp_path):
     (model["a"](X).pow(2).mean() + model["b"](X).abs().mean()).backward()
     assert got["nb"] >= 2
     assert (got["flat"] - flat).abs().max() < 1e-6
+
+
+def _worker_world8(rank, world, port, out):
+    """BASELINE configs[3]'s topology on CPU: 8 ranks x B/8 samples, gradients of one flat buffer reduced in several
+    buckets whose LAST one is smaller than the rest; per-rank BatchNorm statistics (DataParallel semantics,
+    lib/core/base.py:108) - only the gradients are exchanged."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from pose2mesh_release_amd import dist as pd
+    r, w, _ = pd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    seen = pd.ranks_seen()
+    assert seen["world"] == world and seen["ranks"] == list(range(world))
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.BatchNorm1d(40), torch.nn.ReLU(),
+                                torch.nn.Linear(40, 31), torch.nn.BatchNorm1d(31), torch.nn.ReLU(), torch.nn.Linear(31, 7))
+    params, offsets, flat = _flat_setup(model)
+    red = pd.BucketedAllReduce(params, offsets, flat, bucket_bytes=2000)       # 500-float buckets, 2 188 floats in all
+    sizes = [e - s for s, e, _ in red.buckets]
+    assert len(sizes) >= 3 and sizes[-1] < max(sizes), sizes                  # several buckets, an uneven last one
+    assert [s for s, _, _ in red.buckets] == sorted(s for s, _, _ in red.buckets)     # buckets in buffer order
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(64, 12, generator=g), torch.randn(64, 7, generator=g)
+    n = 64 // world
+    xs, ys = X[rank * n:(rank + 1) * n], Y[rank * n:(rank + 1) * n]
+    for _ in range(2):
+        flat.zero_()
+        ((model(xs) - ys) ** 2).mean().backward()
+        flat.mul_(red.finish())
+        # gradients are written LAST layer first: the buckets must have been launched from the back of the buffer
+        order = [b for b, _ in red.last_launch_log]
+        assert sorted(order) == list(range(len(red.buckets))) and order[0] == len(red.buckets) - 1, order
+    torch.save({"flat": flat.clone(), "rm": model[1].running_mean.clone()}, out + f"_{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_is_the_mean_of_the_shard_gradients(tmp_path):
+    """the config-#4 topology (8 ranks) had only ever run with 2.  The averaged flat gradient on every
+    rank == the mean of the 8 per-shard gradients computed by one process (each shard with its OWN BatchNorm batch
+    statistics - what nn.DataParallel replicas do); running statistics stay per rank."""
+    world = 8
+    out = str(tmp_path / "w8")
+    mp.spawn(_worker_world8, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = [torch.load(out + f"_{r}.pt") for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(got[r]["flat"], got[0]["flat"])                       # every rank holds the same average
+    assert not torch.equal(got[0]["rm"], got[1]["rm"])                           # BatchNorm statistics: per rank
+    g = torch.Generator().manual_seed(11)
+    X, Y = torch.randn(64, 12, generator=g), torch.randn(64, 7, generator=g)
+    mean = None
+    for r in range(world):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.BatchNorm1d(40), torch.nn.ReLU(),
+                                    torch.nn.Linear(40, 31), torch.nn.BatchNorm1d(31), torch.nn.ReLU(), torch.nn.Linear(31, 7))
+        params, offsets, flat = _flat_setup(model)
+        for _ in range(2):                      # the second step's gradient does not depend on the first (no optimizer)
+            flat.zero_()
+            ((model(X[r * 8:(r + 1) * 8]) - Y[r * 8:(r + 1) * 8]) ** 2).mean().backward()
+        mean = flat.clone() if mean is None else mean + flat
+    mean /= world
+    assert (got[0]["flat"] - mean).abs().max() < 1e-6

@@ -685,14 +685,16 @@ def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkey
 
 
 @pytest.mark.parametrize("V,Fin,Fout,B", [(736, 128, 128, 5), (1472, 128, 64, 3), (2944, 64, 128, 2)])
-def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fin, Fout, B):
+@pytest.mark.parametrize("slices", ["f16x2", "bf16x3"])
+def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, slices, V, Fin, Fout, B):
     """include/p2m.h "activation on load" (lib/models/backbones/cheby_graph_conv.py:39 + lib/models/meshnet.py:100 folded into the
     next conv's loads): the tile kernel and the weight-gradient contraction reading the RAW conv output y with
     relu(y * scale + shift) applied between the global load and the LDS image give, bit for bit, what they give on the
     tensor x that p2m_bn_act_fwd materialises (same two roundings, same amax word) - tile kernel, LDS-staged basis kernel,
     plane contraction over the real and the fake rows, both weight-gradient launches; p2m_act_bound really bounds the
-    activated tensor."""
-    monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
+    activated tensor.  Round 5: in BOTH slice arithmetics (bf16x3 = the exact path of the bench's headline: no amax words, the
+    VALU-gather tile kernel applies the activation in its producer waves)."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", slices)
     monkeypatch.setattr(ops, "TILE_GEMM", True)
     L = _band_graph(V, 11 + V)
     g = ops.DeviceGraph(L, "cuda:0")
@@ -708,11 +710,13 @@ def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, V, Fi
     fake = torch.ones(V, dtype=torch.bool, device="cuda")
     fake[real] = False
     # the bound: >= the true maximum, and not absurdly loose on this input
-    yw = ops.amax_of(y)
-    word = ops.act_bound(co[2], co[3], yw, ops.new_amax("cuda:0"))
-    bound = word.view(torch.float32).item()
-    true_max = x.abs().max().item()
-    assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
+    word = None
+    if slices == "f16x2":
+        yw = ops.amax_of(y)
+        word = ops.act_bound(co[2], co[3], yw, ops.new_amax("cuda:0"))
+        bound = word.view(torch.float32).item()
+        true_max = x.abs().max().item()
+        assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
     # forward: tile kernel on x vs on y with the activation on load, SAME amax word -> same slices -> same bits
     Wt = (torch.randn(3 * Fin, Fout, generator=gen) / (3 * Fin) ** 0.5).cuda()
     bias = torch.randn(Fout, generator=gen).cuda()
