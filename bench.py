@@ -73,11 +73,11 @@ class TrainStep:
             self.opt = optim.FlatAdam(self.model.parameters(), lr=1e-3)          # funcs_utils.py:92-96
         else:
             self.opt = optim.FlatRMSprop(self.model.parameters(), lr=1e-3)       # funcs_utils.py:87-91 (the yaml recipe)
-        self.model.pose2mesh.accumulate_grads_in_place(True)        # gradients land in opt.flat_grad directly
+        self.model.accumulate_grads_in_place(True)                  # gradients land in opt.flat_grad directly (both halves)
         self.reducer = p2m_dist.BucketedAllReduce(self.opt.params, self.opt.offsets, self.opt.flat_grad) \
             if world > 1 else None
-        if self.reducer is not None:       # in-place MeshNet gradients are reported per layer, from inside the backward
-            self.model.pose2mesh.set_grad_sink(self.reducer.notify)
+        if self.reducer is not None:       # in-place gradients are reported per layer, from inside the backward
+            self.model.set_grad_sink(self.reducer.notify)
         self.losses = p2m_loss.get_loss(faces)
         self.edge_loss = edge_loss
         self.stock_losses = stock_losses

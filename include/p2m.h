@@ -424,6 +424,40 @@ int p2m_mesh_epilogue(const float* cam_mesh, int32_t V0, const int32_t* perm, in
                       const int32_t* jr_ptr, const int32_t* jr_idx, const float* jr_val, int32_t J,
                       float* mesh, float* joints, int32_t B, void* stream);
 
+/* ---- PoseNet, the 2D -> 3D lifter in front of MeshNet (lib/models/posenet.py:11-92) ---------------------------------
+ * A 4096-wide residual MLP over B rows.  Every Linear (posenet.py:19,22,59,68: F.linear and its autograd) is a
+ * weight-streaming contraction at these batch sizes and runs on p2m_gemm_tn, the reduction-split contraction with both
+ * operands row-major over the reduction index:
+ *   forward  z = a W^T + b      P[ch][m][n] = sum_{k in ch} a^T[k][m] * W^T[k][n]      (A = a^T, G = p2m_weight_pack(W, K = 1))
+ *   dX       g_a = g_z W        P[ch][m][k] = sum_{n in ch} g_z^T[n][m] * W[n][k]      (A = g_z^T, G = W as nn.Linear stores it)
+ *   dW       W.grad += g_z^T a  p2m_gemm_tn_acc: the whole reduction (the B rows) in one chunk, added straight into .grad
+ * p2m_gemm_tn_acc: P[k][n] += sum_{r < M} A[r][k] * G[r][n]   (A: [M, Ka], G: [M, N], P: [Ka, N]; same arithmetics).  */
+int p2m_gemm_tn_acc(const float* A, int32_t Ka, const float* G, int32_t N, int64_t M, float* P, int32_t arith,
+                    const void* a_amax, const void* g_amax, void* stream);
+/* The elementwise stage between two contractions, forward (posenet.py:28-38,79-87).  A block owns 32 columns and ALL B
+ * rows of them, so BatchNorm1d's batch statistics are block-local and the whole stage is one launch:
+ *   z = sum_{ch < nch} P[ch] + bias (+ resid)                       written to z (z == NULL: P is the tensor itself)
+ *   has_bn: a = dropout(relu(batch_norm(z)));  else a = z           written row-major to a and / or TRANSPOSED to aT [F, B]
+ * batch_norm: training != 0 -> batch mean / biased variance over the B rows, running statistics updated with `momentum`
+ * and the unbiased variance (nn.BatchNorm1d); else the running statistics.  mean / invstd receive the statistics used
+ * (saved for the backward).  dropout: rnd = uniform [0, 1) numbers drawn by the caller, keep where rnd >= p_drop, scale
+ * 1 / (1 - p_drop) (nn.Dropout); rnd == NULL or p_drop == 0: identity.  amax_out: atomic max of |a| (P2M_ARITH_F16X2). */
+int p2m_pn_stage_fwd(const float* P, int32_t nch, const float* bias, const float* resid, float* z, int32_t has_bn,
+                     int32_t training, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, const float* rnd, float p_drop, float* a, float* aT, float* mean,
+                     float* invstd, void* amax_out, int32_t B, int32_t F, void* stream);
+/* ... and backward (autograd of the same lines): g_a = sum_{ch < nch} P[ch] is the gradient w.r.t. the stage's output a;
+ *   has_bn: g_u = g_a * dropout mask * [batch_norm(z) > 0];  dbeta = sum_r g_u;  dgamma = sum_r g_u xhat;
+ *           g_z = gamma invstd (g_u - dbeta / B - xhat dgamma / B)  (training)   /   gamma invstd g_u  (running statistics)
+ *   else    g_z = g_a;
+ *   g_z += addend (the residual branch's gradient, posenet.py:38);  stored row-major (gz) and transposed (gzT, [F, B]);
+ *   dbias = sum_r g_z: the bias gradient of the Linear that produced z.  accumulate != 0: dgamma / dbeta / dbias are
+ *   added into (the parameters' .grad), else overwritten.  z, mean, invstd: what the forward saved.                  */
+int p2m_pn_stage_bwd(const float* P, int32_t nch, const float* addend, int32_t has_bn, int32_t training, const float* z,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta, const float* rnd,
+                     float p_drop, float* gz, float* gzT, float* dgamma, float* dbeta, float* dbias, int32_t accumulate,
+                     void* amax_out, int32_t B, int32_t F, void* stream);
+
 /* ---- optimizer step over a flat fp32 buffer ------------------------------------------------
  * torch.optim.Adam semantics (lib/funcs_utils.py:92-96, stepped at lib/core/base.py:148): one fused
  * launch for the whole model.  grad is multiplied by grad_scale first (1/world_size after a

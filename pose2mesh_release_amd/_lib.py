@@ -91,6 +91,11 @@ HIP_SYMBOLS = {
     "p2m_rmsprop_step": (_c.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp]),
     "p2m_adam_step_dev": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _vp]),
     "p2m_rmsprop_step_dev": (_c.c_int, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _vp]),
+    "p2m_gemm_tn_acc": (_c.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "p2m_pn_stage_fwd": (_c.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp,
+                                    _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "p2m_pn_stage_bwd": (_c.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp,
+                                    _vp, _i32, _vp, _i32, _i32, _vp]),
     "p2m_chebconv_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
 }
 

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-HIP_SOURCES = ["capi.hip", "basis.hip", "gemm.hip", "bn.hip", "optim.hip", "loss.hip", "chebtile.hip"]
+HIP_SOURCES = ["capi.hip", "basis.hip", "gemm.hip", "bn.hip", "optim.hip", "loss.hip", "chebtile.hip", "posenet.hip"]
 # per-source flags.  chebtile.hip: the gather's fmaf chains must stay scalar v_fma_f32 - SLP-packed v_pk_fma_f32 next to the
 # MFMA waves measured 9 % slower over the real-row shapes of a train step (17.2 vs 19.0 ms)
 HIP_SOURCE_FLAGS = {"chebtile.hip": ["-fno-slp-vectorize"]}

@@ -783,6 +783,8 @@ struct TnArgs {
   const float* a_scale;
   const float* a_shift;
   int nchunks;           // k_gemm_tn_ws: one-dimensional grid of ceil(nchunks / 8) * 8 * nkt * ntn blocks (XCD-aware mapping)
+  int accum = 0;         // P += result instead of P = result (single chunk only: a plain Linear's weight gradient added
+                         // straight into the parameter's .grad, p2m_gemm_tn_acc)
 };
 
 template <int BN, bool ROWS = false>
@@ -923,7 +925,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = acc[i][j][r];
+        if (krow < g.Ktot && n < g.N) {
+          float* d = Pc + (long)krow * g.N + n;
+          *d = g.accum ? *d + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
   if (kt == 0 && g.Pdb != nullptr) {
@@ -975,10 +980,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   // b runs on XCD b % 8), so that A comes from HBM once and from that XCD's L2 for the others.  With the chunk in
   // blockIdx.y the three n-tiles of a 128 x 384 weight gradient sat on three different XCDs (PMC: 1.9x the algorithmic
   // bytes per launch; 1 408 -> 884 MB on the finest level, 144 -> 131 GB per train step).  +0.4 % on the step.
+  // Fewer than 8 chunks (a plain Linear's weight gradient over a batch of rows: ONE chunk, p2m_gemm_tn_acc): that mapping
+  // would put every live block on the XCDs 0 .. nchunks - 1 (measured: one chunk of 1024 tiles ran on 32 of the 256 CUs,
+  // 740 us for 8.6 GFLOP); consecutive blocks then simply take consecutive tiles.
   const int ntiles = g.nkt * g.ntn;
-  const int slot = blockIdx.x >> 3;
-  const int tile = slot % ntiles;
-  const int chunk = (slot / ntiles) * 8 + (blockIdx.x & 7);
+  int tile, chunk;
+  if (g.nchunks >= 8) {
+    const int slot = blockIdx.x >> 3;
+    tile = slot % ntiles;
+    chunk = (slot / ntiles) * 8 + (blockIdx.x & 7);
+  } else {
+    tile = blockIdx.x % ntiles;
+    chunk = blockIdx.x / ntiles;
+  }
   if (chunk >= g.nchunks) return;
   const int kt = tile / g.ntn, nt = tile % g.ntn;
   const int kk0 = kt * BM, n0 = nt * BN;
@@ -1218,7 +1232,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = __builtin_ldexpf(acc[i][j][r], descale);
+          if (krow < g.Ktot && n < g.N) {
+            float* d = Pc + (long)krow * g.N + n;
+            const float v = __builtin_ldexpf(acc[i][j][r], descale);
+            *d = g.accum ? *d + v : v;
+          }
         }
       }
   }
@@ -1251,7 +1269,7 @@ __global__ void k_naive_gemm_tn(TnArgs g) {
     const int q = n / g.Gc;
     const float* Gq = g.G[q] + (n - q * g.Gc);
     for (long r = r_begin; r < r_end; r++) acc = fmaf(Ap[(r >> sh) * g.Ka + k], Gq[r * g.Gc], acc);
-    g.P[(long)chunk * nout + o] = acc;
+    g.P[(long)chunk * nout + o] = g.accum ? g.P[(long)chunk * nout + o] + acc : acc;
   }
   if (g.Pdb != nullptr && o < g.N) {
     float s = 0.f;
@@ -1705,10 +1723,31 @@ extern "C" int32_t p2m_rows_tiles_per_sample(p2m_graph_t gh, int32_t row_set) {
   return cdiv(row_set_of(gr, row_set).n, BM);
 }
 
+static int gemm_tn_impl(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                        int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
+                        int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith,
+                        const void* a_amax, int32_t a_bits, const void* g_amax, int32_t g_bits, int32_t accumulate,
+                        void* stream);
 extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
                            int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
                            int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith,
                            const void* a_amax, int32_t a_bits, const void* g_amax, int32_t g_bits, void* stream) {
+  return gemm_tn_impl(A0, A1, A2, nplanesA, Ka, a0_shift, G0, G1, G2, nplanesG, Gc, M, chunk_rows, P, Pdb, arith, a_amax,
+                      a_bits, g_amax, g_bits, 0, stream);
+}
+// P[k][n] += sum_r A[r][k] G[r][n] over ALL M rows in one chunk: the weight gradient of a plain Linear
+// (lib/models/posenet.py:19,22,59,68) added straight into the parameter's .grad - no partial buffer, no unpack pass.
+extern "C" int p2m_gemm_tn_acc(const float* A, int32_t Ka, const float* G, int32_t N, int64_t M, float* P, int32_t arith,
+                               const void* a_amax, const void* g_amax, void* stream) {
+  const int64_t chunk_rows = ((M + 31) / 32) * 32;
+  return gemm_tn_impl(A, nullptr, nullptr, 1, Ka, 0, G, nullptr, nullptr, 1, N, M, chunk_rows > 0 ? chunk_rows : 32, P,
+                      nullptr, arith, a_amax, 0, g_amax, 0, 1, stream);
+}
+static int gemm_tn_impl(const float* A0, const float* A1, const float* A2, int32_t nplanesA, int32_t Ka,
+                        int32_t a0_shift, const float* G0, const float* G1, const float* G2, int32_t nplanesG,
+                        int32_t Gc, int64_t M, int64_t chunk_rows, float* P, float* Pdb, int32_t arith,
+                        const void* a_amax, int32_t a_bits, const void* g_amax, int32_t g_bits, int32_t accumulate,
+                        void* stream) {
   P2M_CHECK_ARG(nplanesA >= 1 && nplanesA <= 3 && nplanesG >= 1 && nplanesG <= 3, "plane count must be 1..3");
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || (a_amax && g_amax), "P2M_ARITH_F16X2 needs the amax words of both operands");
@@ -1729,6 +1768,8 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   g.a_scale = g.a_shift = nullptr;
   const int nchunks = cdiv(M, chunk_rows);
   g.nchunks = nchunks;
+  g.accum = accumulate;
+  P2M_CHECK_ARG(!accumulate || nchunks == 1, "accumulation needs the whole reduction in one chunk");
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = (Ka % 4 == 0) && (N % 32 == 0) && (Gc % 4 == 0) && (g.Ktot >= 32);
   if (!mfma_ok) {
@@ -1743,13 +1784,13 @@ extern "C" int p2m_gemm_tn(const float* A0, const float* A1, const float* A2, in
   // N = 192 (three planes of 64): two 128-wide tiles (the second half empty) stage A twice, three 64-wide tiles thrice
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
-    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws(cdiv(nchunks, 8) * 8 * g.nkt * g.ntn);
+    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws((nchunks >= 8 ? cdiv(nchunks, 8) * 8 : nchunks) * g.nkt * g.ntn);
     if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<128, false, 2>), grid_ws, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, false, 3>), grid_ws, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, false>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
-    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws(cdiv(nchunks, 8) * 8 * g.nkt * g.ntn);
+    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws((nchunks >= 8 ? cdiv(nchunks, 8) * 8 : nchunks) * g.nkt * g.ntn);
     if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<64, false, 2>), grid_ws, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, false, 3>), grid_ws, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, false>), grid, dim3(256), 0, s, g);
@@ -1794,13 +1835,13 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   if (bx) g.chunk_rows = cdiv(g.chunk_rows, 16) * 16;    // 16-byte aligned id loads; trailing splits may be empty
   if (N % 128 == 0 || (bx && N > 128)) {
     g.ntn = cdiv(N, 128);
-    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws(cdiv(nchunks, 8) * 8 * g.nkt * g.ntn);
+    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws((nchunks >= 8 ? cdiv(nchunks, 8) * 8 : nchunks) * g.nkt * g.ntn);
     if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<128, true, 2>), grid_ws, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<128, true, 3>), grid_ws, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<128, true>), grid, dim3(256), 0, s, g);
   } else {
     g.ntn = cdiv(N, 64);
-    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws(cdiv(nchunks, 8) * 8 * g.nkt * g.ntn);
+    const dim3 grid(g.nkt * g.ntn, nchunks), grid_ws((nchunks >= 8 ? cdiv(nchunks, 8) * 8 : nchunks) * g.nkt * g.ntn);
     if (arith == P2M_ARITH_F16X2) hipLaunchKernelGGL((k_gemm_tn_ws<64, true, 2>), grid_ws, dim3(512), 0, s, g);
     else if (bx) hipLaunchKernelGGL((k_gemm_tn_ws<64, true, 3>), grid_ws, dim3(512), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_tn<64, true>), grid, dim3(256), 0, s, g);

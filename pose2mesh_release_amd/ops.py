@@ -939,10 +939,12 @@ def pick_chunk_rows(M, ntiles_out, target_blocks=None, quantum=32):
     return rows
 
 
-def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits=0):
+def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits=0, tname=None, target_blocks=None):
     """G: one [M, N] tensor or a list of column planes [M, N/len(G)].
     Returns (P[nchunks, len(A)*Ka, N], Pdb[nchunks, N], nchunks).  f16x2: the amax words of the A / G planes (after
-    a_bits / g_bits binades); default: the first planes' own, over the whole tensors."""
+    a_bits / g_bits binades); default: the first planes' own, over the whole tensors.  tname: label of the launch in
+    the per-kernel timing (default gemm_tn_mfma / gemm_tn_valu: the weight-gradient family of bench.py's roofline);
+    target_blocks: blocks the launch should have at least (default TN_TARGET_BLOCKS)."""
     Gl = list(G) if isinstance(G, (list, tuple)) else [G]
     G = Gl[0]
     Gc = N // len(Gl)
@@ -951,7 +953,7 @@ def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits
     mfma = (Ka % 4 == 0) and (N % 32 == 0) and Ktot >= 32 and Gc % 4 == 0
     # the scalar fall-back (the first conv's 15 x 32 gradient) walks a chunk's rows one dependent load at a time: short
     # chunks (32 rows: 94 -> 15 us per step for the 4 864 joint rows of a batch of 256), the unpack sums them
-    chunk_rows = pick_chunk_rows(M, ntiles) if mfma else 32
+    chunk_rows = pick_chunk_rows(M, ntiles, target_blocks) if mfma else 32
     nchunks = (M + chunk_rows - 1) // chunk_rows
     P = torch.empty((nchunks, Ktot, N), device=G.device, dtype=torch.float32)
     Pdb = torch.empty((nchunks, N), device=G.device, dtype=torch.float32)
@@ -962,7 +964,8 @@ def gemm_tn(A, Ka, a0_shift, G, M, N, a_amax=None, a_bits=0, g_amax=None, g_bits
             a_amax = _amax_planes(A)
         if g_amax is None:
             g_amax = _amax_planes(Gl)
-    with _timed("gemm_tn_mfma" if mfma else "gemm_tn_valu", (2.0 * M * Ktot * N, 2.0 * M * Ktot * N, 4.0 * M * (Ktot + N))):
+    with _timed(tname or ("gemm_tn_mfma" if mfma else "gemm_tn_valu"),
+                (2.0 * M * Ktot * N, 2.0 * M * Ktot * N, 4.0 * M * (Ktot + N))):
         check(_lib.hip().p2m_gemm_tn(a[0], a[1], a[2], len(A), Ka, a0_shift, gp[0], gp[1], gp[2], len(Gl), Gc, M,
                                      chunk_rows, _p(P), _p(Pdb), arith_code() if mfma else 0, _p(a_amax), int(a_bits),
                                      _p(g_amax), int(g_bits), _stream()), "p2m_gemm_tn")
@@ -1080,3 +1083,74 @@ def lerp_bwd_add(g, dst, M, F, Fres):
     check(_lib.hip().p2m_lerp_bwd_add(_p(_req(g, "g")), _p(_req(dst, "dst")), M, F, Fres, _stream()),
           "p2m_lerp_bwd_add")
     return dst
+
+
+# ---- PoseNet (lib/models/posenet.py): the elementwise stage between two weight-streaming contractions ----------------
+def gemm_tn_acc(A, G, P, a_amax=None, g_amax=None):
+    """P[k][n] += sum_r A[r][k] * G[r][n] (A: [M, Ka], G: [M, N], P: [Ka, N] fp32, e.g. a parameter's .grad): the whole
+    reduction in one chunk, no partial buffer (include/p2m.h p2m_gemm_tn_acc)."""
+    M, Ka = A.shape
+    N = G.shape[1]
+    if G.shape[0] != M or tuple(P.shape) != (Ka, N):
+        raise P2MError(f"gemm_tn_acc: shapes {tuple(A.shape)} x {tuple(G.shape)} -> {tuple(P.shape)} do not match")
+    mfma = Ka % 4 == 0 and N % 32 == 0 and Ka >= 32
+    if mfma and f16x2():
+        if a_amax is None:
+            a_amax = amax_of(A)
+        if g_amax is None:
+            g_amax = amax_of(G)
+    with _timed("pn_gemm", (2.0 * M * Ka * N, 2.0 * M * Ka * N, 4.0 * (M * (Ka + N) + 2.0 * Ka * N))):
+        check(_lib.hip().p2m_gemm_tn_acc(_p(_req(A, "A")), Ka, _p(_req(G, "G")), N, M, _p(_req(P, "P")),
+                                         arith_code() if mfma else 0, _p(a_amax), _p(g_amax), _stream()), "p2m_gemm_tn_acc")
+    return P
+
+
+def pn_stage_fwd(P, nch, B, F, bias=None, resid=None, want_z=True, bn=None, rnd=None, p_drop=0.0, want_a=True,
+                 want_aT=True):
+    """z = sum of the nch partials P[ch] + bias (+ resid); bn = (gamma, beta, running_mean, running_var, momentum, eps,
+    training) -> a = dropout(relu(batch_norm(z))), else a = z; a row-major and / or transposed ([F, B]).  Returns
+    (z, a, aT, mean, invstd); a / aT come back tagged with their amax word in f16x2 mode (include/p2m.h p2m_pn_stage_fwd)."""
+    dev = P.device
+    z = torch.empty((B, F), device=dev, dtype=torch.float32) if want_z else None
+    a = torch.empty((B, F), device=dev, dtype=torch.float32) if want_a else None
+    aT = torch.empty((F, B), device=dev, dtype=torch.float32) if want_aT else None
+    mean = invstd = None
+    gamma = beta = rm = rv = None
+    mom, eps, training = 0.1, 1e-5, 0
+    if bn is not None:
+        gamma, beta, rm, rv, mom, eps, training = bn
+        st = torch.empty((2, F), device=dev, dtype=torch.float32)
+        mean, invstd = st[0], st[1]
+    word = new_amax(dev) if (f16x2() and (want_a or want_aT)) else None
+    check(_lib.hip().p2m_pn_stage_fwd(_p(_req(P, "P")), int(nch), _p(bias), _p(resid), _p(z), int(bn is not None),
+                                      int(bool(training)), _p(gamma), _p(beta), _p(rm), _p(rv), float(mom), float(eps),
+                                      _p(rnd), float(p_drop), _p(a), _p(aT), _p(mean), _p(invstd), _p(word), B, F,
+                                      _stream()), "p2m_pn_stage_fwd")
+    if word is not None:
+        for t in (a, aT):
+            if t is not None:
+                tag_amax(t, word)
+    return z, a, aT, mean, invstd
+
+
+def pn_stage_bwd(P, nch, B, F, addend=None, bn=None, rnd=None, p_drop=0.0, want_T=True, dgamma=None, dbeta=None,
+                 dbias=None, accumulate=False):
+    """Backward of pn_stage_fwd.  bn = (z, mean, invstd, gamma, beta, training).  Returns (gz, gzT); dgamma / dbeta / dbias
+    (given tensors) are overwritten, or added into when accumulate (include/p2m.h p2m_pn_stage_bwd)."""
+    dev = P.device
+    gz = torch.empty((B, F), device=dev, dtype=torch.float32)
+    gzT = torch.empty((F, B), device=dev, dtype=torch.float32) if want_T else None
+    z = mean = invstd = gamma = beta = None
+    training = 0
+    if bn is not None:
+        z, mean, invstd, gamma, beta, training = bn
+    word = new_amax(dev) if f16x2() else None
+    check(_lib.hip().p2m_pn_stage_bwd(_p(_req(P, "P")), int(nch), _p(addend), int(bn is not None), int(bool(training)),
+                                      _p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(rnd), float(p_drop), _p(gz),
+                                      _p(gzT), _p(dgamma), _p(dbeta), _p(dbias), int(bool(accumulate)), _p(word), B, F,
+                                      _stream()), "p2m_pn_stage_bwd")
+    if word is not None:
+        tag_amax(gz, word)
+        if gzT is not None:
+            tag_amax(gzT, word)
+    return gz, gzT

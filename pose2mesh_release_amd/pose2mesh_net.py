@@ -31,6 +31,19 @@ class FlatPose2Mesh(nn.Module):
         self.pose2mesh.set_inference(real_only, perm_reverse, nv, scale)
         return self
 
+    def accumulate_grads_in_place(self, enable=True):
+        """Both halves add their gradients straight into the parameters' .grad tensors (Pose2Mesh / LinearModel
+        .accumulate_grads_in_place: for training loops that own a flat gradient buffer, optim.FlatAdam / FlatRMSprop)."""
+        self.pose2mesh.accumulate_grads_in_place(enable)
+        self.pose_lifter.accumulate_grads_in_place(enable)
+        return self
+
+    def set_grad_sink(self, sink):
+        """dist.BucketedAllReduce.notify for the gradients that bypass autograd (see Pose2Mesh.set_grad_sink)."""
+        self.pose2mesh.set_grad_sink(sink)
+        self.pose_lifter.set_grad_sink(sink)
+        return self
+
     def forward(self, pose2d):
         pose3d = self.pose_lifter(pose2d.view(len(pose2d), -1)).reshape(-1, self.num_joint, 3)
         # MeshNet gets no gradient path into PoseNet (pose2mesh_net.py:19)
