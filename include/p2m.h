@@ -348,6 +348,12 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * the producer waves between the global load and the LDS image: the activated tensor never exists in HBM.  x_amax must
  * then bound x (p2m_act_bound).                                                                                            */
 int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
+/* 1 when a p2m_cheb_tile_gemm launch of this arithmetic and output width forms the planes with the gather ON THE MATRIX
+ * CORES (the tile's operator as a dense pre-sliced block, TilePlan::ltx / ltx3): P2M_ARITH_F16X2 (two scaled fp16 slices,
+ * 4 samples per unit) and - round 5 - P2M_ARITH_BF16X3 (three exact bf16 slices of operator and operand, 2 samples per
+ * unit; P2M_MG_EXACT=0 switches it off), N <= 128.  The optional planes E1 / E2 then agree with p2m_cheb_basis_fwd_real to
+ * fp32 round-off instead of bitwise, and activation on load is available.                                           */
+int32_t p2m_cheb_tile_gemm_mg(int32_t arith, int32_t N);
 int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
                        int32_t arith, const void* x_amax, const float* bias, const float* addend, float* C, int32_t N,
                        float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,

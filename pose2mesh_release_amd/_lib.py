@@ -50,6 +50,7 @@ HIP_SYMBOLS = {
     "p2m_bn_finalize_split": (_c.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
                                          _vp]),
     "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
+    "p2m_cheb_tile_gemm_mg": (_i32, [_i32, _i32]),
     "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                                       _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "p2m_act_bound": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),

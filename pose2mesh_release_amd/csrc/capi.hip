@@ -68,7 +68,7 @@ static inline unsigned short f16_bits(float v) {
 static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl, int entry_bits) {
   std::vector<int> tile_row{0}, tile_u{0}, ucol, erow{0};
   std::vector<float4> ent;
-  std::vector<unsigned short> ltx;
+  std::vector<unsigned short> ltx, ltx3;
   std::vector<double> dense((size_t)64 * TILE_UPAD);
   const int lt_exp = 14 - entry_bits;
   std::vector<int> local(nsrc, -1), uni;
@@ -96,8 +96,9 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl, int entry
     if ((int)uni.size() > TILE_UCAP || entries > TILE_ECAP) return P2M_OK;   // a single row too large: no plan
     std::sort(uni.begin(), uni.end());
     for (size_t q = 0; q < uni.size(); q++) local[uni[q]] = (int)q;
-    const size_t lt0 = ltx.size();
+    const size_t lt0 = ltx.size(), lt30 = ltx3.size();
     ltx.resize(lt0 + TILE_LTX_ELEMS, 0);
+    ltx3.resize(lt30 + TILE_LTX3_ELEMS, 0);
     std::fill(dense.begin(), dense.end(), 0.0);
     for (int r = i; r < i + rows; r++) {
       for (int j = fr.rp[r]; j < fr.rp[r + 1]; j++) {
@@ -119,6 +120,24 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl, int entry
         const size_t at = lt0 + (((size_t)(u >> 4) * 2 * 2 + (size_t)((u >> 3) & 1)) * 64 + (size_t)pi) * 8 + (u & 7);
         ltx[at] = f16_bits((float)h);
         ltx[at + 2 * 64 * 8] = f16_bits(y - (float)h);
+        // three exact bf16 slices of the fp32 coefficient (truncation: x = h + m + l, split3 of p2m_split.h), unscaled
+        const float cf = (float)dense[(size_t)pi * TILE_UPAD + u];
+        unsigned cb, hb, mb, lb;
+        memcpy(&cb, &cf, 4);
+        hb = cb & 0xFFFF0000u;
+        float hf, r1, mf, r2;
+        memcpy(&hf, &hb, 4);
+        r1 = cf - hf;
+        memcpy(&mb, &r1, 4);
+        mb &= 0xFFFF0000u;
+        memcpy(&mf, &mb, 4);
+        r2 = r1 - mf;
+        memcpy(&lb, &r2, 4);
+        lb &= 0xFFFF0000u;
+        const size_t at3 = lt30 + (((size_t)(u >> 4) * 3 * 2 + (size_t)((u >> 3) & 1)) * 64 + (size_t)pi) * 8 + (u & 7);
+        ltx3[at3] = (unsigned short)(hb >> 16);
+        ltx3[at3 + 2 * 64 * 8] = (unsigned short)(mb >> 16);
+        ltx3[at3 + 2 * 2 * 64 * 8] = (unsigned short)(lb >> 16);
       }
     for (int c : uni) { ucol.push_back(c); local[c] = -1; }
     i += rows;
@@ -135,7 +154,8 @@ static int build_tile_plan(const FlatRows& fr, int nsrc, TilePlan& pl, int entry
       (rc = upload(ucol.data(), sizeof(int) * ucol.size(), (void**)&pl.ucol)) != P2M_OK ||
       (rc = upload(erow.data(), sizeof(int) * erow.size(), (void**)&pl.erow)) != P2M_OK ||
       (rc = upload(ent.data(), sizeof(float4) * ent.size(), (void**)&pl.ent)) != P2M_OK ||
-      (rc = upload(ltx.data(), sizeof(unsigned short) * ltx.size(), (void**)&pl.ltx)) != P2M_OK)
+      (rc = upload(ltx.data(), sizeof(unsigned short) * ltx.size(), (void**)&pl.ltx)) != P2M_OK ||
+      (rc = upload(ltx3.data(), sizeof(unsigned short) * ltx3.size(), (void**)&pl.ltx3)) != P2M_OK)
     return rc;
   pl.lt_exp = lt_exp;
   pl.ntiles = (int)tile_row.size() - 1;
@@ -320,6 +340,7 @@ extern "C" int p2m_graph_destroy(p2m_graph_t gh) {
     if (pl.ent) (void)hipFree(pl.ent);
     if (pl.tile_cnt) (void)hipFree(pl.tile_cnt);
     if (pl.ltx) (void)hipFree(pl.ltx);
+    if (pl.ltx3) (void)hipFree(pl.ltx3);
   }
   delete g;
   return P2M_OK;

@@ -35,6 +35,7 @@
 // latencies) for N <= 128, 4 + 4 for N = 256 (the 128-register accumulator needs the 256-register budget).
 #include "p2m_split.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace p2m {
@@ -90,7 +91,7 @@ enum { CT_PLAIN = 0, CT_STATS = 1, CT_ADDEND = 2, CT_ACT = 3 };
 // in all four MFMA waves at once with the producer waves idle, once per sample group: cycle counters in the kernel put
 // the general form at a fifth of the kernel's time.  Same values: fmaf(acc, 2^descale, bias) rounds once, like
 // ldexp(acc, descale) + bias.  The stores take the `global_store v_off, v_data, s[base]` form (sample base in SGPRs).
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, int SG = CT_S>
 __device__ __forceinline__ void tile_epilogue_full(const TileGemmArgs& g, const TilePlan& pl, floatx16 (&acc)[TM][TN],
                                                    const int* rowvid, int grp, int tile, int wm, int wn, int l31, int lhi,
                                                    int descale) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void tile_epilogue_full(const TileGemmArgs& g, const 
       }
   }
   // wave-uniform sample index (readfirstlane tells the compiler so): 64-bit sample bases in SGPRs, 32-bit lane offsets
-  const int b0s = grp * CT_S + __builtin_amdgcn_readfirstlane(wm) * TM;
+  const int b0s = grp * SG + __builtin_amdgcn_readfirstlane(wm) * TM;
 #pragma unroll
   for (int i = 0; i < TM; i++) {
     char* Cs = reinterpret_cast<char*>(g.C + (long)(b0s + i) * g.c_rows * g.N);
@@ -177,7 +178,7 @@ __device__ __forceinline__ void tile_epilogue_full(const TileGemmArgs& g, const 
 // Epilogue of one sample group in the MFMA waves: bias (+ activation / addend), store, BatchNorm partials; then a fresh
 // accumulator.  MODE is compiled in (see above).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) +
 // 8 (reg >> 2) + 4 (lane >> 5).
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, int SG = CT_S>
 __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TilePlan& pl, floatx16 (&acc)[TM][TN],
                                               const int* rowvid, int grp, int tile, int R, int wm, int wn, int l31,
                                               int lhi, int descale) {
@@ -208,7 +209,7 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
   }
   // pass 2: stores, accumulator row by accumulator row: the row-validity mask is the same for every tile, a
   // sample's validity is wave-uniform
-  const int b0s = grp * CT_S + wm * TM;
+  const int b0s = grp * SG + wm * TM;
   float vmax = 0.f;
   float* Cb[TM][TN];
   const float* Ab[TM][TN];
@@ -615,34 +616,46 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 // = 152 KB.  120 MFMAs per wave and unit instead of 72, ~150 VALU instructions per lane instead of ~550.
 // E1 / E2 differ from the fmaf chain of k_basis_tile by fp32 round-off (22-bit operands, fp32 accumulation).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int MG_LDU = TILE_UPAD + 8;                  // fp16 per row of the transposed union image: 272 B = 17 x 16 B
-constexpr int MG_LDK = 3 * CT_CF + 8;                  // fp16 per row of the A image: 208 B = 13 x 16 B
-constexpr int MG_XU_SLICE = CT_S * CT_CF * MG_LDU;     // rows (sample, feature as e * 8 + q for feature 4 q + e)
-constexpr int MG_A_SLICE = CT_S * 32 * MG_LDK;         // rows (sample, tile row)
-constexpr int MG_XU_BYTES = 2 * MG_XU_SLICE * 2;
-constexpr int MG_A_BYTES = 2 * MG_A_SLICE * 2;
-constexpr int MG_LT_BYTES = TILE_LTX_ELEMS * 2;
-constexpr int MG_LDS_BYTES = MG_XU_BYTES + MG_A_BYTES + MG_LT_BYTES + 256;
+constexpr int MG_LDU = TILE_UPAD + 8;                  // 16-bit words per row of the transposed union image: 272 B = 17 x 16 B
+constexpr int MG_LDK = 3 * CT_CF + 8;                  // 16-bit words per row of the A image: 208 B = 13 x 16 B
+// per slice arithmetic (NS slices) and SG samples per unit
+constexpr int mg_xu_slice(int sg) { return sg * CT_CF * MG_LDU; }     // rows (sample, feature as e * 8 + q for feature 4 q + e)
+constexpr int mg_a_slice(int sg) { return sg * 32 * MG_LDK; }         // rows (sample, tile row)
+constexpr int mg_lt_elems(int ns) { return (TILE_UPAD / 16) * ns * 64 * 16; }
+constexpr int mg_lds_bytes(int ns, int sg) { return (ns * mg_xu_slice(sg) + ns * mg_a_slice(sg) + mg_lt_elems(ns)) * 2 + 256; }
 static_assert(TILE_UCAP <= TILE_UPAD && TILE_UPAD == 128, "stage 1 walks 8 k-steps of 16 union rows");
-static_assert(MG_LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+static_assert(mg_lt_elems(2) == TILE_LTX_ELEMS && mg_lt_elems(3) == TILE_LTX3_ELEMS, "dense operator blocks of the plan");
+static_assert(mg_lds_bytes(2, 4) <= 160 * 1024 && mg_lds_bytes(3, 2) <= 160 * 1024, "LDS budget of one CU");
 
-template <int TM, int TN, int NPW, int MODE>
+// The matrix-core gather in BOTH slice arithmetics (round 5).  NS = 2 (two scaled fp16 slices): a unit is 4 samples x 32
+// features, as described above.  NS = 3 (three exact bf16 slices - the arithmetic of the bench's headline): every image
+// grows by half, so a unit is SG = 2 samples x 32 features (52 + 40 + 48 KB = 140 KB) - the same 120 MFMAs per wave and unit
+// (stage 1: one sample x one plane per wave, 8 k-steps x 6 slice products; stage 2: 6 k-steps x 6 products x TN tiles),
+// i.e. twice the units per row.  The dense operator block exists as a second image of three exact bf16 slices
+// (TilePlan::ltx3, unscaled: bf16 has fp32's exponent range), X / plane 0 are cut with split3_pack4, nothing is scaled.
+// TMS = samples per MFMA wave (SG = 2 TMS).
+template <int TMS, int TN, int NPW, int MODE, int NS>
 __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(TileGemmArgs g) {
-  constexpr int NS = 2;
-  typedef f16x8 frag_t;
+  typedef typename SliceFrag<NS>::type frag_t;
+  constexpr int TM = TMS;
+  constexpr int SG = 2 * TMS;                 // samples per unit
+  constexpr int SB = SG == 4 ? 2 : 1;         // log2(SG)
+  constexpr int XU_SLICE = mg_xu_slice(SG), A_SLICE = mg_a_slice(SG);
+  constexpr int LT_BYTES = mg_lt_elems(NS) * 2;
   constexpr int NP = 64 * NPW;
-  constexpr int WM = CT_S / TM;
-  constexpr int WN = 4 / WM;
-  constexpr int NXI = 16 / NPW;               // union items (4 rows x 4 features) per producer lane
-  constexpr int NPI = 1024 / NP;              // plane-0 items (1 row x 4 features) per producer lane
+  static_assert(NPW == 4 && (SG == 4 || SG == 2), "256 producer lanes; 4 or 2 samples per unit");
+  constexpr int NUH = NP >> (4 + SB);         // u-quad pairs walked in parallel by the producer lanes
+  constexpr int NXI = 16 / NUH;               // union items (4 rows x 4 features) per producer lane
+  constexpr int NPR = NP >> (3 + SB);         // tile rows walked in parallel (plane 0)
+  constexpr int NPI = 32 / NPR;               // plane-0 items (1 row x 4 features) per producer lane
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* Xu = reinterpret_cast<unsigned short*>(ct_smem);
-  unsigned short* Ai = Xu + 2 * MG_XU_SLICE;
-  unsigned short* Lt = Ai + 2 * MG_A_SLICE;
-  int* rowvid = reinterpret_cast<int*>(ct_smem + MG_XU_BYTES + MG_A_BYTES + MG_LT_BYTES);
+  unsigned short* Ai = Xu + NS * XU_SLICE;
+  unsigned short* Lt = Ai + NS * A_SLICE;
+  int* rowvid = reinterpret_cast<int*>(ct_smem + (NS * XU_SLICE + NS * A_SLICE) * 2 + LT_BYTES);
 
   const TilePlan& pl = g.pl;
-  const int ngroups = (g.B + CT_S - 1) / CT_S;
+  const int ngroups = (g.B + SG - 1) / SG;
   const int nbg = (ngroups + g.gpb - 1) / g.gpb;
   const int lid = xcd_contiguous(blockIdx.x, gridDim.x);
   if (lid >= pl.ntiles * nbg) return;
@@ -660,14 +673,20 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
   const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
   if (t < 32) rowvid[t] = t < R ? g.row_ids[r0 + t] : -1;
   {                                           // the tile's dense block: global -> LDS, once per block
-    const u32x4* src = reinterpret_cast<const u32x4*>(pl.ltx + (size_t)tile * TILE_LTX_ELEMS);
+    const unsigned short* img = NS == 2 ? pl.ltx + (size_t)tile * TILE_LTX_ELEMS : pl.ltx3 + (size_t)tile * TILE_LTX3_ELEMS;
+    const u32x4* src = reinterpret_cast<const u32x4*>(img);
     u32x4* dst = reinterpret_cast<u32x4*>(Lt);
-    for (int k = t; k < MG_LT_BYTES / 16; k += 256 + 64 * NPW) dst[k] = src[k];
+    for (int k = t; k < LT_BYTES / 16; k += 256 + 64 * NPW) dst[k] = src[k];
   }
   __syncthreads();
-  const int sx = slice_scale_exp(*g.x_amax, g.x_bits);
-  const float x_sc = exp2_int(sx);
-  const int descale = -(sx + slice_scale_exp(*g.b_amax, 0));
+  int sx = 0, descale = 0, lt_exp = 0;        // NS = 3: nothing is scaled
+  float x_sc = 1.f;
+  if constexpr (NS == 2) {
+    sx = slice_scale_exp(*g.x_amax, g.x_bits);
+    x_sc = exp2_int(sx);
+    descale = -(sx + slice_scale_exp(*g.b_amax, 0));
+    lt_exp = pl.lt_exp;
+  }
 
   if (t >= 256) {
     // ------------------------------------------------------------------------------------------------ producers
@@ -675,26 +694,26 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
     const int q = pt & 7;                               // this lane's 4 features (16 bytes) of a 128-byte line
     // union image items: (u-quad, sample, q).  The 16 lanes of a store group are 8 q x 2 u-quads: rows e * 8 + q are
     // 4 dwords apart mod 32, the two u-quads 2 dwords -> every 8-byte store of a group has its own bank pair
-    const int ulo = (pt >> 3) & 1, s = (pt >> 4) & 3, uhi = pt >> 6;
+    const int ulo = (pt >> 3) & 1, s = (pt >> 4) & (SG - 1), uhi = pt >> (4 + SB);
     unsigned uoff[NXI][4];
 #pragma unroll
     for (int k = 0; k < NXI; k++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int u = ((((uhi + k * NPW) << 1) | ulo) << 2) + j;
+        const int u = ((((uhi + k * NUH) << 1) | ulo) << 2) + j;
         uoff[k][j] = (unsigned)pl.ucol[u0 + (u < U ? u : U - 1)] * (unsigned)(g.Ka * 4);   // clamped: their Lt columns are 0
       }
     // plane-0 items: (tile row, sample, q)
-    const int s0 = (pt >> 3) & 3, i0 = pt >> 5;
+    const int s0 = (pt >> 3) & (SG - 1), i0 = pt >> (3 + SB);
     unsigned a0off[NPI];
 #pragma unroll
     for (int k = 0; k < NPI; k++) {
-      const int vid = rowvid[i0 + k * (NP / 32)];
+      const int vid = rowvid[i0 + k * NPR];
       a0off[k] = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
     }
     f32x4 xr[NXI][4], p0[NPI];
     auto sample_of = [&](int grp, int ss) {             // clamped: a group's missing samples recompute the last one
-      const int b = grp * CT_S + ss;
+      const int b = grp * SG + ss;
       return b < g.B ? b : g.B - 1;
     };
     int lg = grp0, lfc = 0;                             // next unit of the loaders
@@ -732,14 +751,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       }
 #pragma unroll
       for (int k = 0; k < NXI; k++) {
-        const int uq = ((uhi + k * NPW) << 1) | ulo;
+        const int uq = ((uhi + k * NUH) << 1) | ulo;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          u32x2 ph, pl2;
-          split2_pack4(xr[k][0][e], xr[k][1][e], xr[k][2][e], xr[k][3][e], x_sc, ph, pl2);
+          u32x2 sl[NS];
+          split_pack4<NS>(xr[k][0][e], xr[k][1][e], xr[k][2][e], xr[k][3][e], x_sc, sl);
           unsigned short* d = Xu + (s * 32 + e * 8 + q) * MG_LDU + uq * 4;
-          *reinterpret_cast<u32x2*>(d) = ph;
-          *reinterpret_cast<u32x2*>(d + MG_XU_SLICE) = pl2;
+#pragma unroll
+          for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * XU_SLICE) = sl[z];
         }
       }
     };
@@ -753,11 +772,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       }
 #pragma unroll
       for (int k = 0; k < NPI; k++) {
-        u32x2 ph, pl2;
-        split2_pack4(p0[k][0], p0[k][1], p0[k][2], p0[k][3], x_sc, ph, pl2);
-        unsigned short* d = Ai + (s0 * 32 + i0 + k * (NP / 32)) * MG_LDK + q * 4;
-        *reinterpret_cast<u32x2*>(d) = ph;
-        *reinterpret_cast<u32x2*>(d + MG_A_SLICE) = pl2;
+        u32x2 sl[NS];
+        split_pack4<NS>(p0[k][0], p0[k][1], p0[k][2], p0[k][3], x_sc, sl);
+        unsigned short* d = Ai + (s0 * 32 + i0 + k * NPR) * MG_LDK + q * 4;
+#pragma unroll
+        for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * A_SLICE) = sl[z];
       }
     };
     load_unit();
@@ -776,8 +795,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
     }
   } else {
     // ------------------------------------------------------------------------------------------------ MFMA waves
-    // 2 x 2 over (sample pair, plane) in stage 1 and over (sample pair, column half) in stage 2
-    static_assert(WM == 2 && WN == 2 && TM == 2, "wave pair (2 wm, 2 wm + 1) owns samples 2 wm, 2 wm + 1");
+    // 2 x 2 over (sample half, plane) in stage 1 and over (sample half, column half) in stage 2
     const int wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -793,8 +811,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
     const long bx_plane = (long)(g.Ka / 16) * NS * bx_slice;
     const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
     // ring of NB fragment sets: the set of step st is refilled, for step st + NB (of this unit or the next), as soon as
-    // step st has used it.  N = 64: one set per k-step, a whole unit of lead; N = 128: three sets (six would spill)
-    constexpr int NB = TN == 1 ? 6 : 3;
+    // step st has used it.  Two fp16 slices - N = 64: one set per k-step, a whole unit of lead; N = 128: three sets (six
+    // would spill).  Three bf16 slices (a set is half as large again, the accumulators half as many): three sets
+    constexpr int NB = NS == 3 ? 3 : (TN == 1 ? 6 : 3);
     frag_t fb[NB][NS][TN];
     auto load_b = [&](int fc, int st, frag_t (&b)[NS][TN]) {
       const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * NS * bx_slice;
@@ -808,14 +827,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
     auto read_a = [&](int sl, int koff, frag_t (&a)[TM]) {
 #pragma unroll
       for (int i = 0; i < TM; i++)
-        a[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * MG_A_SLICE + i * 32 * MG_LDK + koff));
+        a[i] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * A_SLICE + i * 32 * MG_LDK + koff));
     };
-    // stage 1: this wave forms plane wn + 1 of samples 2 wm, 2 wm + 1.  A fragments = rows (sample, feature) of the union
+    // stage 1: this wave forms plane wn + 1 of its TM samples.  A fragments = rows (sample, feature) of the union
     // image; B fragments = rows (plane wn, tile row) of the dense block (LDS, 16-byte units [k-step][slice][half][row])
-    const unsigned short* xu_lane = Xu + ((wm * 2) * 32 + l31) * MG_LDU + lhi * 8;
+    const unsigned short* xu_lane = Xu + ((wm * TM) * 32 + l31) * MG_LDU + lhi * 8;
     const unsigned short* lt_lane = Lt + (lhi * 64 + wn * 32 + l31) * 8;
-    const float e_sc = exp2_int(-pl.lt_exp);             // stage-1 accumulator = E 2^(sx + lt_exp)
-    unsigned short* c_lane = Ai + ((wm * 2) * 32 + l31) * MG_LDK + (wn + 1) * CT_CF + 16 * lhi;
+    const float e_sc = exp2_int(-lt_exp);                // stage-1 accumulator = E 2^(sx + lt_exp)
+    unsigned short* c_lane = Ai + ((wm * TM) * 32 + l31) * MG_LDK + (wn + 1) * CT_CF + 16 * lhi;
     float* Eout = wn == 0 ? g.E1 : g.E2;
 #pragma unroll
     for (int st = 0; st < NB; st++) load_b(0, st, fb[st]);
@@ -825,16 +844,16 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
       // ---- stage 1.  Fragments of step ks + 1 are read in front of the MFMAs of step ks: issued behind them, their
       // latency would be a bubble of the matrix pipe at every step
-      floatx16 e[2];                                    // (the first product of a unit takes the literal 0 as its addend)
-      frag_t xa[2][2][NS], lt[2][NS];                   // [ring][sample][slice], [ring][slice]
-      auto read_x = [&](int ks, frag_t (&x)[2][NS], frag_t (&l)[NS]) {
+      floatx16 e[TM];                                   // (the first product of a unit takes the literal 0 as its addend)
+      frag_t xa[2][TM][NS], lt[2][NS];                  // [ring][sample][slice], [ring][slice]
+      auto read_x = [&](int ks, frag_t (&x)[TM][NS], frag_t (&l)[NS]) {
 #pragma unroll
         for (int sl = 0; sl < NS; sl++) {
 #pragma unroll
-          for (int i = 0; i < 2; i++)
+          for (int i = 0; i < TM; i++)
             x[i][sl] = __builtin_bit_cast(
-                frag_t, *reinterpret_cast<const u32x4*>(xu_lane + i * 32 * MG_LDU + sl * MG_XU_SLICE + ks * 16));
-          l[sl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lt_lane + (ks * 2 + sl) * 128 * 8));
+                frag_t, *reinterpret_cast<const u32x4*>(xu_lane + i * 32 * MG_LDU + sl * XU_SLICE + ks * 16));
+          l[sl] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lt_lane + (ks * NS + sl) * 128 * 8));
         }
       };
       read_x(0, xa[0], lt[0]);
@@ -842,46 +861,67 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       for (int ks = 0; ks < TILE_UPAD / 16; ks++) {
         if (ks + 1 < TILE_UPAD / 16) read_x(ks + 1, xa[(ks + 1) & 1], lt[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        const frag_t (&x)[2][NS] = xa[ks & 1];
+        const frag_t (&x)[TM][NS] = xa[ks & 1];
         const frag_t (&l)[NS] = lt[ks & 1];
-#pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][1], l[0], ks == 0 ? floatx16{} : e[i]);
-#pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], l[1], e[i]);
-#pragma unroll
-        for (int i = 0; i < 2; i++) e[i] = slice_mfma<NS>(x[i][0], l[0], e[i]);
+        // slice products, smallest first (slice 0 = high)
+#define P2M_S1(SX, SL, FIRST)                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; i++)                                  \
+      e[i] = slice_mfma<NS>(x[i][SX], l[SL], (FIRST) && ks == 0 ? floatx16{} : e[i]);
+        if constexpr (NS == 3) {
+          P2M_S1(2, 0, true)
+          P2M_S1(0, 2, false)
+          P2M_S1(1, 1, false)
+          P2M_S1(1, 0, false)
+          P2M_S1(0, 1, false)
+          P2M_S1(0, 0, false)
+        } else {
+          P2M_S1(1, 0, true)
+          P2M_S1(0, 1, false)
+          P2M_S1(0, 0, false)
+        }
+#undef P2M_S1
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the plane leaves the accumulators: lane = tile row l31, registers j + 4 q4 = features 16 lhi + 4 j + q4
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < TM; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          u32x2 ph, pl2;
-          split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, ph, pl2);
+          u32x2 sl[NS];
+          if constexpr (NS == 2) split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, sl[0], sl[1]);
+          else split3_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], sl[0], sl[1], sl[2]);
           unsigned short* d = c_lane + i * 32 * MG_LDK + 4 * j;
-          *reinterpret_cast<u32x2*>(d) = ph;
-          *reinterpret_cast<u32x2*>(d + MG_A_SLICE) = pl2;
+#pragma unroll
+          for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * A_SLICE) = sl[z];
         }
       }
       lds_block_barrier();                              // X1(w): planes 1, 2 of unit w visible; union image released
       // ---- stage 2
       frag_t fa[2][NS][TM];                             // A fragments, one step ahead
-      read_a(0, 0, fa[0][0]);
-      read_a(1, 0, fa[0][1]);
+#pragma unroll
+      for (int sl = 0; sl < NS; sl++) read_a(sl, 0, fa[0][sl]);
 #pragma unroll
       for (int st = 0; st < 6; st++) {
         if (st + 1 < 6) {
-          read_a(0, (st + 1) * 16, fa[(st + 1) & 1][0]);
-          read_a(1, (st + 1) * 16, fa[(st + 1) & 1][1]);
+#pragma unroll
+          for (int sl = 0; sl < NS; sl++) read_a(sl, (st + 1) * 16, fa[(st + 1) & 1][sl]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
       acc[i][j] = slice_mfma<NS>(fa[st & 1][SA][i], fb[st % NB][SB][j], acc[i][j]);
-        P2M_PAIR(1, 0)
-        P2M_PAIR(0, 1)
-        P2M_PAIR(0, 0)
+        if constexpr (NS == 3) {
+          P2M_PAIR(2, 0)
+          P2M_PAIR(0, 2)
+          P2M_PAIR(1, 1)
+          P2M_PAIR(1, 0)
+          P2M_PAIR(0, 1)
+          P2M_PAIR(0, 0)
+        } else {
+          P2M_PAIR(1, 0)
+          P2M_PAIR(0, 1)
+          P2M_PAIR(0, 0)
+        }
 #undef P2M_PAIR
         __builtin_amdgcn_sched_barrier(0);
         if (st + NB < 6) load_b(fc, st + NB, fb[st % NB]);       // step st + NB of this unit, or of the next one (the last
@@ -892,25 +932,26 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       // front of stage 2 makes each of its waits for weight fragments a wait for the store's HBM acknowledgement as well
       if (Eout != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-          const int bsm = grp * CT_S + wm * 2 + i;
+        for (int i = 0; i < TM; i++) {
+          const int bsm = grp * SG + wm * TM + i;
           if (l31 < R && bsm < g.B) {
             float* dst = Eout + ((long)bsm * g.nset + r0 + l31) * g.Ka + fc * CT_CF + 16 * lhi;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               f32x4 o;
 #pragma unroll
-              for (int q4 = 0; q4 < 4; q4++) o[q4] = __builtin_ldexpf(e[i][j + 4 * q4], -(sx + pl.lt_exp));
+              for (int q4 = 0; q4 < 4; q4++)
+                o[q4] = NS == 2 ? __builtin_ldexpf(e[i][j + 4 * q4], -(sx + lt_exp)) : e[i][j + 4 * q4];
               *reinterpret_cast<f32x4*>(dst + 4 * j) = o;          // (cached: L2 merges the 16-byte pieces of a line)
             }
           }
         }
       }
       if (fc == nchunks - 1) {
-        if (R == 32 && (grp + 1) * CT_S <= g.B && descale >= -120 && descale <= 120)
-          tile_epilogue_full<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, wm, wn, l31, lhi, descale);
+        if (R == 32 && (grp + 1) * SG <= g.B && descale >= -120 && descale <= 120)
+          tile_epilogue_full<TM, TN, MODE, SG>(g, pl, acc, rowvid, grp, tile, wm, wn, l31, lhi, descale);
         else
-          tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
+          tile_epilogue<TM, TN, MODE, SG>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
         grp++;
       }
       fc = fcn;
@@ -951,8 +992,8 @@ struct DeviceOnce {
 // gpb: sample groups a block walks (tables loaded once per block).  At least ~8 blocks per CU so that the last round of
 // blocks is well filled (measured over the 16 real-row shapes of a train step: gpb 16 / 8 / 4 / 2 -> 21.4 / 19.0 / 18.4 /
 // 18.0 ms; the finest level alone prefers 8 by 2 %).
-static int pick_gpb(int ntiles, int ngroups) {
-  int gpb = 8;
+static int pick_gpb(int ntiles, int ngroups, int gpb_max = 8) {
+  int gpb = gpb_max;
   while (gpb > 1 && (long)ntiles * cdiv(ngroups, gpb) < 8 * 256) gpb >>= 1;
   return gpb;
 }
@@ -980,35 +1021,64 @@ static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
   if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT, NS>(a, s);
   return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN, NS>(a, s);
 }
-template <int TM, int TN, int NPW, int MODE>
+template <int TMS, int TN, int NPW, int MODE, int NS>
 static int launch_mg_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
+  constexpr int SG = 2 * TMS;
+  constexpr int LDS_BYTES = mg_lds_bytes(NS, SG);
   static DeviceOnce attr_set;
   if (const int rc = attr_set.run([] {
-        return hipFuncSetAttribute((const void*)k_cheb_mg_gemm<TM, TN, NPW, MODE>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
-      }, "p2m_cheb_tile_gemm(matrix gather)", MG_LDS_BYTES))
+        return hipFuncSetAttribute((const void*)k_cheb_mg_gemm<TMS, TN, NPW, MODE, NS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      }, "p2m_cheb_tile_gemm(matrix gather)", LDS_BYTES))
     return rc;
-  const int ngroups = cdiv(a.B, CT_S);
-  const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
-  hipLaunchKernelGGL((k_cheb_mg_gemm<TM, TN, NPW, MODE>), dim3(nblocks), dim3(256 + 64 * NPW), MG_LDS_BYTES, s, a);
+  TileGemmArgs b = a;
+  const int ngroups = cdiv(a.B, SG);
+  // (2-sample units: a block still walks up to 16 samples' worth of groups, so that the 48 KB operator block and the
+  //  tables are loaded as rarely per row as with 4-sample units)
+  b.gpb = pick_gpb(a.pl.ntiles, ngroups, SG == 2 ? 16 : 8);
+  const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, b.gpb), 8) * 8;
+  hipLaunchKernelGGL((k_cheb_mg_gemm<TMS, TN, NPW, MODE, NS>), dim3(nblocks), dim3(256 + 64 * NPW), LDS_BYTES, s, b);
   return check_launch("cheb_tile_gemm(matrix gather)");
 }
-template <int TM, int TN, int NPW>
+template <int TMS, int TN, int NPW, int NS>
 static int launch_mg_gemm(const TileGemmArgs& a, hipStream_t s) {
-  if (a.stats != nullptr) return launch_mg_gemm_mode<TM, TN, NPW, CT_STATS>(a, s);
-  if (a.addend != nullptr) return launch_mg_gemm_mode<TM, TN, NPW, CT_ADDEND>(a, s);
-  if (a.act_scale != nullptr || a.act_relu) return launch_mg_gemm_mode<TM, TN, NPW, CT_ACT>(a, s);
-  return launch_mg_gemm_mode<TM, TN, NPW, CT_PLAIN>(a, s);
+  if (a.stats != nullptr) return launch_mg_gemm_mode<TMS, TN, NPW, CT_STATS, NS>(a, s);
+  if (a.addend != nullptr) return launch_mg_gemm_mode<TMS, TN, NPW, CT_ADDEND, NS>(a, s);
+  if (a.act_scale != nullptr || a.act_relu) return launch_mg_gemm_mode<TMS, TN, NPW, CT_ACT, NS>(a, s);
+  return launch_mg_gemm_mode<TMS, TN, NPW, CT_PLAIN, NS>(a, s);
+}
+
+// P2M_MG_EXACT (read once per process): 1 = three-bf16-slice launches with N <= 128 take the
+// matrix-core gather like the two-fp16-slice ones; 0 (default) = the VALU-gather kernel.  Measured over the real-row shapes of a
+// train step at B = 256 (profiles/r05_d_probe_mg{0,1}.txt): forward 8.63 vs 8.51 ms, with the planes out 5.29 vs 5.21 ms - the
+// exact matrix-core gather (240 MFMAs per 128 rows x 32 features in 2-sample units) only ties the VALU gather that six slice
+// products per step already hide, so the kernel with bitwise planes stays the default.
+static bool mg_exact() {
+  static const bool v = [] { const char* e = getenv("P2M_MG_EXACT"); return e ? atoi(e) != 0 : false; }();
+  return v;
 }
 
 template <int TM, int TN, int NPW>
 static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
-  if (a.x_amax == nullptr) return launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
-  // two fp16 slices: N <= 128 takes the gather on the matrix cores (4 producer waves: they only move data, and the MFMA
-  // waves need the 256-register budget for the dense-block rows and two accumulator sets); N = 256 (a 128-register
-  // accumulator) stays with the VALU gather
-  if constexpr (TN == 1) return a.N == 128 ? launch_mg_gemm<2, 2, 4>(a, s) : launch_mg_gemm<2, 1, 4>(a, s);
+  // N <= 128 takes the gather on the matrix cores (4 producer waves: they only move data, and the MFMA waves need the
+  // 256-register budget for the dense-block rows and the accumulator sets); N = 256 (a 128-register accumulator) stays
+  // with the VALU gather.  Two fp16 slices: 4 samples per unit; three bf16 slices: 2 samples per unit (LDS).
+  if (a.x_amax == nullptr) {
+    if constexpr (TN == 1) {
+      if (mg_exact() && a.pl.ltx3 != nullptr)
+        return a.N == 128 ? launch_mg_gemm<1, 2, 4, 3>(a, s) : launch_mg_gemm<1, 1, 4, 3>(a, s);
+    }
+    return launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
+  }
+  if constexpr (TN == 1) return a.N == 128 ? launch_mg_gemm<2, 2, 4, 2>(a, s) : launch_mg_gemm<2, 1, 4, 2>(a, s);
   else return launch_tile_gemm_ns<TM, TN, NPW, 2>(a, s);
+}
+
+extern "C" int32_t p2m_cheb_tile_gemm_mg(int32_t arith, int32_t N) {
+  /* 1 when a p2m_cheb_tile_gemm launch of this arithmetic / width takes the matrix-core gather (planes out supported at
+   * full speed, E1 / E2 to fp32 round-off instead of bitwise the basis kernel's) */
+  if (N > 128) return 0;
+  return arith == P2M_ARITH_F16X2 || (arith == P2M_ARITH_BF16X3 && mg_exact()) ? 1 : 0;
 }
 
 extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, int32_t Ka, int32_t N) {

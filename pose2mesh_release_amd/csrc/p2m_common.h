@@ -30,9 +30,14 @@ struct TilePlan {
   // ltx[tile][u / 16][slice][(u / 8) % 2][p * 32 + i][u % 8].
   unsigned short* ltx = nullptr;
   int lt_exp = 0;
+  // (round 5) the same block as three EXACT bf16 slices of the fp32 coefficients, unscaled, same unit layout with three
+  // slices per 16-column step: ltx3[tile][u / 16][slice][(u / 8) % 2][p * 32 + i][u % 8] - the matrix-core gather in the
+  // three-bf16-slice arithmetic
+  unsigned short* ltx3 = nullptr;
 };
 constexpr int TILE_UPAD = 128;                       // union columns of the dense block (>= TILE_UCAP, a multiple of 16)
 constexpr int TILE_LTX_ELEMS = (TILE_UPAD / 16) * 2 * 64 * 16;     // uint16 per tile: 32 KB
+constexpr int TILE_LTX3_ELEMS = (TILE_UPAD / 16) * 3 * 64 * 16;    // 48 KB
 // (measured and rejected: 64-row tiles / 240 union rows - halving the resident blocks costs more than the 22 % fewer L2-side
 //  reads bring; 80 / 512 and 100 / 768 at three resident blocks: DESIGN.md section 6)
 constexpr int TILE_RMAX = 32;      // rows per tile

@@ -677,8 +677,16 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
         return True
     if plan == 2:
         return False
-    if f16x2() and N <= 128:        # the gather runs on the matrix cores (k_cheb_mg_gemm): also with the planes written out,
-        return g.n_real >= TILE_GEMM_MG_MIN_ROWS        # at any batch (B = 64 inference 3.51 vs 3.96 ms, B = 8 1.63 vs 1.76)
+    if _lib.hip().p2m_cheb_tile_gemm_mg(arith_code(), N):
+        # the gather runs on the matrix cores (k_cheb_mg_gemm: f16x2; bf16x3 with P2M_MG_EXACT=1): also with the planes
+        # written out, at any batch (f16x2: B = 64 inference 3.51 vs 3.96 ms, B = 8 1.63 vs 1.76)
+        return g.n_real >= TILE_GEMM_MG_MIN_ROWS
+    if GEMM_ARITH == "bf16x3":
+        # Round 5 (profiles/r05_d_probe_mg0.txt, B = 256): in the exact arithmetic the VALU-gather tile kernel beats basis
+        # kernel + plane contraction on EVERY own / un-pooled plan of the split levels, N = 256 and planes out included
+        # (finest 128 -> 128: 1.85 vs 2.51 ms forward, 2.08 vs 2.51 with the planes; 1 472-vertex level 256 -> 256: 0.89 vs 1.08):
+        # six slice products per MFMA step hide the gather's VALU work that the three of f16x2 do not.
+        return g.n_real >= TILE_GEMM_MG_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
     return not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
 
 
@@ -757,7 +765,7 @@ def fold_act_ok(g, Ka, N, B, narrow=False):
         return False
     if narrow:
         return bool(g.classes)
-    if N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B):
+    if tile_gemm_ok(g, 0, Ka, N, False, B=B):
         return True
     return bool(BASIS_TILED and g.plan_tiles[0] > 0 and (Ka in (32, 64) or Ka % 128 == 0) and N % 32 == 0
                 and not tile_gemm_ok(g, 0, Ka, N, False, B=B))
@@ -786,7 +794,7 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
         # relu(y * scale + shift) on load: tile kernel / basis kernel + plane 0 of the contraction / fake-row contraction
         if a0_shift != 0 or want_planes:
             raise P2MError("conv_split: activation on load needs the level's own plan and no planes out (fold_act_ok)")
-        if N <= 128 and tile_gemm_ok(g, 0, Ka, N, False, B=B):
+        if tile_gemm_ok(g, 0, Ka, N, False, B=B):
             st1, _ = cheb_tile_gemm(g, 0, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats, amax=xa, amax_out=amax_out,
                                     in_act=in_act)
             tiled = True
