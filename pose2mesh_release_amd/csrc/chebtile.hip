@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
   static_assert(NPW == 4 && (SG == 4 || SG == 2), "256 producer lanes; 4 or 2 samples per unit");
   constexpr int NUH = NP >> (4 + SB);         // u-quad pairs walked in parallel by the producer lanes
   constexpr int NXI = 16 / NUH;               // union items (4 rows x 4 features) per producer lane
-  constexpr int NPR = NP >> (3 + SB);         // tile rows walked in parallel (plane 0)
+  constexpr int NPR = NP >> (3 + SB);         // tile rows walked in parallel (plane 0): 8 (SG = 4) or 16 (SG = 2)
   constexpr int NPI = 32 / NPR;               // plane-0 items (1 row x 4 features) per producer lane
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* Xu = reinterpret_cast<unsigned short*>(ct_smem);
@@ -703,12 +703,16 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
         const int u = ((((uhi + k * NUH) << 1) | ulo) << 2) + j;
         uoff[k][j] = (unsigned)pl.ucol[u0 + (u < U ? u : U - 1)] * (unsigned)(g.Ka * 4);   // clamped: their Lt columns are 0
       }
-    // plane-0 items: (tile row, sample, q)
-    const int s0 = (pt >> 3) & (SG - 1), i0 = pt >> (3 + SB);
+    // plane-0 items: (tile row, sample, q).  Round 5 (profiles/r05_f_lds_conflict_ablation.txt): the 16 lanes of a store
+    // group were 8 q x 2 SAMPLES - 32 rows = 1 664 dwords = 0 mod 32 banks apart: a 2-way conflict on every store (8.0 M of
+    // the kernel's 24.1 M SQ_LDS_BANK_CONFLICT cycles).  Now 8 q x 2 rows FOUR apart (208 dwords = 16 mod 32): the 8-byte
+    // stores of a group tile the 32 banks.
+    const int r4 = (pt >> 3) & 1, s0 = (pt >> 4) & (SG - 1), rh = pt >> (4 + SB);
+    auto p0_row = [&](int k) { return (rh & 3) + 4 * r4 + 8 * ((rh >> 2) + (NPR / 8) * k); };
     unsigned a0off[NPI];
 #pragma unroll
     for (int k = 0; k < NPI; k++) {
-      const int vid = rowvid[i0 + k * NPR];
+      const int vid = rowvid[p0_row(k)];
       a0off[k] = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
     }
     f32x4 xr[NXI][4], p0[NPI];
@@ -757,8 +761,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
           u32x2 sl[NS];
           split_pack4<NS>(xr[k][0][e], xr[k][1][e], xr[k][2][e], xr[k][3][e], x_sc, sl);
           unsigned short* d = Xu + (s * 32 + e * 8 + q) * MG_LDU + uq * 4;
+#ifndef P2M_ABL_NO_XU        // (profiling ablations, tools/lds_conflict_ablation.sh: which LDS access class conflicts)
 #pragma unroll
           for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * XU_SLICE) = sl[z];
+#else
+          asm volatile("" :: "v"(sl[0]), "v"(sl[NS - 1]), "v"(d));
+#endif
         }
       }
     };
@@ -774,9 +782,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       for (int k = 0; k < NPI; k++) {
         u32x2 sl[NS];
         split_pack4<NS>(p0[k][0], p0[k][1], p0[k][2], p0[k][3], x_sc, sl);
-        unsigned short* d = Ai + (s0 * 32 + i0 + k * NPR) * MG_LDK + q * 4;
+        unsigned short* d = Ai + (s0 * 32 + p0_row(k)) * MG_LDK + q * 4;
+#ifndef P2M_ABL_NO_P0
 #pragma unroll
         for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * A_SLICE) = sl[z];
+#else
+        asm volatile("" :: "v"(sl[0]), "v"(sl[NS - 1]), "v"(d));
+#endif
       }
     };
     load_unit();
@@ -846,6 +858,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
       // latency would be a bubble of the matrix pipe at every step
       floatx16 e[TM];                                   // (the first product of a unit takes the literal 0 as its addend)
       frag_t xa[2][TM][NS], lt[2][NS];                  // [ring][sample][slice], [ring][slice]
+#if defined(P2M_ABL_LINEAR_X)      // x fragments from a LINEAR (lane * 16 bytes) pattern: wrong values, conflict-free by construction
+      const unsigned short* xu_lane = Xu + lane * 8;
+#endif
+#if defined(P2M_ABL_LINEAR_LT)
+      const unsigned short* lt_lane = Lt + lane * 8;
+#endif
       auto read_x = [&](int ks, frag_t (&x)[TM][NS], frag_t (&l)[NS]) {
 #pragma unroll
         for (int sl = 0; sl < NS; sl++) {
@@ -883,20 +901,37 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_mg_gemm(
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the plane leaves the accumulators: lane = tile row l31, registers j + 4 q4 = features 16 lhi + 4 j + q4
+      // Round 5: two feature quads per 16-BYTE store.  As 8-byte stores the 16 lanes of a store group were 16 tile rows of one
+      // column - row stride 52 dwords = 20 mod 32 banks has period 8: a 2-way conflict on every store, 16.1 M of the kernel's
+      // 24.1 M SQ_LDS_BANK_CONFLICT cycles (ablation: profiles/r05_f_lds_conflict_ablation.txt).  A ds_write_b128 is serviced
+      // in groups of 8 lanes = 8 rows x 4 banks: they tile the 32 banks, and the stores are half as many.
 #pragma unroll
       for (int i = 0; i < TM; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          u32x2 sl[NS];
-          if constexpr (NS == 2) split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, sl[0], sl[1]);
-          else split3_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], sl[0], sl[1], sl[2]);
-          unsigned short* d = c_lane + i * 32 * MG_LDK + 4 * j;
+        for (int jp = 0; jp < 2; jp++) {
+          u32x2 sa[NS], sb[NS];
+          const int j = 2 * jp;
+          if constexpr (NS == 2) {
+            split2_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], e_sc, sa[0], sa[1]);
+            split2_pack4(e[i][j + 1], e[i][j + 5], e[i][j + 9], e[i][j + 13], e_sc, sb[0], sb[1]);
+          } else {
+            split3_pack4(e[i][j], e[i][j + 4], e[i][j + 8], e[i][j + 12], sa[0], sa[1], sa[2]);
+            split3_pack4(e[i][j + 1], e[i][j + 5], e[i][j + 9], e[i][j + 13], sb[0], sb[1], sb[2]);
+          }
+          unsigned short* d = c_lane + i * 32 * MG_LDK + 8 * jp;
+#ifndef P2M_ABL_NO_CONV
 #pragma unroll
-          for (int z = 0; z < NS; z++) *reinterpret_cast<u32x2*>(d + z * A_SLICE) = sl[z];
+          for (int z = 0; z < NS; z++) *reinterpret_cast<u32x4*>(d + z * A_SLICE) = u32x4{sa[z][0], sa[z][1], sb[z][0], sb[z][1]};
+#else
+          asm volatile("" :: "v"(sa[0]), "v"(sb[NS - 1]), "v"(d));
+#endif
         }
       }
       lds_block_barrier();                              // X1(w): planes 1, 2 of unit w visible; union image released
       // ---- stage 2
+#if defined(P2M_ABL_LINEAR_A)
+      const unsigned short* a_lane = Ai + lane * 8;
+#endif
       frag_t fa[2][NS][TM];                             // A fragments, one step ahead
 #pragma unroll
       for (int sl = 0; sl < NS; sl++) read_a(sl, 0, fa[0][sl]);
