@@ -388,6 +388,12 @@ int p2m_bn_finalize_tiles(p2m_graph_t g, int32_t plan, const float* stats_real, 
  *             the constant term once per member.
  * Results are those of the full computation (fp32 round-off class: the statistics' summation order changes).       */
 int p2m_graph_fake_ids(p2m_graph_t g, int32_t* out /* host, n_fake entries */);
+/* The REAL (non-padding) vertices of the level in COMPACT ROW ORDER: row i of every compact plane ([B * n_real, F]:
+ * p2m_cheb_basis_fwd_real, the planes out of p2m_cheb_tile_gemm, planes_compact of p2m_gemm_planes_rows / p2m_gemm_tn_rows)
+ * belongs to vertex out[i].  A permutation of the real vertex ids - since round 5 a LOCALITY order (greedy patches over the
+ * level's graph, so that the 32-row tiles of the tile plans have small neighbourhood unions), not the ascending one;
+ * P2M_TILE_ORDER=tree (environment, read once) keeps the ascending coarsening-tree order.  out: [n_real] int32, host.  */
+int p2m_graph_real_ids(p2m_graph_t g, int32_t* out);
 int p2m_graph_set_classes(p2m_graph_t g, const int32_t* rep_of /* host, V entries */);
 int p2m_graph_class_info(p2m_graph_t g, int32_t counts[3] /* has classes, representatives, all fake vertices */);
 /* weighted BatchNorm partials of the representatives of y [B*V, N]: stats [B * ceil(n_rep/128)][2][N] */

@@ -61,6 +61,7 @@ HIP_SYMBOLS = {
     "p2m_bn_finalize_tiles": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                          _i32, _vp]),
     "p2m_graph_fake_ids": (_c.c_int, [_vp, _vp]),
+    "p2m_graph_real_ids": (_c.c_int, [_vp, _vp]),
     "p2m_graph_set_classes": (_c.c_int, [_vp, _vp]),
     "p2m_graph_class_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 3)]),
     "p2m_stats_rows_w": (_c.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <map>
 #include <utility>
 #include <vector>
@@ -61,6 +62,76 @@ static inline unsigned short f16_bits(float v) {
   unsigned short b;
   memcpy(&b, &h, sizeof(b));
   return b;
+}
+
+// Locality order of the real rows (round 5).  Tiles are runs of <= TILE_RMAX consecutive rows of the compact
+// real-row order whose merged-CSR neighbourhoods have <= TILE_UCAP distinct source rows.  In the coarsening-tree order
+// (lib/coarsening.py:214-258) 32 consecutive real rows touch ~130 rows, so the cap cuts the tiles at ~28 rows: 12 % of the
+// 32-row MFMA tiles are padding and every output row fetches 4.05 union rows.  Here the order is rebuilt by greedy patch
+// growing over the level's graph: a patch starts at the unassigned real vertex with the most assigned neighbours and keeps
+// adding the frontier vertex whose merged row adds the FEWEST new union columns, until 32 rows or a cap.  Measured on the
+// SMPL-like levels (tools/probes/tile_locality_probe.py, profiles/r05_tile_locality_probe.txt): 245 -> 230 tiles, 28.1 -> 30.0
+// rows per tile, 4.05 -> 3.55 union rows per row at the finest level.  (The 2-ring of ANY 32-vertex patch of this degree-3..13
+// mesh is ~100 rows: <= 3.0 rows per row is out of reach of a reordering.)  The order only permutes the compact row set
+// (real_ids): storage order, r >> 1 un-pooling and the classes are untouched.  P2M_TILE_ORDER=tree keeps the tree order.
+static std::vector<int> locality_order(const std::vector<int>& real_ids, int V, const int32_t* row_ptr, const int32_t* col,
+                                       const std::vector<int>& rp, const std::vector<int>& mc) {
+  const int n = (int)real_ids.size();
+  std::vector<char> isreal(V, 0), assigned(V, 0), infront(V, 0), inbound(V, 0);
+  for (int v : real_ids) isreal[v] = 1;
+  std::vector<int> cnt(V, 0), stamp(V, -1), order, boundary, front;
+  order.reserve(n);
+  int done = 0, next_unassigned = 0, patch_id = 0;
+  while (done < n) {
+    // seed: the boundary vertex with the most assigned neighbours (ties: the smallest id), else the first unassigned one
+    int seed = -1, best = -1;
+    size_t keep = 0;
+    for (size_t q = 0; q < boundary.size(); q++) {
+      const int v = boundary[q];
+      if (assigned[v]) continue;
+      boundary[keep++] = v;
+      if (cnt[v] > best || (cnt[v] == best && v < seed)) { best = cnt[v]; seed = v; }
+    }
+    boundary.resize(keep);
+    if (seed < 0) {
+      while (assigned[real_ids[next_unassigned]]) next_unassigned++;
+      seed = real_ids[next_unassigned];
+    }
+    patch_id++;
+    front.clear();
+    int rows = 0, usize = 0, entries = 0;
+    int cur = seed;
+    while (true) {
+      // add `cur` to the patch
+      for (int j = rp[cur]; j < rp[cur + 1]; j++)
+        if (stamp[mc[j]] != patch_id) { stamp[mc[j]] = patch_id; usize++; }
+      entries += rp[cur + 1] - rp[cur];
+      assigned[cur] = 1;
+      order.push_back(cur);
+      rows++;
+      done++;
+      for (int j = row_ptr[cur]; j < row_ptr[cur + 1]; j++) {
+        const int w = col[j];
+        cnt[w]++;
+        if (isreal[w] && !assigned[w] && !infront[w]) { infront[w] = 1; front.push_back(w); }
+      }
+      if (rows >= TILE_RMAX) break;
+      int pick = -1, pick_new = 1 << 30;
+      for (int w : front) {
+        if (assigned[w]) continue;
+        int nw = 0;
+        for (int j = rp[w]; j < rp[w + 1]; j++) nw += stamp[mc[j]] != patch_id;
+        if (nw < pick_new || (nw == pick_new && w < pick)) { pick_new = nw; pick = w; }
+      }
+      if (pick < 0 || usize + pick_new > TILE_UCAP || entries + (rp[pick + 1] - rp[pick]) > TILE_ECAP) break;
+      cur = pick;
+    }
+    for (int w : front) {                       // what is left of the frontier joins the boundary of the assigned region
+      infront[w] = 0;
+      if (!assigned[w] && !inbound[w]) { inbound[w] = 1; boundary.push_back(w); }
+    }
+  }
+  return order;
 }
 
 // entry_bits: binades that bound the entries' magnitudes (|a|, |b| <= 2^entry_bits): the dense blocks are stored times
@@ -245,6 +316,10 @@ extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, cons
   // tile plans of the LDS-staged basis kernel (levels with a real/fake split only; small levels keep the row kernel)
   if (g->n_fake > 0 && g->n_real >= 256) {
     int rc2 = P2M_OK;
+    {
+      static const bool tree_order = [] { const char* e = getenv("P2M_TILE_ORDER"); return e && !strcmp(e, "tree"); }();
+      if (!tree_order) real_ids = locality_order(real_ids, V, row_ptr, col, rp, mc);
+    }
     for (int sh = 0; sh < 2 && rc2 == P2M_OK; sh++) {
       if (sh == 1 && (V & 1)) break;
       FlatRows fr;
@@ -385,6 +460,15 @@ extern "C" int p2m_graph_fake_ids(p2m_graph_t gh, int32_t* out) {
   const Graph* g = reinterpret_cast<const Graph*>(gh);
   if (g->n_fake == 0) return P2M_OK;
   hipError_t e = hipMemcpy(out, g->fake_ids, sizeof(int) * g->n_fake, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); return P2M_ERR_HIP; }
+  return P2M_OK;
+}
+
+extern "C" int p2m_graph_real_ids(p2m_graph_t gh, int32_t* out) {
+  P2M_CHECK_ARG(gh && out, "null pointer");
+  const Graph* g = reinterpret_cast<const Graph*>(gh);
+  if (g->n_real == 0) return P2M_OK;
+  hipError_t e = hipMemcpy(out, g->real_ids, sizeof(int) * g->n_real, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); return P2M_ERR_HIP; }
   return P2M_OK;
 }

@@ -190,6 +190,13 @@ class DeviceGraph:
         check(_lib.hip().p2m_graph_fake_ids(self.handle, out.ctypes.data_as(_vp)), "p2m_graph_fake_ids")
         return out[:self.n_fake]
 
+    def real_ids_host(self):
+        """The real vertices in COMPACT ROW ORDER (row i of every compact plane belongs to vertex out[i]): a locality
+        order since round 5, not the ascending one (include/p2m.h p2m_graph_real_ids)."""
+        out = np.zeros(max(self.n_real, 1), dtype=np.int32)
+        check(_lib.hip().p2m_graph_real_ids(self.handle, out.ctypes.data_as(_vp)), "p2m_graph_real_ids")
+        return out[:self.n_real]
+
     def set_classes(self, rep_of):
         """Declare the runs of identical fake rows (include/p2m.h "classes"): afterwards row sets 2 / 4 hold the
         representatives only."""

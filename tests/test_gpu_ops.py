@@ -417,7 +417,9 @@ def test_tiled_basis_is_bitwise_the_full_basis(ops, V, Fdim, shift, B):
     X = torch.randn(B * (V >> shift), Fdim, generator=gen).cuda()
     T1, T2 = ops.cheb_basis_fwd(g, X, B, Fdim, shift)
     T1c, T2c = ops.cheb_basis_fwd_real(g, X, B, Fdim, shift)
-    real = torch.as_tensor(_real_ids(L), device="cuda")
+    order = g.real_ids_host()                  # compact row i <-> vertex order[i] (a locality order since round 5)
+    assert np.array_equal(np.sort(order), _real_ids(L))
+    real = torch.as_tensor(order.astype(np.int64), device="cuda")
     assert real.numel() == g.n_real
     ref1 = T1.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
     ref2 = T2.view(B, V, Fdim)[:, real].reshape(-1, Fdim)
