@@ -85,7 +85,7 @@ class GraphedInference:
             self._held = [m._weight_cache._d.copy() for m in self.model.modules() if hasattr(m, "_weight_cache")]
             if self.use_graph:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _ops.capture_guard(), torch.cuda.graph(g):     # (no finalizer may run inside the capture)
                     out = self._eager()
                 self.graph = g
             self.mesh, self.joints, self.pose3d = out

@@ -212,12 +212,54 @@ class DeviceGraph:
         self.n_pair_real, self.n_pair_fake = int(c2[0]), int(c2[1])
 
     def __del__(self):
+        # p2m_graph_destroy calls hipFree, which is illegal while ANY stream of the thread captures (it invalidates the
+        # capture): the cyclic garbage collector may run this finalizer at any allocation - also inside a `with
+        # torch.cuda.graph(...)` block (round 5: GraphedInference re-captures failed with hipErrorStreamCaptureInvalidated in
+        # long test processes full of collectable models).  During a capture the handle is parked and freed later.
         try:
-            if getattr(self, "handle", None):
-                _lib.hip().p2m_graph_destroy(self.handle)
+            h = getattr(self, "handle", None)
+            if h:
                 self.handle = None
+                if _capturing():
+                    _deferred_destroy.append(h)
+                else:
+                    _lib.hip().p2m_graph_destroy(h)
         except Exception:
             pass
+
+
+_deferred_destroy = []      # graph handles whose finalizer ran during a stream capture (DeviceGraph.__del__)
+
+
+def drain_deferred_destroys():
+    """Free the graph handles parked by finalizers that ran inside a stream capture (no-op while capturing)."""
+    if _deferred_destroy and not _capturing():
+        while _deferred_destroy:
+            try:
+                _lib.hip().p2m_graph_destroy(_deferred_destroy.pop())
+            except Exception:
+                pass
+
+
+class capture_guard:
+    """Context manager around a stream capture (infer.GraphedInference, train.GraphedTrainStep): collects garbage BEFORE the
+    capture and keeps the cyclic collector off inside it, so that no finalizer - ours (hipFree) or torch's (graphs, events,
+    streams of dead objects) - runs API calls that are illegal during a capture; parked handles are freed afterwards."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        drain_deferred_destroys()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *a):
+        import gc
+        if self._was:
+            gc.enable()
+        drain_deferred_destroys()
+        return False
 
 
 def class_representatives(V, fake_ids, depth):
@@ -371,6 +413,8 @@ def amax_begin_step(device):
     """Renew the device's chunk of amax words: called at the start of every forward that hands words out (the network's
     AND the stand-alone ChebConv's)."""
     _amax_chunks.pop(torch.device(device).index, None)
+    if _deferred_destroy:
+        drain_deferred_destroys()
 
 
 def _capturing():

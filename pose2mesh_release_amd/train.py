@@ -63,7 +63,7 @@ class GraphedTrainStep:
                 self.opt.zero_grad()
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
+            with _ops.capture_guard(), torch.cuda.graph(g, stream=self.stream):   # (no finalizer may run inside the capture)
                 self.opt.zero_grad()
                 loss = self.loss_fn()
                 loss.backward()

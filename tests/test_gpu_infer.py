@@ -179,3 +179,28 @@ def test_graphed_inference_at_configs1_size_vs_oracle(hip_libs):
     assert helpers.max_vertex_l2(mesh[idx].cpu() / 1000.0, om / 1000.0) <= 1e-4
     assert (joints[idx].cpu() - oj).abs().max() <= 1e-1                      # millimetres (1e-4 m)
     net.set_inference(real_only=False)
+
+
+def test_graph_handle_finalizer_is_capture_safe(hip_libs):
+    """Round 5: DeviceGraph.__del__ frees device memory (hipFree), which invalidates any stream capture in progress, and the
+    cyclic garbage collector may run it at any time (GraphedInference re-captures failed with hipErrorStreamCaptureInvalidated
+    in long processes full of dead models).  Inside a capture the handle is parked and the capture survives; it is freed
+    afterwards.  ops.capture_guard (used by GraphedInference / GraphedTrainStep) also keeps the collector off inside."""
+    import gc
+    from pose2mesh_release_amd import ops
+    gL, _, _ = helpers.golden_graphs("mano")
+    victim = ops.DeviceGraph(gL[0], "cuda:0")
+    a = torch.ones(8, device="cuda")
+    torch.cuda.synchronize()
+    ops.drain_deferred_destroys()
+    g = torch.cuda.CUDAGraph()
+    with ops.capture_guard(), torch.cuda.graph(g):
+        assert not gc.isenabled()
+        b = a * 2.0
+        del victim                                   # refcount -> 0: the finalizer runs HERE, inside the capture
+        assert len(ops._deferred_destroy) == 1
+        c = b + 1.0
+    assert gc.isenabled() and len(ops._deferred_destroy) == 0        # freed after the capture
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(c, torch.full((8,), 3.0, device="cuda"))
