@@ -1229,14 +1229,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * WTN + j * 32 + l31;
+        // accumulate form (p2m_gemm_tn_acc): the 16 old values of the tile first, all loads in flight, then add and store
+        // (one load - add - store chain per element waited for every load in turn: 116 us for a 4096 x 4096 gradient)
+        float old[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (krow < g.Ktot && n < g.N) {
-            float* d = Pc + (long)krow * g.N + n;
-            const float v = __builtin_ldexpf(acc[i][j][r], descale);
-            *d = g.accum ? *d + v : v;
-          }
+          old[r] = (g.accum && krow < g.Ktot && n < g.N) ? Pc[(long)krow * g.N + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int krow = kk0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (krow < g.Ktot && n < g.N) Pc[(long)krow * g.N + n] = __builtin_ldexpf(acc[i][j][r], descale) + old[r];
         }
       }
   }
@@ -1296,6 +1300,46 @@ __global__ void k_weight_pack(const float* __restrict__ W, float* __restrict__ W
   Wt[idx] = v;
   if (W2) W2[(long)fout * Fin * K + kk] = v;
   if (W3) W3[((long)k * Fout + fout) * Fin + fin] = v;     // [k*Fout + fout][fin]: B operand of dX = [g|Lg|L2g] W3
+}
+
+// K = 1, Wt only: a plain transpose Wt[fin][fout] = W[fout][fin] (the fc lift of meshnet.py:105 and, round 5, the four
+// 4096 x 4096 Linears of PoseNet: 67 MB each per optimizer step).  k_weight_pack reads W at a stride of Fin floats per lane:
+// 100 us for 4096 x 4096 (1.3 TB/s) in the round-5 step trace.  64 x 64 tiles through LDS, 16-byte accesses on both sides.
+__global__ __launch_bounds__(256) void k_transpose_tiled(const float* __restrict__ W, float* __restrict__ Wt, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tq = threadIdx.x & 15, ty = threadIdx.x >> 4;           // 16 column quads x 16 rows per pass
+  const bool vec = (C & 3) == 0 && (R & 3) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int r = r0 + ty + 16 * p, c = c0 + 4 * tq;
+    if (r < R) {
+      if (vec && c + 3 < C) {
+        const float4 v = *reinterpret_cast<const float4*>(W + (long)r * C + c);
+        tile[ty + 16 * p][4 * tq] = v.x; tile[ty + 16 * p][4 * tq + 1] = v.y;
+        tile[ty + 16 * p][4 * tq + 2] = v.z; tile[ty + 16 * p][4 * tq + 3] = v.w;
+      } else {
+        for (int e = 0; e < 4; e++)
+          if (c + e < C) tile[ty + 16 * p][4 * tq + e] = W[(long)r * C + c + e];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int c = c0 + ty + 16 * p, r = r0 + 4 * tq;               // output row c, columns r .. r + 3
+    if (c < C) {
+      if (vec && r + 3 < R) {
+        float4 v;
+        v.x = tile[4 * tq][ty + 16 * p]; v.y = tile[4 * tq + 1][ty + 16 * p];
+        v.z = tile[4 * tq + 2][ty + 16 * p]; v.w = tile[4 * tq + 3][ty + 16 * p];
+        *reinterpret_cast<float4*>(Wt + (long)c * R + r) = v;
+      } else {
+        for (int e = 0; e < 4; e++)
+          if (r + e < R) Wt[(long)c * R + r + e] = tile[4 * tq + e][ty + 16 * p];
+      }
+    }
+  }
 }
 
 // Weff[k][n] = Wt[k][n] + a * Wt[Ka + k][n] + b * Wt[2 Ka + k][n]: the K = Fin weight seen by fake vertices
@@ -1853,6 +1897,12 @@ extern "C" int p2m_weight_pack(const float* W, float* Wt, float* W2, float* W3, 
                                void* stream) {
   P2M_CHECK_ARG(W && Wt && Fout > 0 && Fin > 0 && K > 0, "null pointer or empty shape");
   long tot = (long)Fout * Fin * K;
+  if (K == 1 && W2 == nullptr && W3 == nullptr && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(Wt) & 15) == 0) {
+    hipLaunchKernelGGL(k_transpose_tiled, dim3(cdiv(Fin, 64), cdiv(Fout, 64)), dim3(256), 0, (hipStream_t)stream, W, Wt, Fout,
+                       Fin);
+    return check_launch("weight_pack(transpose)");
+  }
   hipLaunchKernelGGL(k_weight_pack, dim3(cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, W, Wt, W2, W3, Fout, Fin, K);
   return check_launch("weight_pack");
 }
