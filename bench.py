@@ -6,23 +6,32 @@
          bench.py --gpus N --steps K --warmup W
   python bench.py --mode infer            (BASELINE.json configs[1]: batch 64, J=17, eval forward + Tester epilogue)
 
+ARITHMETIC OF THE HEADLINE (round 5).  The reference computes in fp32.  `value` is measured with the fp32 contractions emulated
+EXACTLY on the matrix pipe - every operand as three bf16 slices = 24-bit significands, six slice products per fp32 product
+(`--arith bf16x3`, the default of this script; `dtype` says so).  The package's import-time default, `f16x2` (two scaled fp16
+slices = 22-bit operands, three products: tolerance-compliant - vertex L2 1.4e-5 vs float64 at this batch - but narrower than
+fp32), is the FAST MODE: measured in the same process at the same warm-up / step counts and reported under `arith_ab`, never as
+`value`.  `--arith f16x2|f32` or $P2M_GEMM_ARITH select another main arithmetic explicitly.
+
 Protocol: 20 warm-up + 50 timed steps by default; `value` / `ms_per_step` are wall-clock over the timed region,
 `ms_per_step_stats` the per-step median / p10 / p90 from one HIP event per step.  The default 1-GPU train run also reports, from
-the same process and after the timed region: `arith_ab` (the same step in the other two contraction arithmetics: bf16x3 = exact
-fp32 emulation, f32 = native MFMA), `also` (configs[1] inference and configs[4] MANO B=512 train; `--also none` to skip), and for
-N > 1 `multi_gpu` (ranks seen over the job's backend, per-rank per-bucket all-reduce timings and the hidden fraction).
+the same process and after the timed region: `arith_ab` (f16x2 at full protocol, native-f32 MFMA briefly), `also` (configs[1]
+inference and configs[4] MANO B=512 train, each in the main arithmetic and in the fast mode; `--also none` to skip), and for N > 1
+`multi_gpu` (ranks seen over the job's backend, per-rank per-bucket all-reduce timings and the hidden fraction).  `--gpus N` prints
+NO line unless N ranks, the nccl (RCCL) backend and N distinct GPUs are seen.
 
 One "step" (train mode) = one full reference train step (lib/core/base.py:122-148) on one synthetic batch that is
-already resident in HBM: FlatPose2Mesh forward (PoseNet + coarse-to-fine GCN), perm-reverse gather, joint regression,
-the five reference losses, backward, [gradient all-reduce], Adam.  Weak scaling: every rank owns `--batch` samples.
-Rank 0 prints ONE JSON line.
+already resident in HBM: FlatPose2Mesh forward (PoseNet + coarse-to-fine GCN, both on hand-written kernels), perm-reverse gather,
+joint regression, the five reference losses, backward, [gradient all-reduce], Adam.  Weak scaling: every rank owns `--batch`
+samples.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline         the dominant kernel (the dense plane contraction k_gemm_planes_ws): algorithmic fp32 FLOPs of its
-                   launches / their HIP-event time, against the MFMA peak of the pipe it runs on expressed in
-                   algorithmic FLOPs (bf16x3: 2500 / 6 = 416.7 TFLOP/s; P2M_GEMM_ARITH=f32: 157.3 TFLOP/s);
-                   `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                   (profiles/traffic_latest.json, FETCH_SIZE x 2 + WRITE_SIZE, see tools/rocprof_traffic.sh)
+  roofline         the contraction family with the largest time in the step (bf16x3: the basis-inside-the-contraction tile
+                   kernels): algorithmic fp32 FLOPs and algorithmic HBM bytes of its launches / their HIP-event time, against
+                   the matrix-pipe peak expressed in algorithmic FLOPs (bf16x3: 2500 / 6 = 416.7 TFLOP/s; f16x2: 2500 / 3;
+                   P2M_GEMM_ARITH=f32: 157.3 TFLOP/s) and 8 TB/s - `bound` names the binding one; `traffic` = HBM bytes per
+                   launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic_latest.json,
+                   FETCH_SIZE x 2 + WRITE_SIZE, tools/rocprof_traffic.sh); the other families follow as roofline_<family>
   roofline_sparse  the Chebyshev-basis kernels (HBM-bound): BYTES THE LAUNCHES MOVE (real-vertex rows only, un-pooled
                    inputs read at the coarse resolution) / HIP-event time, vs 8 TB/s.  SURVEY 8(d)'s all-V-rows figure
                    is kept as `speedup_equivalent` (it credits the fake-vertex split, which is an algorithmic saving,
@@ -676,8 +685,8 @@ def main():
                                           ("k_gemm_tn_ws",) if slices else ("k_gemm_tn<",), None,
                                           merged_serial("gemm_tn_mfma", "gemm_tn_mfma_bwd")),
                 "fused": family(merged("cheb_tile_gemm", "cheb_tile_gemm_bwd"),
-                                "k_cheb_mg_gemm / k_cheb_tile_gemm: Chebyshev planes formed per tile on chip, no T1/T2 in HBM "
-                                "on the way in", ("k_cheb_mg_gemm", "k_cheb_tile_gemm"), summ.get("cheb_tile_gemm"),
+                                "k_cheb_tile_gemm (VALU gather: bf16x3, N = 256) / k_cheb_mg_gemm (gather on the matrix cores: f16x2): "
+                                "Chebyshev planes formed per tile on chip, no T1/T2 in HBM on the way in", ("k_cheb_mg_gemm", "k_cheb_tile_gemm"), summ.get("cheb_tile_gemm"),
                                 merged_serial("cheb_tile_gemm", "cheb_tile_gemm_bwd")),
             }
             fams = {k: v for k, v in fams.items() if v is not None}
