@@ -192,3 +192,18 @@ def test_world_size_8_is_the_mean_of_the_shard_gradients(tmp_path):
         mean = flat.clone() if mean is None else mean + flat
     mean /= world
     assert (got[0]["flat"] - mean).abs().max() < 1e-6
+
+
+def test_bench_refuses_a_scaling_point_without_the_ranks():
+    """`bench.py --gpus N` must not print a JSON line unless N ranks are really there (RCCL, N distinct
+    GPUs: checked on the GPU box by tests/test_gpu_dist.py).  Without torchrun WORLD_SIZE is 1: no line, non-zero exit, and
+    the message says how to launch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    assert "WORLD_SIZE=1" in r.stderr and "torch.distributed.run" in r.stderr
