@@ -342,17 +342,17 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * BatchNorm + ReLU as in p2m_gemm_planes (excludes stats).  arith: P2M_ARITH_BF16X3 or P2M_ARITH_F16X2 (Bx split with
  * the same arith; x_amax = amax word bounding X and A0, the kernel adds the level's p2m_graph_plane_bits for the planes
  * it forms).  amax_out as in p2m_gemm_planes.
- * in_scale / in_shift [Ka] (optional; P2M_ARITH_F16X2 with N <= 128, no planes out): ACTIVATION ON LOAD - X and A0 hold the
+ * in_scale / in_shift [Ka] (optional; both slice arithmetics and both gather forms since round 5; no planes out): ACTIVATION ON LOAD - X and A0 hold the
  * raw output y of the previous conv and the operand is x = max(fma(y, in_scale[f], in_shift[f]), 0), its BatchNorm + ReLU
  * (lib/models/backbones/cheby_graph_conv.py:39, lib/models/meshnet.py:100) with the two roundings of p2m_bn_act_fwd, applied in
- * the producer waves between the global load and the LDS image: the activated tensor never exists in HBM.  x_amax must
- * then bound x (p2m_act_bound).                                                                                            */
+ * the producer waves between the global load and the LDS image: the activated tensor never exists in HBM.  With
+ * P2M_ARITH_F16X2 x_amax must then bound x (p2m_act_bound); P2M_ARITH_BF16X3 needs no bound.                               */
 int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
 /* 1 when a p2m_cheb_tile_gemm launch of this arithmetic and output width forms the planes with the gather ON THE MATRIX
  * CORES (the tile's operator as a dense pre-sliced block, TilePlan::ltx / ltx3): P2M_ARITH_F16X2 (two scaled fp16 slices,
  * 4 samples per unit) and - round 5 - P2M_ARITH_BF16X3 (three exact bf16 slices of operator and operand, 2 samples per
- * unit; P2M_MG_EXACT=0 switches it off), N <= 128.  The optional planes E1 / E2 then agree with p2m_cheb_basis_fwd_real to
- * fp32 round-off instead of bitwise, and activation on load is available.                                           */
+ * unit; OPT-IN, environment P2M_MG_EXACT=1 read once per process: it measured equal to the VALU gather), N <= 128.  The
+ * optional planes E1 / E2 then agree with p2m_cheb_basis_fwd_real to fp32 round-off instead of bitwise.              */
 int32_t p2m_cheb_tile_gemm_mg(int32_t arith, int32_t N);
 int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
                        int32_t arith, const void* x_amax, const float* bias, const float* addend, float* C, int32_t N,
