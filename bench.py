@@ -92,6 +92,7 @@ class TrainStep:
         self.stock_losses = stock_losses
         self.mesh_loss = p2m_loss.FusedMeshLoss(faces, perm_rev, synthetic_regressor(J, int(faces.max()) + 1),
                                                 w_normal=1e-1, w_edge=20.0 if edge_loss else 0.0, w_joint=1e-3)
+        self.lift_loss = p2m_loss.FusedCoordLoss(1e-3)              # base.py:128,139 (the lifted-pose term), one launch
         self.perm_rev = np.asarray(perm_rev)
         self.perm = torch.as_tensor(self.perm_rev[:self.nv], dtype=torch.long, device=device)
         self.Jreg = torch.from_numpy(synthetic_regressor(J, self.nv)).to(device)
@@ -113,7 +114,7 @@ class TrainStep:
         between zero_grad and the optimizer step."""
         pred_mesh, lift_pose = self.model(self.pose2d)
         mesh_total, _ = self.mesh_loss(pred_mesh, self.gt_mesh, self.gt_reg, self.one, self.one)
-        return mesh_total + 1e-3 * self.losses[4](lift_pose, self.gt_lift, self.one)
+        return mesh_total + self.lift_loss(lift_pose, self.gt_lift, self.one)
 
     def __call__(self):
         m = self.model
@@ -124,7 +125,7 @@ class TrainStep:
         if not self.stock_losses:
             # base.py:130-143 (gather, J-regression, vertex/normal/edge/joint losses) in one fused HIP call
             mesh_total, _ = self.mesh_loss(pred_mesh, self.gt_mesh, self.gt_reg, self.one, self.one)
-            lift = 1e-3 * self.losses[4](lift_pose, self.gt_lift, self.one)
+            lift = self.lift_loss(lift_pose, self.gt_lift, self.one)
             loss = mesh_total + lift
             if self.reducer is not None:
                 # the two branches share no parameters (pose2mesh_net.py:20 detaches the lifted pose): back-propagate

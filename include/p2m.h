@@ -242,11 +242,13 @@ int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamm
 /* pair_gx / pair_gy (optional, [M/2, F]; M even, F in {32,64,128,256}): by-products pair_gx[q] = gx[2q] + gx[2q+1] and
  * pair_gy[q] = gy[2q] + gy[2q+1] -- the pair-sums the backward of an un-pooled conv needs (residual gradient for the
  * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.
- * amax_out (optional): atomic max of |gy stored| into a zeroed amax word (the pair sums are bounded by twice it).    */
+ * amax_out (optional): atomic max of |gy stored| into a zeroed amax word (the pair sums are bounded by twice it).
+ * zero_holes (with classes): the pass walks EVERY row and stores zeros at the holes (and at pair sums of two holes) instead
+ * of leaving them untouched - for levels whose other kernels read all rows; no memset of the outputs is needed.        */
 int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                      const float* mean, const float* invstd, const float* gamma, const float* coef,
                      int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
-                     p2m_graph_t classes, void* amax_out, void* stream);
+                     p2m_graph_t classes, int32_t zero_holes, void* amax_out, void* stream);
 
 /* out[p, f] = in[2p, f] + in[2p+1, f]   (backward of the x2 nearest un-pool, meshnet.py:74) */
 int p2m_pair_sum(const float* in, float* out, int64_t Mout, int32_t F, p2m_graph_t classes /* of `in`'s level, or NULL */,
@@ -427,6 +429,12 @@ int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* perm, int32_
                   const int32_t* vj_ptr, const int32_t* vj_idx, const float* vj_val, int32_t J,
                   const float* gt_pose, const float* valid_pose, float w_vertex, float w_normal, float w_edge,
                   float w_joint, float* workspace, float* losses, float* grad_cam, int32_t B, void* stream);
+
+/* CoordLoss of a small tensor (lib/core/loss.py:10-23; the lifted-pose term of lib/core/base.py:128,139), value and gradient
+ * in one launch:  loss[0] = w * mean |pred * valid - target * valid|,  grad[i] = w * sign(..) * valid / n   (grad optional).
+ * valid (optional): one mask value per `per_mask` consecutive elements (per_mask = 3: the reference's [B, J, 1] masks).   */
+int p2m_coord_loss(const float* pred, const float* target, const float* valid, int32_t per_mask, int64_t n, float w,
+                   float* loss, float* grad, void* stream);
 
 /* ---- test-step / demo epilogue (lib/core/base.py:200-204, demo/run.py:169-171) -------------------------------
  * mesh[b, i] = scale * cam_mesh[b, perm[i]], i < nv  (tree order incl. fake vertices -> mesh-model vertex order;

@@ -82,9 +82,10 @@ HIP_SYMBOLS = {
     "p2m_bn_bwd_reduce": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     "p2m_bn_bwd_finalize": (_c.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "p2m_bn_bwd_apply": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp,
-                                    _vp, _vp]),
+                                    _i32, _vp, _vp]),
     "p2m_pair_sum": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "p2m_lerp_bwd_add": (_c.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "p2m_coord_loss": (_c.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp]),
     "p2m_mesh_loss_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "p2m_mesh_loss": (_c.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i32, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),

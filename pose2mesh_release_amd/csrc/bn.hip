@@ -21,6 +21,10 @@ namespace p2m {
 // Stage 2 (k_bn_finalize): one thread per column adds the FIN_SPLITS partials in a fixed order and writes the
 // coefficients.  Deterministic (no atomics).  The single-stage form read 4-byte words at a 2N*4-byte stride from
 // N/8 blocks only: ~35 us per call for the fine levels, 40 calls per step.
+// (Round 5 built both stages as ONE launch - the stage-1 block that draws the last ticket of its column group runs stage 2:
+//  __threadfence / device-scope atomic / __threadfence.  Parity-green, 40 launches fewer, and 1.4-1.7 ms per step SLOWER
+//  (44.1 vs 45.7 ms, same box): at agent scope a fence is buffer_wbl2 sc1 + buffer_inv sc1, which writes back and drops the
+//  XCD's L2 - under the side-stream contraction whose working set lives there.  Two launches it stays.)
 constexpr int FIN_COLS = 32;    // columns per stage-1 block
 constexpr int FIN_RG = 8;       // tile-row groups per stage-1 block
 constexpr int FIN_SPLITS = 48;  // slices of the tile range: the minimum ...
@@ -158,10 +162,10 @@ __global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 // j = b * n + i  ->  actual row b * V + ids[i] -- so every lane always has a row to move (predicating the holes away
 // instead left a third of the loads in flight empty: 4.3 instead of 5+ TB/s).  ids == nullptr: identity.
 struct RowMap {
-  const float* w;      // per-vertex weight (1 real vertex, class size for a representative); with ids only
+  const float* w;      // per-vertex weight (1 real vertex, class size for a representative, 0 hole)
   const int* ids;      // [n] live vertices of the level, ascending
-  unsigned n, V;
-};
+  unsigned n, V;       // ids == nullptr && w != nullptr (the apply pass with zero_holes): EVERY row is walked, vertex = row % V,
+};                     // a hole is not loaded and gets zeros stored - the caller needs no memset of its outputs
 struct RowPos { unsigned b, i; };
 __device__ __forceinline__ RowPos row_pos(long j, const RowMap& m) {
   RowPos p;
@@ -565,13 +569,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_generic(const float* __res
     const unsigned vtx = (unsigned)m.ids[pj.i];
     wr = m.w[vtx];
     idx = ((long)pj.b * m.V + vtx) * F + f;
+  } else if (m.w != nullptr) {                               // zero_holes: every row, a hole gets 0 (RowMap)
+    wr = m.w[(unsigned)((idx / F) % (long)m.V)];
   }
-  const float v = y[idx];
-  float go = gx[idx];
+  const float v = wr != 0.f ? y[idx] : 0.f;
+  float go = wr != 0.f ? gx[idx] : 0.f;
   if (relu && fmaf(v, scale[f], shift[f]) <= 0.f) go = 0.f;
   const float k = gamma[f] * invstd[f];
   const float c0 = coef ? coef[f] : 0.f, c1 = coef ? coef[F + f] : 0.f;
-  const float o = fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0));
+  const float o = wr != 0.f ? fmaf(k, go, wr * fmaf(-k * c1 * invstd[f], v - mean[f], -k * c0)) : 0.f;
   if (live) gy[idx] = o;
   if (amax != nullptr) amax_commit(amax, live ? amax_abs(o) : 0.f);
 }
@@ -660,6 +666,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   long r1 = r0 + APPLY_ROWS_PER_BLOCK;
   if (r1 > M) r1 = M;
   const bool mapped = m.ids != nullptr;                     // M, r0, r1 count LOGICAL rows (the live ones) then
+  const bool dense_w = !mapped && m.w != nullptr;           // every row, holes zeroed (RowMap)
+  const bool weighted = mapped || dense_w;
   RowPos pb = {0u, 0u};
   if (mapped && r0 + rloc < r1) pb = row_pos(r0 + rloc, m);
   for (long rb = r0 + rloc; rb < r1; rb += 4 * RP) {        // 4 rows per pass: 8 loads in flight per thread
@@ -675,8 +683,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         const unsigned vtx = (unsigned)m.ids[pu.i];
         wq[u] = m.w[vtx];
         r = (long)pu.b * m.V + vtx;
+      } else if (dense_w) {
+        wq[u] = m.w[(unsigned)(r % (long)m.V)];
       }
       row[u] = r;
+      // (dense_w: a hole's row is loaded like any other - the memory is there, whatever it holds is dropped by the select
+      //  below - so the eight loads of a pass stay unconditional)
       *reinterpret_cast<float4*>(g[u]) = *reinterpret_cast<const float4*>(gx + r * F + f);
       *reinterpret_cast<float4*>(v[u]) = *reinterpret_cast<const float4*>(y + r * F + f);
     }
@@ -691,8 +703,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       for (int i = 0; i < 4; i++) {
         float go = g[u][i];
         if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-        o[i] = mapped ? fmaf(k[i], go, wr * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
-                      : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+        o[i] = weighted ? fmaf(k[i], go, wr * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                        : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+        if (wr == 0.f) o[i] = 0.f;                          // a hole (dense_w walk only): zeros, whatever a0 is
       }
       *reinterpret_cast<float4*>(gy + row[u] * F + f) = *reinterpret_cast<float4*>(o);
       vmax = amax4(vmax, o);
@@ -736,6 +749,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
   // with classes, m maps LOGICAL pairs (Mp of them: the coarse vertices with a live child, m.ids over m.V = V/2) to
   // actual pairs; m.w is the FINE level's weight table (children 2c, 2c+1): a hole child is neither loaded nor stored
   const bool mapped = m.ids != nullptr;
+  const bool dense_w = !mapped && m.w != nullptr;           // every pair, holes and hole parents zeroed (RowMap; m.V = V/2)
+  const bool weighted = mapped || dense_w;
   RowPos pp = {0u, 0u};
   if (mapped && p0 + rloc < p1) pp = row_pos(p0 + rloc, m);
   for (long pb = p0 + rloc; pb < p1; pb += 2 * RP) {        // 2 pairs = 4 rows per pass: 8 loads in flight per thread
@@ -751,6 +766,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
         const unsigned c = (unsigned)m.ids[pu.i];
         wq[u] = m.w[2 * c + (u & 1)];
         q = (long)pu.b * m.V + c;
+      } else if (dense_w) {
+        wq[u] = m.w[2u * (unsigned)(q % (long)m.V) + (u & 1)];
       }
       pair[u >> 1] = q;
       const long r = 2 * q + (u & 1);
@@ -775,17 +792,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_pairs(const float* __restr
         for (int i = 0; i < 4; i++) {
           float go = g[u][i];
           if (relu && fmaf(v[u][i], sc[i], sh[i]) <= 0.f) go = 0.f;
-          o[c][i] = mapped ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
-                           : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
+          o[c][i] = weighted ? fmaf(k[i], go, wr[c] * fmaf(a1[i], v[u][i] - mu[i], a0[i]))
+                             : fmaf(k[i], go, fmaf(a1[i], v[u][i] - mu[i], a0[i]));
           if (wr[c] == 0.f) o[c][i] = 0.f;                // a hole: no data (its g / v registers were zeroed above)
         }
-        if (wr[c] != 0.f) {
+        if (wr[c] != 0.f || dense_w) {
           *reinterpret_cast<float4*>(gy + (2 * q + c) * F + f) = *reinterpret_cast<float4*>(o[c]);
           vmax = amax4(vmax, o[c]);
         }
       }
       // the pair-sums leave the holes out; a pair of two holes (a hole parent) is not written at all
-      if (wr[0] != 0.f || wr[1] != 0.f) {
+      if (wr[0] != 0.f || wr[1] != 0.f || dense_w) {
         if (pair_gx) {
           float sx[4];
 #pragma unroll
@@ -1121,17 +1138,25 @@ extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, f
 extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* gamma, const float* coef,
                                 int32_t relu, float* gy, float* pair_gx, float* pair_gy, int64_t M, int32_t F,
-                                p2m_graph_t classes, void* amax_out, void* stream) {
+                                p2m_graph_t classes, int32_t zero_holes, void* amax_out, void* stream) {
   P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && gamma && gy && M > 0, "null pointer or empty shape");
   unsigned* amax = static_cast<unsigned*>(amax_out);
   RowMap m;
   long Mlog;
   hipStream_t s = (hipStream_t)stream;
+  // zero_holes: walk every row instead of the live ones (RowMap: ids = nullptr, w kept)
+  auto dense = [&](bool pairs, long* Ml) {
+    if (!zero_holes || m.ids == nullptr) return;
+    m.ids = nullptr;
+    m.n = m.V;
+    *Ml = pairs ? M / 2 : M;
+  };
   if (pair_gx || pair_gy) {
     P2M_CHECK_ARG(M % 2 == 0 && (F == 32 || F == 64 || F == 128 || F == 256),
                   "pair-sum by-products need an even row count and F in {32, 64, 128, 256}");
     long Mp;
     P2M_CHECK_ARG(row_map_of(classes, M, true, &m, &Mp), "M is not a multiple of the level's (even) vertex count");
+    dense(true, &Mp);
     const int gridp = cdiv(Mp, APPLY_ROWS_PER_BLOCK / 2);
     switch (F) {
       case 32:  hipLaunchKernelGGL(k_bn_bwd_apply_pairs<8>,  dim3(gridp), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, pair_gx, pair_gy, Mp, m, amax); break;
@@ -1142,6 +1167,7 @@ extern "C" int p2m_bn_bwd_apply(const float* gx, const float* y, const float* sc
     return check_launch("bn_bwd_apply(pairs)");
   }
   P2M_CHECK_ARG(row_map_of(classes, M, false, &m, &Mlog), "M is not a multiple of the level's vertex count (or too large)");
+  dense(false, &Mlog);
   const int grid = cdiv(Mlog, APPLY_ROWS_PER_BLOCK);
   switch (F) {
     case 32:  hipLaunchKernelGGL(k_bn_bwd_apply<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, gamma, coef, relu, gy, Mlog, m, amax); break;

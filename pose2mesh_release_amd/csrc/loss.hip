@@ -211,6 +211,31 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
   if (threadIdx.x == 0) losses[which] = (float)((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 
+// ---- CoordLoss on a small tensor (lib/core/loss.py:10-23; the lifted-pose term of lib/core/base.py:128,139) -------
+//   loss = w * mean | pred * valid - target * valid |,   grad = w * sign(pred * valid - target * valid) * valid / n
+// One block: a [B, J, 3] pose is a few thousand numbers; fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void k_coord_loss(const float* __restrict__ pred, const float* __restrict__ target,
+                                                     const float* __restrict__ valid, int per_mask, long n, float w,
+                                                     float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ double wsum[16];
+  double s = 0.0;
+  const float gscale = w / (float)n;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float v = valid ? valid[i / per_mask] : 1.f;
+    const float d = pred[i] * v - target[i] * v;                // loss.py:19-20: both sides masked, then the difference
+    s += (double)fabsf(d);
+    if (grad) grad[i] = d > 0.f ? gscale * v : d < 0.f ? -gscale * v : 0.f;     // torch's abs backward: sign(d), 0 at 0
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; k++) t += wsum[k];
+    loss[0] = (float)(t / (double)n) * w;
+  }
+}
+
 // ---- test-step / demo epilogue (lib/core/base.py:200-204, demo/run.py:169-171) ---------------------------------
 //   mesh[b, i] = scale * cam_mesh[b, perm[i]]          (tree order incl. fake vertices -> mesh-model vertex order)
 //   joints[b, j] = sum_k jr_val[k] * mesh[b, jr_idx[k]]  (CSR row j of the joint regressor)
@@ -310,4 +335,12 @@ extern "C" int p2m_mesh_loss(const float* cam_mesh, int32_t V0, const int32_t* p
   hipLaunchKernelGGL(k_vertex_grad, dim3(nb_vert), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_loss_finalize, dim3(4), dim3(256), 0, s, a.partial, a.npart, nb_vert, nb_face, nb_face, nb_pose, losses);
   return check_launch("mesh_loss");
+}
+
+extern "C" int p2m_coord_loss(const float* pred, const float* target, const float* valid, int32_t per_mask, int64_t n,
+                              float w, float* loss, float* grad, void* stream) {
+  P2M_CHECK_ARG(pred && target && loss && n > 0 && per_mask > 0, "null pointer or empty shape");
+  hipLaunchKernelGGL(k_coord_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, valid, per_mask, (long)n, w,
+                     loss, grad);
+  return check_launch("coord_loss");
 }

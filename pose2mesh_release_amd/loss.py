@@ -131,6 +131,54 @@ class _MeshLossFn(torch.autograd.Function):
         return ctx.grad * g_total, None, None, None, None, None
 
 
+class _CoordLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, valid, w):
+        if not pred.is_cuda:
+            raise _libmod.P2MError("FusedCoordLoss (HIP) needs GPU tensors; use CoordLoss for the stock torch module")
+        p_, t_ = pred.contiguous().float(), target.contiguous().float()
+        if p_.shape != t_.shape:
+            raise ValueError(f"pred {tuple(p_.shape)} and target {tuple(t_.shape)} differ")
+        n = p_.numel()
+        v, per = None, 1
+        if valid is not None:
+            B = p_.shape[0]
+            if valid.numel() == B:                                     # [B], [B,1], [B,1,1]: one value per sample
+                v, per = valid.reshape(B).contiguous().float(), n // B
+            elif p_.dim() == 3 and tuple(valid.shape) == (B, p_.shape[1], 1):      # the reference's [B, J, 1] masks
+                v, per = valid.reshape(B * p_.shape[1]).contiguous().float(), p_.shape[2]
+            else:
+                v = valid.expand_as(p_).contiguous().float().reshape(-1)
+        grad = torch.empty_like(p_) if ctx.needs_input_grad[0] else None
+        loss = torch.empty(1, device=p_.device, dtype=torch.float32)
+
+        def p(x):
+            return None if x is None else _ct.c_void_p(x.data_ptr())
+        with torch.cuda.device(p_.device):
+            _libmod.check(_libmod.hip().p2m_coord_loss(p(p_), p(t_), p(v), per, n, float(w), p(loss), p(grad),
+                                                       _ct.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                          "p2m_coord_loss")
+        ctx.grad, ctx.shape = grad, pred.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g).view(ctx.shape), None, None, None
+
+
+class FusedCoordLoss(nn.Module):
+    """weight * CoordLoss(has_valid=True)(pred, target, valid) (lib/core/loss.py:10-23; base.py:128,139 weights the lifted-pose
+    term by cfg.TRAIN.joint_loss_weight) - value and gradient from ONE launch (p2m_coord_loss) instead of a dozen
+    elementwise torch kernels in forward + autograd.  valid: None, per sample ([B], [B,1,1]) or the reference's [B, J, 1]."""
+
+    def __init__(self, weight=1.0):
+        super().__init__()
+        self.weight = float(weight)
+
+    def forward(self, pred, target, target_valid=None):
+        return _CoordLossFn.apply(pred, target, target_valid, self.weight)
+
+
 def _regressor_tables(jr, nv):
     """CSR (by joint) and CSC (by vertex) of a dense [J, nv] joint regressor."""
     import scipy.sparse as sp

@@ -1108,14 +1108,13 @@ def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None,
                                 int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
-    alloc = torch.zeros if (zero_holes and cls is not None) else torch.empty
-    gy = alloc((M, F), device=y.device, dtype=torch.float32)
+    gy = torch.empty((M, F), device=y.device, dtype=torch.float32)      # (zero_holes: the pass itself stores the zeros)
     word = new_amax(y.device) if f16x2() else None
-    pgx = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
-    pgy = alloc((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
+    pgx = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_in else None
+    pgy = torch.empty((M // 2, F), device=y.device, dtype=torch.float32) if pair_out else None
     check(lib.p2m_bn_bwd_apply(_p(gx), _p(y), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]), _p(_req(gamma, "bn.weight")),
                                _p(coef) if training else None, int(relu), _p(gy), _p(pgx), _p(pgy), M, F, cls,
-                               _p(word), _stream()), "p2m_bn_bwd_apply")
+                               int(bool(zero_holes and cls is not None)), _p(word), _stream()), "p2m_bn_bwd_apply")
     if word is not None:
         tag_amax(gy, word)
     if pair_in or pair_out:

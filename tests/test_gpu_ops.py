@@ -598,6 +598,51 @@ def test_classes_of_identical_fake_rows(ops):
                        pgy.view(B, V // 2, F)[:, live_c])
 
 
+@pytest.mark.parametrize("N,ntiles", [(32, 40), (64, 3000), (128, 23552), (256, 6000), (3, 700), (200, 5000)])
+def test_statistics_finalize_is_exact_and_repeatable(hip_libs, N, ntiles):
+    """The two-stage statistics finalize (csrc/bn.hip: stage 1 writes double partials to a per-stream scratch, stage 2 sums them
+    in a fixed order), forward and backward form, for every split count (48 / 96 / 192) and odd widths: the values match
+    float64, and 60 repetitions with 256 MB of unrelated traffic in between are bitwise the first one (written for the
+    single-launch form of round 5 - last-ticket block runs stage 2 - which passed it and was 1.5 ms per step slower)."""
+    from pose2mesh_release_amd import _lib, ops
+    gen = torch.Generator().manual_seed(N * 7 + ntiles)
+    tr = ops.stats_tile_rows()
+    M = ntiles * tr - 5
+    st = torch.randn(ntiles, 2, N, generator=gen)
+    st[:, 1] = st[:, 1].abs() * tr
+    st[:, 0] *= tr ** 0.5
+    gamma, beta = torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    cnt = torch.full((ntiles,), float(tr), dtype=torch.float64)
+    cnt[-1] = tr - 5
+    sd = st.double()
+    mean = sd[:, 0].sum(0) / M
+    var = ((sd[:, 1] + sd[:, 0] ** 2 / cnt[:, None]).sum(0) / M - mean ** 2).clamp_min(0)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    stc, gc, bc = st.cuda(), gamma.cuda(), beta.cuda()
+    junk = torch.empty(64 << 20, device="cuda")
+    # backward form: nblk partial rows [nblk, 2, N] -> dbeta, dgamma, coef
+    nblk = max(1, ntiles // 2)
+    part = torch.randn(nblk, 2, N, generator=gen).cuda()
+    pd = part.double().cpu()
+    first = first_b = None
+    for rep in range(60):
+        co = ops.bn_finalize(stc, M, gc, bc, None, None, 0.1, 1e-5)
+        dg, db, coef = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(2, N, device="cuda")
+        _lib.check(_lib.hip().p2m_bn_bwd_finalize(part.data_ptr(), nblk, M, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, N,
+                                                  None), "p2m_bn_bwd_finalize")
+        junk.fill_(float(rep))
+        if first is None:
+            first, first_b = co.clone(), (dg.clone(), db.clone(), coef.clone())
+            assert (co[0].double().cpu() - mean).abs().max() <= 1e-6 * max(1.0, float(mean.abs().max()))
+            assert ((co[1].double().cpu() - invstd) / invstd).abs().max() <= 1e-5
+            assert (db.double().cpu() - pd[:, 0].sum(0)).abs().max() <= 1e-6 * max(1.0, float(pd[:, 0].sum(0).abs().max()))
+            assert (dg.double().cpu() - pd[:, 1].sum(0)).abs().max() <= 1e-6 * max(1.0, float(pd[:, 1].sum(0).abs().max()))
+            assert (coef[0].double().cpu() - pd[:, 0].sum(0) / M).abs().max() <= 1e-6
+        else:
+            assert torch.equal(co, first), rep
+            assert all(torch.equal(a, b) for a, b in zip((dg, db, coef), first_b)), rep
+
+
 def _real_ids(L):
     """Vertices whose row is not the lone diagonal (the complement of the isolated padding vertices)."""
     L = L.tocsr()

@@ -116,6 +116,35 @@ def test_fused_mesh_loss_matches_stock_losses(hip_libs):
     assert float(cam2.grad[:, torch.as_tensor(fake, device="cuda")].abs().max()) == 0.0
 
 
+def test_fused_coord_loss_matches_the_stock_module(hip_libs):
+    """p2m_coord_loss (the lifted-pose term, lib/core/loss.py:10-23 weighted as lib/core/base.py:139; value + gradient in one
+    launch) against weight * CoordLoss for the mask shapes the reference uses, incl. exact zeros of the difference."""
+    from pose2mesh_release_amd import loss as L
+    B, J = 12, 17
+    g = torch.Generator().manual_seed(5)
+    pred0 = (torch.randn(B, J, 3, generator=g) * 300)
+    tgt = (torch.randn(B, J, 3, generator=g) * 300)
+    tgt[0, 0] = pred0[0, 0]                                        # d == 0: sign(0) = 0 on both sides
+    masks = {"none": None, "sample": (torch.rand(B, 1, 1, generator=g) > 0.3).float(),
+             "joint": (torch.rand(B, J, 1, generator=g) > 0.3).float(), "flat": (torch.rand(B, generator=g) > 0.3).float()}
+    fused = L.FusedCoordLoss(1e-3)
+    for name, m in masks.items():
+        a = pred0.clone().cuda().requires_grad_(True)
+        b = pred0.clone().cuda().requires_grad_(True)
+        mm = None if m is None else m.cuda()
+        mref = None if m is None else (mm.view(B, 1, 1) if mm.dim() == 1 else mm)
+        ref = 1e-3 * (L.CoordLoss(has_valid=True)(a, tgt.cuda(), mref) if m is not None else L.CoordLoss()(a, tgt.cuda()))
+        (ref * 3.0).backward()
+        out = fused(b, tgt.cuda(), mm)
+        assert out.dim() == 0
+        (out * 3.0).backward()
+        assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref)), name
+        assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(a.grad.abs().max()), name
+        assert float(b.grad[0, 0].abs().max()) == 0.0 and float(a.grad[0, 0].abs().max()) == 0.0, name
+    with pytest.raises(Exception):
+        fused(pred0, tgt)                                          # CPU tensors: no silent fallback
+
+
 def test_in_place_gradient_accumulation_is_bitwise_the_autograd_path(hip_libs):
     """Pose2Mesh.accumulate_grads_in_place: weight / bias / BatchNorm gradients written straight into the flat gradient
     buffer by the unpack / finalize kernels == the tensors autograd would have added, and they ADD to what is there."""
