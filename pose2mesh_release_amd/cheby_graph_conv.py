@@ -56,7 +56,8 @@ class _ChebConvFn(torch.autograd.Function):
             raise P2MError(f"x has {V} vertices but the graph has {g.V}")
         M = B * V
         with torch.cuda.device(x.device):
-            ops.amax_begin_step(x.device)      # fresh amax words per call (a captured graph must re-zero its own)
+            # (amax words, f16x2 mode: drawn from the device's current chunk - ops.new_amax renews it when it runs out or when
+            #  the capture state flips; a network built from this op does not pay a chunk per layer call)
             xc = x.contiguous().float().view(M, Fin)
             T1, T2 = ops.cheb_basis_fwd(g, xc, B, Fin, 0)
             Wt, W2, _ = ops.weight_pack(weight.contiguous(), Fin, 3, need_w2=True)

@@ -410,8 +410,8 @@ def f16x2():
 
 
 def amax_begin_step(device):
-    """Renew the device's chunk of amax words: called at the start of every forward that hands words out (the network's
-    AND the stand-alone ChebConv's)."""
+    """Renew the device's chunk of amax words: called at the start of every network forward that hands words out (a step
+    then draws from one chunk; the stand-alone ChebConv op just draws from whatever chunk is current)."""
     _amax_chunks.pop(torch.device(device).index, None)
     if _deferred_destroy:
         drain_deferred_destroys()
