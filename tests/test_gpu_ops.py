@@ -593,6 +593,16 @@ def test_classes_of_identical_fake_rows(ops):
         < 1e-4 * max(1.0, ref_cls.abs().max().item())
     assert (pgx.view(B, V // 2, F)[:, live_c].double() - coarse_class_sums(gx_full)).abs().max() < 1e-5
     assert float(pgy.view(B, V // 2, F)[:, ~live_c].abs().max()) == 0.0          # hole parents: untouched zeros
+    # the same pass without the by-products (k_bn_bwd_apply's every-row walk) and at a width outside {32, 64, 128, 256} (the
+    # generic kernel): live rows as above, zeros stored at the holes - nothing pre-zeroes the outputs (round 5)
+    gy1, _, _ = ops.bn_relu_bwd(gx_cls, y_hole.view(M, F), co, gamma, True, True, M, F, classes=g, zero_holes=True)
+    assert torch.equal(gy1, gy)
+    Fg = F - 8
+    cog = co[:, :Fg].contiguous()
+    gyg, _, _ = ops.bn_relu_bwd(gx_cls[:, :Fg].contiguous(), y_hole.view(M, F)[:, :Fg].contiguous(), cog, gamma[:Fg].contiguous(),
+                                True, True, M, Fg, classes=g, zero_holes=True)
+    assert torch.isfinite(gyg).all() and float(gyg.view(B, V, Fg)[:, hole].abs().max()) == 0.0
+    assert (gyg - gy[:, :Fg]).abs().max() <= 2e-6 * max(1.0, float(gy.abs().max()))
     gy.view(B, V, F)[:, hole] = float("nan")
     assert torch.equal(ops.pair_sum(gy, M // 2, F, classes=g).view(B, V // 2, F)[:, live_c],
                        pgy.view(B, V // 2, F)[:, live_c])
