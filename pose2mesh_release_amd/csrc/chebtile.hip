@@ -283,6 +283,17 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 }
 
+#ifdef P2M_TILE_TRACE
+// Probe build only (tools/tile_trace.sh, tools/probes/tile_trace_probe.py): s_memtime stamps of one producer wave and one MFMA
+// wave of one block at the phase boundaries of every unit.  [role][unit][event]
+__device__ unsigned long long g_tile_trc[2][40][8];
+#define P2M_TRC(role, w, ev)                                                                          \
+  do {                                                                                                \
+    if (trc_on && (w) < 40) g_tile_trc[role][w][ev] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
+#else
+#define P2M_TRC(role, w, ev) do { } while (0)
+#endif
 // TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
 // the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
 template <int TM, int TN, int NPW, int MODE, int NS>
@@ -355,6 +366,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   __syncthreads();
 
   const bool producer = t >= 256;             // wave-uniform
+#ifdef P2M_TILE_TRACE
+  const bool trc_on = lid == P2M_TILE_TRACE && (t == 0 || t == 256);
+#endif
   float x_sc = 1.f;                           // two-fp16-slice mode: the planes are staged times 2^sx
   int descale = 0;
   if (NS == 2) {
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     lds_block_barrier();                                // B1(-1): xs(0) visible
     int grp = grp0, fc = 0;
     for (int w = 0; w < nunits; w++) {
+      P2M_TRC(0, w, 0);
       u32x2 sp[NRP][3][NS];                             // [row][plane][slice]: the A operand of this unit, held until the
                                                         // MFMA waves release the image
       if (in_act) {                                     // plane 0 of unit w = (grp, fc)
@@ -455,6 +470,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         const int i = ri[ps];
         const int e = rowoff[i + 1];
         int j = rowoff[i];
+        // (round 5, measured with the stamps above: this phase is ~6 000 of a unit's ~12 200 cycles and the MFMA waves wait
+        //  ~3 500 for it - it sits at the rate of its ds_read_b128s, not at latency or VALU issue: two rows of a lane
+        //  interleaved (two independent chains) gathered 7 % faster and made the kernel 2.5 % slower; a third fewer fmafs
+        //  changed nothing.  profiles/r05_tile_phase_trace.txt)
         f32x4 en[4];                                    // the block of 4 entries being used; the next one is fetched under
 #pragma unroll                                          // its FMAs (reading past the row's end is harmless: the table is
         for (int k = 0; k < 4; k++) en[k] = ents[j + k];   // contiguous and has 4 entries of slack)
@@ -488,8 +507,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         split_pack4<NS>(t1[0], t1[1], t1[2], t1[3], x_sc, sp[ps][1]);
         split_pack4<NS>(t2[0], t2[1], t2[2], t2[3], x_sc, sp[ps][2]);
       }
+      P2M_TRC(0, w, 1);
       lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
                                                         //        every producer is done reading xs(w)
+      P2M_TRC(0, w, 2);
 #pragma unroll
       for (int ps = 0; ps < NRP; ps++) {
         unsigned short* d = As + (s * 32 + ri[ps]) * CT_LDA + s * CT_SPAD + q * 4;
@@ -498,16 +519,20 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 #pragma unroll
           for (int sl = 0; sl < NS; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[ps][p][sl];
       }
+      P2M_TRC(0, w, 3);
       lds_block_barrier();                              // B1(w): image of unit w visible - the MFMA waves go; everything
                                                         //        below runs under their MFMAs, not in front of them
+      P2M_TRC(0, w, 4);
       if (w + 1 < nunits) {
         store_xs();                                     // xs(w + 1) from the registers loaded a unit ago
         load_p0();
         if (w + 2 < nunits) load_union();
       }
       if (++fc == nchunks) { fc = 0; grp++; }
+      P2M_TRC(0, w, 5);
       lds_block_barrier();                              // B3(w): xs(w + 1) visible to every producer (the MFMA waves pass
                                                         //        it between two of their k-steps)
+      P2M_TRC(0, w, 6);
     }
   } else {
     // ------------------------------------------------------------------------------------------------------------
@@ -548,8 +573,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     int grp = grp0, fc = 0;
     for (int w = 0; w < nunits; w++) {
       const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
+      P2M_TRC(1, w, 0);
       lds_block_barrier();                              // B2(w)
+      P2M_TRC(1, w, 1);
       lds_block_barrier();                              // B1(w): image of unit w is in LDS
+      P2M_TRC(1, w, 2);
       frag_t fl[TM];                                    // the low-slice A fragments: what the first MFMAs of a step read
       read_a(NS - 1, 0, fl);
 #pragma unroll
@@ -585,10 +613,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         if (st == 1) lds_block_barrier();               // B3(w): the producers' xs stores for unit w + 1 (not ours to wait
                                                         //        for, but s_barrier is block-wide)
       }
+      P2M_TRC(1, w, 3);
       if (fc == nchunks - 1) {
         tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
         grp++;
       }
+      P2M_TRC(1, w, 4);
       fc = fcn;
     }
   }
@@ -1187,3 +1217,11 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   if (N == 256) return launch_tile_gemm<4, 2, 4>(a, s);
   return N == 128 ? launch_tile_gemm<4, 1, 8>(a, s) : launch_tile_gemm<2, 1, 8>(a, s);
 }
+
+#ifdef P2M_TILE_TRACE
+extern "C" int p2m_tile_trace_dump(unsigned long long* out /* [2][40][8] host */) {
+  if (hipDeviceSynchronize() != hipSuccess) return P2M_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2m::g_tile_trc), sizeof(unsigned long long) * 2 * 40 * 8) == hipSuccess ? P2M_OK
+                                                                                                                   : P2M_ERR_HIP;
+}
+#endif
