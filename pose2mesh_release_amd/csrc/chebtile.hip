@@ -178,7 +178,9 @@ __device__ __forceinline__ void tile_epilogue_full(const TileGemmArgs& g, const 
 // Epilogue of one sample group in the MFMA waves: bias (+ activation / addend), store, BatchNorm partials; then a fresh
 // accumulator.  MODE is compiled in (see above).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) +
 // 8 (reg >> 2) + 4 (lane >> 5).
-template <int TM, int TN, int MODE, int SG = CT_S>
+// STORE = false (round 5, the LDS-staged epilogue of k_cheb_tile_gemm): values and BatchNorm partials only - the accumulator
+// keeps the finished values, nothing is stored or zeroed here (the block stages them in LDS and every wave copies rows out).
+template <int TM, int TN, int MODE, int SG = CT_S, bool STORE = true>
 __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TilePlan& pl, floatx16 (&acc)[TM][TN],
                                               const int* rowvid, int grp, int tile, int R, int wm, int wn, int l31,
                                               int lhi, int descale) {
@@ -224,7 +226,7 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    if (voff[r] >= 0) {
+    if (STORE && voff[r] >= 0) {
       if (MODE == CT_ADDEND) {
         float ad[TM][TN];
 #pragma unroll
@@ -248,7 +250,7 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
       }
     }
   }
-  if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
+  if (STORE && g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
   if (MODE == CT_STATS) {
     // column sums over the tile's rows of each sample: the other 16 rows sit in lane ^ 32
 #pragma unroll
@@ -275,12 +277,13 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
         }
       }
   }
+  if (STORE)
 #pragma unroll
-  for (int i = 0; i < TM; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-    for (int j = 0; j < TN; j++)
+      for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 }
 
 #ifdef P2M_TILE_TRACE
@@ -306,6 +309,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   constexpr int RPP = 2 * NPW;                // tile rows the producers gather per pass (2 per wave)
   constexpr int NRP = 32 / RPP;               // gather passes = rows per producer lane
   constexpr int NPU = (TILE_UCAP + RPP - 1) / RPP;      // union-row loads per producer lane
+  // LDS-staged epilogue (round 5; three-bf16-slice launches with N <= 128): the in-kernel stamps put the epilogue - 64 (+ 64
+  // addend) 4-byte accesses per lane in the four MFMA waves, everything else waiting - at 15 % (forward) / 26 % (addend, planes
+  // out) of the kernel.  Here the MFMA waves drop the finished values of a sample group into the A image's LDS (free between
+  // B2 and the next image store) and ALL waves of the block copy whole rows out with 16-byte accesses (6 per lane; the addend
+  // comes in with 16-byte loads).  Same values, same BatchNorm partials (they come from the registers, as before).
+  constexpr int NCOL = WN * TN * 32;                    // columns of the block's output tile (= N)
+  constexpr bool LEPI = TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(ct_smem);
   unsigned char* xs = ct_smem + CT_AS_BYTES;
@@ -376,6 +386,38 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     x_sc = exp2_int(sx);
     descale = -(sx + slice_scale_exp(*g.b_amax, 0));
   }
+
+  // copy-out of the staged tile of sample group egrp by every thread of the block (LEPI): piece p = (sample, row, 16-byte column
+  // group); a row of C is N * 4 contiguous bytes at (sample, vertex id of the tile row)
+  auto copy_out = [&](int egrp) {
+    constexpr int C4 = NCOL / 4, NPIECE = CT_S * 32 * C4, NIT = (NPIECE + NT - 1) / NT;
+    const float* stg = reinterpret_cast<const float*>(ct_smem);
+    f32x4 v[NIT], ad[NIT];
+    long off[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int p = t + k * NT;
+      const int c4 = p % C4, row = (p / C4) % 32, i = p / (C4 * 32);
+      const int vid = p < NPIECE ? rowvid[row] : -1;
+      const int b = egrp * CT_S + i;
+      off[k] = (vid >= 0 && b < g.B) ? ((long)b * g.c_rows + vid) * g.N + c4 * 4 : -1;
+      if (off[k] >= 0) {
+        v[k] = *reinterpret_cast<const f32x4*>(stg + (i * 32 + row) * NCOL + c4 * 4);
+        if (MODE == CT_ADDEND) ad[k] = *reinterpret_cast<const f32x4*>(g.addend + off[k]);
+      }
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      if (off[k] >= 0) {
+        if (MODE == CT_ADDEND) v[k] += ad[k];
+        *reinterpret_cast<f32x4*>(g.C + off[k]) = v[k];
+#pragma unroll
+        for (int c = 0; c < 4; c++) vmax = fmaxf(vmax, amax_abs(v[k][c]));
+      }
+    }
+    if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
+  };
 
   if (producer) {
     // ------------------------------------------------------------------------------------------------------------
@@ -511,6 +553,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
                                                         //        every producer is done reading xs(w)
       P2M_TRC(0, w, 2);
+      if (LEPI && w > 0 && fc == 0) {                   // the unit before closed a sample group: its tile is being staged
+        lds_block_barrier();                            // E1: staged
+        copy_out(grp - 1);
+        lds_block_barrier();                            // E2: every wave has read its pieces - the image may overwrite them
+      }
 #pragma unroll
       for (int ps = 0; ps < NRP; ps++) {
         unsigned short* d = As + (s * 32 + ri[ps]) * CT_LDA + s * CT_SPAD + q * 4;
@@ -533,6 +580,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       lds_block_barrier();                              // B3(w): xs(w + 1) visible to every producer (the MFMA waves pass
                                                         //        it between two of their k-steps)
       P2M_TRC(0, w, 6);
+    }
+    if (LEPI) {                                         // the last unit's tile
+      lds_block_barrier();                              // F0: the MFMA waves are done with the last image
+      lds_block_barrier();                              // E1
+      copy_out(grp - 1);
     }
   } else {
     // ------------------------------------------------------------------------------------------------------------
@@ -567,6 +619,26 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         a[i] = __builtin_bit_cast(
             frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * CT_SLICE + i * (32 * CT_LDA + CT_SPAD) + st * 16));
     };
+    auto stage_acc = [&]() {                            // LEPI: finished values -> LDS [sample][row][column], fresh accumulator
+      float* stg = reinterpret_cast<float*>(ct_smem);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            stg[((wm * TM + i) * 32 + row) * NCOL + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+          }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    };
     load_b(0, 0, fb[0]);
     if (NB == 3) load_b(0, 1, fb[1]);
     lds_block_barrier();                                // B1(-1)
@@ -576,6 +648,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       P2M_TRC(1, w, 0);
       lds_block_barrier();                              // B2(w)
       P2M_TRC(1, w, 1);
+      if (LEPI && w > 0 && fc == 0) {                   // (grp was advanced by the epilogue of the unit before)
+        stage_acc();
+        lds_block_barrier();                            // E1
+        copy_out(grp - 1);
+        zero_acc();
+        lds_block_barrier();                            // E2
+      }
       lds_block_barrier();                              // B1(w): image of unit w is in LDS
       P2M_TRC(1, w, 2);
       frag_t fl[TM];                                    // the low-slice A fragments: what the first MFMAs of a step read
@@ -615,11 +694,17 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       }
       P2M_TRC(1, w, 3);
       if (fc == nchunks - 1) {
-        tile_epilogue<TM, TN, MODE>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
+        tile_epilogue<TM, TN, MODE, CT_S, !LEPI>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
         grp++;
       }
       P2M_TRC(1, w, 4);
       fc = fcn;
+    }
+    if (LEPI) {
+      lds_block_barrier();                              // F0
+      stage_acc();
+      lds_block_barrier();                              // E1
+      copy_out(grp - 1);
     }
   }
 }

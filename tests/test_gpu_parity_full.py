@@ -165,7 +165,10 @@ def test_basis_inside_the_contraction_network_vs_oracle_train(hip_libs, tmp_path
 
 @pytest.mark.parametrize("env,tag", [({"P2M_GEMM_ARITH": "f16x2"}, "a_f16x2_human36_B3"),
                                      ({"P2M_GEMM_ARITH": "f16x2", "P2M_TILE_GEMM": "1"}, "a_f16x2_tile_human36_B3"),
-                                     ({"P2M_GEMM_ARITH": "bf16x3"}, "a_bf16x3_human36_B3")])
+                                     ({"P2M_GEMM_ARITH": "bf16x3"}, "a_bf16x3_human36_B3"),
+                                     # the bench's headline path: k_cheb_tile_gemm in three bf16 slices on every plan (at B = 256
+                                     # the policy picks it by itself), LDS-staged epilogue, planes out, activation on load
+                                     ({"P2M_GEMM_ARITH": "bf16x3", "P2M_TILE_GEMM": "1"}, "a_bf16x3_tile_human36_B3")])
 def test_slice_arithmetics_network_vs_oracle_train(hip_libs, tmp_path, env, tag):
     """The whole network in each slice arithmetic of the contractions (include/p2m.h P2M_ARITH_*: two scaled fp16 slices with
     the amax words travelling with the tensors, three exact bf16 slices), with and without the basis inside the
