@@ -17,8 +17,9 @@ Protocol: 20 warm-up + 50 timed steps by default; `value` / `ms
 `ms_per_step_stats` the per-step median / p10 / p90 from one HIP event per step.  The default 1-GPU train run also reports, from
 the same process and after the timed region: `arith_ab` (f16x2 at full protocol, native-f32 MFMA briefly), `also` (configs[1]
 inference and configs[4] MANO B=512 train, each in the main arithmetic and in the fast mode; `--also none` to skip), and for N > 1
-`multi_gpu` (ranks seen over the job's backend, per-rank per-bucket all-reduce timings and the hidden fraction).  `--gpus N` prints
-NO line unless N ranks, the nccl (RCCL) backend and N distinct GPUs are seen.
+`multi_gpu` (ranks seen over the job's backend, per-rank per-bucket all-reduce timings and the hidden fraction).  `python bench.py
+--gpus N` with no launcher (WORLD_SIZE unset) starts its N ranks itself (round 6); either way NO line is printed unless N ranks,
+the nccl (RCCL) backend and N distinct GPUs are seen.
 
 One "step" (train mode) = one full reference train step (lib/core/base.py:122-148) on one synthetic batch that is
 already resident in HBM: FlatPose2Mesh forward (PoseNet + coarse-to-fine GCN, both on hand-written kernels), perm-reverse gather,
@@ -282,6 +283,33 @@ def _port_ratio():
         return {"port_over_reference_time": None}
 
 
+def self_launch_command(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when no launcher set WORLD_SIZE: torch.distributed.run,
+    one node, N processes (one per GPU), rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """Runs the N-rank job and returns its exit code; rank 0's JSON line goes to this process's stdout unchanged.
+    $P2M_BENCH_LAUNCH_DRYRUN=1 prints the command instead (CPU test of the launch contract)."""
+    import subprocess
+    cmd = self_launch_command(n, argv)
+    if os.environ.get("P2M_BENCH_LAUNCH_DRYRUN") == "1":
+        print(json.dumps({"self_launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def _traffic_for(*kernel_prefixes):
     """HBM bytes per launch of a kernel family (all template instantiations whose name contains the prefix) from the
     committed PMC passes of this command (tools/rocprof_traffic.sh -> profiles/traffic_latest.json)."""
@@ -390,10 +418,14 @@ def main():
         if a not in ("infer", "mano"):
             ap.error(f"--also: unknown leg {a!r} (infer, mano, none)")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, exactly
+        # the command of the module docstring) and let the checks below - N ranks, RCCL, N distinct GPUs - run in them
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank, world, local = p2m_dist.init_from_env()
     if world != args.gpus:
-        # a line that says n_gpus = N must come from N ranks: `--gpus N` without torchrun (WORLD_SIZE unset) or with another
-        # world size is refused instead of silently measuring something else
+        # a line that says n_gpus = N must come from N ranks: another world size than --gpus is refused instead of
+        # silently measuring something else
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with `python -m "
                          f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                          f"--master-port P bench.py --gpus {args.gpus} ...` (no line printed)")

@@ -58,6 +58,11 @@ typedef struct p2m_graph* p2m_graph_t;
 const char* p2m_last_error_string(void);
 /* Library version / build info (e.g. "p2m-hip 0.3 (gfx950; ...)"). */
 const char* p2m_version(void);
+/* Identity of the stream capture `stream` is recording into: *id_out = the runtime's capture id (hipStreamGetCaptureInfo),
+ * 0 when the stream is not capturing.  Host-side only (no launch): the amax-word pool of the Python layer keys its chunks
+ * on it, so that two captures taken back to back never share graph-private memory.  No reference counterpart (the
+ * reference has no stream captures). */
+int p2m_stream_capture_id(void* stream, unsigned long long* id_out);
 
 /* ---- graph handle: one per coarsening level ------------------------------------------------
  * Replaces sparse_python_to_torch (lib/graph_utils.py:98-109) and the per-forward
@@ -461,11 +466,15 @@ int p2m_gemm_tn_acc(const float* A, int32_t Ka, const float* G, int32_t N, int64
  * batch_norm: training != 0 -> batch mean / biased variance over the B rows, running statistics updated with `momentum`
  * and the unbiased variance (nn.BatchNorm1d); else the running statistics.  mean / invstd receive the statistics used
  * (saved for the backward).  dropout: rnd = uniform [0, 1) numbers drawn by the caller, keep where rnd >= p_drop, scale
- * 1 / (1 - p_drop) (nn.Dropout); rnd == NULL or p_drop == 0: identity.  amax_out: atomic max of |a| (P2M_ARITH_F16X2). */
+ * 1 / (1 - p_drop) (nn.Dropout); rnd == NULL or p_drop == 0: identity.  amax_out: atomic max of |a| (P2M_ARITH_F16X2).
+ * B_real (round 6; 0 = B): the first B_real of the B rows hold samples, the rest are PADDING - the contractions want
+ * B >= 32 and B % 4 == 0, so the caller zero-pads any other batch (B = 1 of demo/run.py:160 included).  Padding rows are
+ * left out of the batch statistics (mean, variance and the unbiased-variance factor use B_real) and their a / aT values
+ * are stored as 0, so they stay exactly zero through every Linear; in the backward their gradient is 0 in and 0 out. */
 int p2m_pn_stage_fwd(const float* P, int32_t nch, const float* bias, const float* resid, float* z, int32_t has_bn,
                      int32_t training, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, const float* rnd, float p_drop, float* a, float* aT, float* mean,
-                     float* invstd, void* amax_out, int32_t B, int32_t F, void* stream);
+                     float* invstd, void* amax_out, int32_t B, int32_t F, int32_t B_real, void* stream);
 /* ... and backward (autograd of the same lines): g_a = sum_{ch < nch} P[ch] is the gradient w.r.t. the stage's output a;
  *   has_bn: g_u = g_a * dropout mask * [batch_norm(z) > 0];  dbeta = sum_r g_u;  dgamma = sum_r g_u xhat;
  *           g_z = gamma invstd (g_u - dbeta / B - xhat dgamma / B)  (training)   /   gamma invstd g_u  (running statistics)
@@ -476,7 +485,7 @@ int p2m_pn_stage_fwd(const float* P, int32_t nch, const float* bias, const float
 int p2m_pn_stage_bwd(const float* P, int32_t nch, const float* addend, int32_t has_bn, int32_t training, const float* z,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, const float* rnd,
                      float p_drop, float* gz, float* gzT, float* dgamma, float* dbeta, float* dbias, int32_t accumulate,
-                     void* amax_out, int32_t B, int32_t F, void* stream);
+                     void* amax_out, int32_t B, int32_t F, int32_t B_real, void* stream);
 
 /* ---- optimizer step over a flat fp32 buffer ------------------------------------------------
  * torch.optim.Adam semantics (lib/funcs_utils.py:92-96, stepped at lib/core/base.py:148): one fused

@@ -22,6 +22,7 @@ _i32, _i64, _f32, _vp = _c.c_int32, _c.c_int64, _c.c_float, _c.c_void_p
 HIP_SYMBOLS = {
     "p2m_last_error_string": (_c.c_char_p, []),
     "p2m_version": (_c.c_char_p, []),
+    "p2m_stream_capture_id": (_c.c_int, [_vp, _c.POINTER(_c.c_uint64)]),
     "p2m_graph_create": (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _c.POINTER(_vp)]),
     "p2m_graph_destroy": (_c.c_int, [_vp]),
     "p2m_graph_info": (_c.c_int, [_vp, _c.POINTER(_i32 * 4)]),
@@ -96,9 +97,9 @@ HIP_SYMBOLS = {
     "p2m_rmsprop_step_dev": (_c.c_int, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _vp]),
     "p2m_gemm_tn_acc": (_c.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
     "p2m_pn_stage_fwd": (_c.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp,
-                                    _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+                                    _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "p2m_pn_stage_bwd": (_c.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp,
-                                    _vp, _i32, _vp, _i32, _i32, _vp]),
+                                    _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "p2m_chebconv_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
 }
 

@@ -239,6 +239,16 @@ using namespace p2m;
 
 extern "C" const char* p2m_last_error_string(void) { return g_err; }
 
+extern "C" int p2m_stream_capture_id(void* stream, unsigned long long* id_out) {
+  if (!id_out) { set_error("p2m_stream_capture_id: id_out is null"); return P2M_ERR_INVALID; }
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id);
+  if (e != hipSuccess) { set_error("hipStreamGetCaptureInfo failed: %s", hipGetErrorString(e)); return P2M_ERR_HIP; }
+  *id_out = st == hipStreamCaptureStatusActive ? (id ? id : ~0ull) : 0ull;
+  return 0;
+}
+
 extern "C" const char* p2m_version(void) { return "p2m-hip 0.6 (gfx950; PoseNet stages, locality-ordered tiles; fp32 contractions as 2 scaled fp16 slices or 3 exact bf16 slices on the matrix pipe, or on the f32 MFMA; basis inside the contraction, paired operator, fake-row classes, activation on load)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).

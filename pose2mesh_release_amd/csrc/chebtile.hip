@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   // B2 and the next image store) and ALL waves of the block copy whole rows out with 16-byte accesses (6 per lane; the addend
   // comes in with 16-byte loads).  Same values, same BatchNorm partials (they come from the registers, as before).
   constexpr int NCOL = WN * TN * 32;                    // columns of the block's output tile (= N)
-  constexpr bool LEPI = TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4;
+  constexpr bool LEPI = NS == 3 && TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(ct_smem);
   unsigned char* xs = ct_smem + CT_AS_BYTES;

@@ -58,7 +58,8 @@ struct Graph {
   float* b = nullptr;      // [nnz]  coefficients of 2*L*L - I
   // Fake (padding) vertices are isolated: their merged row is the diagonal alone, with the SAME (fake_a, fake_b)
   // for the whole level.  For them T1 = fake_a*x and T2 = fake_b*x, so the contraction needs only K = Fin with
-  // W0 + fake_a*W1 + fake_b*W2.  real_ids / fake_ids list the two vertex sets (sorted) for the row-set kernels.
+  // W0 + fake_a*W1 + fake_b*W2.  real_ids / fake_ids list the two vertex sets for the row-set kernels (fake_ids
+  // ascending; real_ids in the LOCALITY order of the tile plans since round 5 - nothing depends on either being sorted).
   int n_real = 0, n_fake = 0;
   int* real_ids = nullptr;   // [n_real]
   int* fake_ids = nullptr;   // [n_fake]

@@ -50,6 +50,9 @@ struct PnFwdArgs {
   float* invstd;         // [F] out
   unsigned* amax_out;    // optional: max |a| (atomic max into a zeroed word)
   int B, F;
+  int Br;                // rows that hold samples (<= B): rows >= Br are PADDING (batches the contractions cannot take as
+                         // they are - B < 32 or B % 4 != 0 - are zero-padded by the caller): left out of the batch
+                         // statistics, and their a / aT values are stored as 0 so that they stay zero through every Linear
 };
 
 __device__ __forceinline__ void pn_block_amax(unsigned* word, float m) {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void k_pn_stage_fwd(PnFwdArgs g) {
       for (int u = 0; u < 4; u++) {
         if (r + u * PN_RG >= g.B) break;
         if (g.z != nullptr) *reinterpret_cast<pn4*>(g.z + o[u]) = v[u];
-        s += v[u];
+        if (r + u * PN_RG < g.Br) s += v[u];
       }
     }
   }
@@ -137,19 +140,19 @@ __global__ __launch_bounds__(256) void k_pn_stage_fwd(PnFwdArgs g) {
   if (g.has_bn) {
     if (g.training) {
       const pn4 tot = pn_colsum(s, red);
-      mean = tot / (float)g.B;
+      mean = tot / (float)g.Br;
       pn4 m2 = {0.f, 0.f, 0.f, 0.f};
       if (live)
-        for (int r = ty; r < g.B; r += PN_RG) {
+        for (int r = ty; r < g.Br; r += PN_RG) {
           const pn4 d = pn_ld4(zsrc + (long)r * g.F + c) - mean;
           m2 += d * d;
         }
-      const pn4 var = pn_colsum(m2, red) / (float)g.B;                // biased: what normalises (F.batch_norm)
+      const pn4 var = pn_colsum(m2, red) / (float)g.Br;               // biased: what normalises (F.batch_norm)
 #pragma unroll
       for (int e = 0; e < 4; e++) invstd[e] = 1.0f / sqrtf(var[e] + g.eps);
       if (live && ty == 0 && g.running_mean != nullptr) {
         // nn.BatchNorm1d: running = (1 - momentum) * running + momentum * batch statistic, UNBIASED variance
-        const float ub = g.B > 1 ? (float)g.B / (float)(g.B - 1) : 1.f;
+        const float ub = g.Br > 1 ? (float)g.Br / (float)(g.Br - 1) : 1.f;
         const pn4 rm = pn_ld4(g.running_mean + c), rv = pn_ld4(g.running_var + c);
         *reinterpret_cast<pn4*>(g.running_mean + c) = (1.f - g.momentum) * rm + g.momentum * mean;
         *reinterpret_cast<pn4*>(g.running_var + c) = (1.f - g.momentum) * rv + g.momentum * (var * ub);
@@ -179,8 +182,9 @@ __global__ __launch_bounds__(256) void k_pn_stage_fwd(PnFwdArgs g) {
       pn4 v = {0.f, 0.f, 0.f, 0.f};
       if (live) {
         const long o = (long)(rbase + rr) * g.F + c;
-        v = pn_ld4(zsrc + o);
-        if (g.has_bn) {
+        const bool pad = rbase + rr >= g.Br;
+        if (!pad) v = pn_ld4(zsrc + o);
+        if (g.has_bn && !pad) {
           pn4 u = {1.f, 1.f, 1.f, 1.f};
           if (g.rnd != nullptr) u = pn_ld4(g.rnd + o);
 #pragma unroll
@@ -223,6 +227,7 @@ struct PnBwdArgs {
   int accumulate;        // dgamma / dbeta / dbias: += instead of =
   unsigned* amax_out;
   int B, F;
+  int Br;                // rows that hold samples (see PnFwdArgs): the gradient of a padding row is 0 in and 0 out
 };
 
 __device__ __forceinline__ void pn_store_vec(float* dst, int c, pn4 v, int accumulate) {
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(256) void k_pn_stage_bwd(PnBwdArgs g) {
       for (int u = 0; u < 4; u++) {
         if (r + u * PN_RG >= g.B) break;
         pn4 w = v[u];
-        if (g.has_bn) {
+        if (r + u * PN_RG >= g.Br) w = pn4{0.f, 0.f, 0.f, 0.f};
+        else if (g.has_bn) {
           const pn4 xh = (pn_ld4(g.z + o[u]) - mean) * invstd;
           pn4 rn = {1.f, 1.f, 1.f, 1.f};
           if (g.rnd != nullptr) rn = pn_ld4(g.rnd + o[u]);
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(256) void k_pn_stage_bwd(PnBwdArgs g) {
       pn_store_vec(g.dgamma, c, t1, g.accumulate);
     }
     if (g.training) {
-      c0m = t0 / (float)g.B;
-      c1m = t1 / (float)g.B;
+      c0m = t0 / (float)g.Br;
+      c1m = t1 / (float)g.Br;
     }
   }
   // ---- pass 2: g_z = gamma * invstd * (g_u - mean(g_u) - xhat * mean(g_u xhat))  (eval: gamma * invstd * g_u) (+ addend)
@@ -303,12 +309,14 @@ __global__ __launch_bounds__(256) void k_pn_stage_bwd(PnBwdArgs g) {
       pn4 v = {0.f, 0.f, 0.f, 0.f};
       if (live) {
         const long o = (long)(rbase + rr) * g.F + c;
-        v = pn_ld4(g.gz + o);                             // this thread's own store of pass 1
-        if (g.has_bn) {
-          const pn4 xh = (pn_ld4(g.z + o) - mean) * invstd;
-          v = k * (v - c0m - xh * c1m);
+        if (rbase + rr < g.Br) {
+          v = pn_ld4(g.gz + o);                           // this thread's own store of pass 1
+          if (g.has_bn) {
+            const pn4 xh = (pn_ld4(g.z + o) - mean) * invstd;
+            v = k * (v - c0m - xh * c1m);
+          }
+          if (g.addend != nullptr) v += pn_ld4(g.addend + o);
         }
-        if (g.addend != nullptr) v += pn_ld4(g.addend + o);
         *reinterpret_cast<pn4*>(g.gz + o) = v;
         sb += v;
 #pragma unroll
@@ -334,9 +342,10 @@ extern "C" int p2m_pn_stage_fwd(const float* P, int32_t nch, const float* bias, 
                                 int32_t has_bn, int32_t training, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, const float* rnd,
                                 float p_drop, float* a, float* aT, float* mean, float* invstd, void* amax_out, int32_t B,
-                                int32_t F, void* stream) {
+                                int32_t F, int32_t B_real, void* stream) {
   P2M_CHECK_ARG(P != nullptr && nch >= 1 && B > 0 && F > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(F % 4 == 0, "the feature count must be a multiple of 4 (16-byte accesses)");
+  P2M_CHECK_ARG(B_real >= 0 && B_real <= B, "B_real must be 0 (= B) or 1 .. B");
   P2M_CHECK_ARG(z != nullptr || (nch == 1 && bias == nullptr && resid == nullptr),
                 "without a z output P must be the tensor itself (one chunk, no bias, no residual)");
   P2M_CHECK_ARG(!has_bn || (mean != nullptr && invstd != nullptr), "BatchNorm needs the mean / invstd outputs");
@@ -349,7 +358,7 @@ extern "C" int p2m_pn_stage_fwd(const float* P, int32_t nch, const float* bias, 
   g.running_mean = running_mean; g.running_var = running_var; g.momentum = momentum; g.eps = eps;
   g.rnd = (has_bn && rnd != nullptr && p_drop > 0.f) ? rnd : nullptr; g.p_drop = p_drop;
   g.a = a; g.aT = aT; g.mean = mean; g.invstd = invstd;
-  g.amax_out = static_cast<unsigned*>(amax_out); g.B = B; g.F = F;
+  g.amax_out = static_cast<unsigned*>(amax_out); g.B = B; g.F = F; g.Br = B_real > 0 ? B_real : B;
   hipLaunchKernelGGL(k_pn_stage_fwd, dim3(cdiv(F, PN_COLS)), dim3(256), 0, (hipStream_t)stream, g);
   return check_launch("pn_stage_fwd");
 }
@@ -358,9 +367,10 @@ extern "C" int p2m_pn_stage_bwd(const float* P, int32_t nch, const float* addend
                                 const float* z, const float* mean, const float* invstd, const float* gamma,
                                 const float* beta, const float* rnd, float p_drop, float* gz, float* gzT, float* dgamma,
                                 float* dbeta, float* dbias, int32_t accumulate, void* amax_out, int32_t B, int32_t F,
-                                void* stream) {
+                                int32_t B_real, void* stream) {
   P2M_CHECK_ARG(P != nullptr && nch >= 1 && gz != nullptr && B > 0 && F > 0, "null pointer or empty shape");
   P2M_CHECK_ARG(F % 4 == 0, "the feature count must be a multiple of 4 (16-byte accesses)");
+  P2M_CHECK_ARG(B_real >= 0 && B_real <= B, "B_real must be 0 (= B) or 1 .. B");
   P2M_CHECK_ARG(!has_bn || (z != nullptr && mean != nullptr && invstd != nullptr),
                 "the BatchNorm backward needs z and the statistics of the forward");
   P2M_CHECK_ARG(rnd == nullptr || (p_drop >= 0.f && p_drop < 1.f), "dropout probability must be in [0, 1)");
@@ -369,7 +379,7 @@ extern "C" int p2m_pn_stage_bwd(const float* P, int32_t nch, const float* addend
   g.z = z; g.mean = mean; g.invstd = invstd; g.gamma = gamma; g.beta = beta;
   g.rnd = (has_bn && rnd != nullptr && p_drop > 0.f) ? rnd : nullptr; g.p_drop = p_drop;
   g.gz = gz; g.gzT = gzT; g.dgamma = dgamma; g.dbeta = dbeta; g.dbias = dbias; g.accumulate = accumulate;
-  g.amax_out = static_cast<unsigned*>(amax_out); g.B = B; g.F = F;
+  g.amax_out = static_cast<unsigned*>(amax_out); g.B = B; g.F = F; g.Br = B_real > 0 ? B_real : B;
   hipLaunchKernelGGL(k_pn_stage_bwd, dim3(cdiv(F, PN_COLS)), dim3(256), 0, (hipStream_t)stream, g);
   return check_launch("pn_stage_bwd");
 }

@@ -47,8 +47,9 @@ class GraphedInference:
 
     # Checked on EVERY call, exactly: ops.WEIGHT_EPOCH (bumped by the flat optimizers, every train-mode forward and
     # GraphedTrainStep, which move weights by raw pointer) and the (pointer, version) of EVERY parameter and buffer - an
-    # in-place edit of one interior tensor (`net.cl[7].weight.data.copy_(...)`, a partial load_state_dict) moves nothing
-    # else.  The tensor list is cached at capture time, so the check is one pass of two attribute reads per tensor (~40 us
+    # in-place edit of one interior tensor (`with torch.no_grad(): net.cl[7].weight.copy_(...)`, a partial load_state_dict)
+    # moves nothing else.  NOT caught: writes through `tensor.data` (torch gives `.data` its own version counter) - after
+    # such a write call ops.bump_weight_epoch(), or the graph replays the stale packed weights (class docstring).  The tensor list is cached at capture time, so the check is one pass of two attribute reads per tensor (~40 us
     # for the ~190 tensors of FlatPose2Mesh; the 0.2 ms a naive check costs is the model.parameters() walk, not this).
     def _weights_tag(self):
         return (_ops.WEIGHT_EPOCH,) + tuple((t.data_ptr(), t._version) for t in self._tensors)

@@ -143,12 +143,14 @@ class _CoordLossFn(torch.autograd.Function):
         v, per = None, 1
         if valid is not None:
             B = p_.shape[0]
-            if valid.numel() == B:                                     # [B], [B,1], [B,1,1]: one value per sample
-                v, per = valid.reshape(B).contiguous().float(), n // B
-            elif p_.dim() == 3 and tuple(valid.shape) == (B, p_.shape[1], 1):      # the reference's [B, J, 1] masks
+            vs = tuple(valid.shape)
+            per_sample = vs == (B,) or (len(vs) == p_.dim() and vs[0] == B and all(d == 1 for d in vs[1:]))
+            if per_sample:                                             # [B] / [B,1,1]: one value per sample (a [J,1] mask
+                v, per = valid.reshape(B).contiguous().float(), n // B   # with J == B broadcasts per JOINT: generic path)
+            elif p_.dim() == 3 and vs == (B, p_.shape[1], 1):          # the reference's [B, J, 1] masks
                 v, per = valid.reshape(B * p_.shape[1]).contiguous().float(), p_.shape[2]
-            else:
-                v = valid.expand_as(p_).contiguous().float().reshape(-1)
+            else:                                                      # whatever `pred * target_valid` broadcasts to
+                v = valid.expand_as(p_).contiguous().float().reshape(-1)     # (raises on incompatible shapes, as torch does)
         grad = torch.empty_like(p_) if ctx.needs_input_grad[0] else None
         loss = torch.empty(1, device=p_.device, dtype=torch.float32)
 

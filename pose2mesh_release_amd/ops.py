@@ -418,22 +418,31 @@ def amax_begin_step(device):
 
 
 def _capturing():
+    """0 when the current stream is not capturing, else the IDENTITY of the capture it records into (the runtime's capture
+    id, p2m_stream_capture_id): two captures taken back to back are two different states."""
     try:
-        return bool(torch.cuda.is_current_stream_capturing())
+        if not torch.cuda.is_current_stream_capturing():
+            return 0
     except Exception:
-        return False
+        return 0
+    cid = ctypes.c_uint64(0)
+    check(_lib.hip().p2m_stream_capture_id(_stream(), ctypes.byref(cid)), "p2m_stream_capture_id")
+    return int(cid.value) or -1
 
 
 def new_amax(device):
-    """One zeroed amax word.  A chunk belongs to the capture state it was created in: a chunk made before a stream capture
-    is never re-zeroed by the graph's replays (its words would only grow), and one made INSIDE a capture is graph-private
-    memory (zeroed by every replay, uninitialised before the first) - so the chunk is dropped whenever that state flips.
+    """One zeroed amax word.  A chunk belongs to the capture it was created in (0: none): a chunk made before a stream
+    capture is never re-zeroed by the graph's replays (its words would only grow), and one made INSIDE a capture is that
+    graph's private memory (zeroed by every replay of THAT graph, uninitialised before the first, gone when the graph is
+    destroyed) - so the chunk is dropped whenever the capture identity changes, also from one capture straight to the next
+    (round 6: it used to be keyed on a boolean).
     A chunk is zeroed on the stream that created it; any other stream that draws a word from it first waits for that
     (inside a capture the record / wait pair becomes a dependency edge of the graph)."""
     key = torch.device(device).index
     if key is None:
         key = torch.cuda.current_device()
-    cap = _capturing()
+    with torch.cuda.device(key):
+        cap = _capturing()
     ent = _amax_chunks.get(key)
     if ent is None or ent[1] >= ent[0].numel() or ent[2] != cap:
         with torch.cuda.device(key):
@@ -1164,10 +1173,11 @@ def gemm_tn_acc(A, G, P, a_amax=None, g_amax=None):
 
 
 def pn_stage_fwd(P, nch, B, F, bias=None, resid=None, want_z=True, bn=None, rnd=None, p_drop=0.0, want_a=True,
-                 want_aT=True):
+                 want_aT=True, B_real=0):
     """z = sum of the nch partials P[ch] + bias (+ resid); bn = (gamma, beta, running_mean, running_var, momentum, eps,
     training) -> a = dropout(relu(batch_norm(z))), else a = z; a row-major and / or transposed ([F, B]).  Returns
-    (z, a, aT, mean, invstd); a / aT come back tagged with their amax word in f16x2 mode (include/p2m.h p2m_pn_stage_fwd)."""
+    (z, a, aT, mean, invstd); a / aT come back tagged with their amax word in f16x2 mode (include/p2m.h p2m_pn_stage_fwd).
+    B_real: rows that hold samples when the batch is zero-padded (0: all B)."""
     dev = P.device
     z = torch.empty((B, F), device=dev, dtype=torch.float32) if want_z else None
     a = torch.empty((B, F), device=dev, dtype=torch.float32) if want_a else None
@@ -1183,7 +1193,7 @@ def pn_stage_fwd(P, nch, B, F, bias=None, resid=None, want_z=True, bn=None, rnd=
     check(_lib.hip().p2m_pn_stage_fwd(_p(_req(P, "P")), int(nch), _p(bias), _p(resid), _p(z), int(bn is not None),
                                       int(bool(training)), _p(gamma), _p(beta), _p(rm), _p(rv), float(mom), float(eps),
                                       _p(rnd), float(p_drop), _p(a), _p(aT), _p(mean), _p(invstd), _p(word), B, F,
-                                      _stream()), "p2m_pn_stage_fwd")
+                                      int(B_real), _stream()), "p2m_pn_stage_fwd")
     if word is not None:
         for t in (a, aT):
             if t is not None:
@@ -1192,7 +1202,7 @@ def pn_stage_fwd(P, nch, B, F, bias=None, resid=None, want_z=True, bn=None, rnd=
 
 
 def pn_stage_bwd(P, nch, B, F, addend=None, bn=None, rnd=None, p_drop=0.0, want_T=True, dgamma=None, dbeta=None,
-                 dbias=None, accumulate=False):
+                 dbias=None, accumulate=False, B_real=0):
     """Backward of pn_stage_fwd.  bn = (z, mean, invstd, gamma, beta, training).  Returns (gz, gzT); dgamma / dbeta / dbias
     (given tensors) are overwritten, or added into when accumulate (include/p2m.h p2m_pn_stage_bwd)."""
     dev = P.device
@@ -1206,7 +1216,7 @@ def pn_stage_bwd(P, nch, B, F, addend=None, bn=None, rnd=None, p_drop=0.0, want_
     check(_lib.hip().p2m_pn_stage_bwd(_p(_req(P, "P")), int(nch), _p(addend), int(bn is not None), int(bool(training)),
                                       _p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(rnd), float(p_drop), _p(gz),
                                       _p(gzT), _p(dgamma), _p(dbeta), _p(dbias), int(bool(accumulate)), _p(word), B, F,
-                                      _stream()), "p2m_pn_stage_bwd")
+                                      int(B_real), _stream()), "p2m_pn_stage_bwd")
     if word is not None:
         tag_amax(gz, word)
         if gzT is not None:

@@ -17,7 +17,8 @@ On the GPU the forward / backward of the whole lifter is ONE autograd.Function o
     residual add (:38), their autograd                         columns and all B rows, so the batch statistics are block-local
 
 P2M_POSENET=stock keeps the stock torch modules (hipBLASLt GEMMs) on the GPU as the A/B form; CPU tensors always take them
-(PoseNet on the CPU is plain torch, as in the reference).  Odd batch sizes (B % 4 != 0 or B < 32) take the stock modules too.
+(PoseNet on the CPU is plain torch, as in the reference).  Every batch size takes the HIP path (round 6): B < 32 or B % 4 != 0 -
+B = 1 of demo/run.py:160 included - is zero-padded, the stage kernels keep the padding out of the statistics (B_real).
 """
 import os
 import sys
@@ -92,12 +93,21 @@ class _PoseNetFn(torch.autograd.Function):
         wc = net._weight_cache
         names, _ = net._param_list()
         P = {n: t for n, t in zip(names, params)}
-        B, Fh = x.shape[0], net.linear_size
+        Br, Fh = x.shape[0], net.linear_size
+        # the contractions take B >= 32, B % 4 == 0 (B is a tile dimension of p2m_gemm_tn): any other batch - B = 1 of
+        # demo/run.py:160 included - is zero-padded; the stage kernels leave the padding rows out of the statistics and
+        # keep them exactly zero (include/p2m.h, B_real)
+        B = max(32, (Br + 3) // 4 * 4)
         nin, nout = net.input_size, net.output_size
         training = net.training
-        p_drop = float(net.p_dropout)
+        # the dropout probability is read where the reference applies it - each block's own nn.Dropout module
+        # (posenet.py:20,29,34) - so that `m.p = 0` on those modules switches it off here as it does there
+        p_drop = [float(st.dropout.p) for st in net.linear_stages]
         nst = len(net.linear_stages)
         x = x.contiguous().float()
+        if training and Br == 1 and nst > 0:
+            # F.batch_norm's own check (posenet.py:28 in train mode with one sample)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {[Br, Fh]}")
 
         aux = {}          # operands the backward needs again (MeshNet's train-mode forward bumps ops.WEIGHT_EPOCH in between,
                           # which would make the cache rebuild them: one 67 MB amax pass per weight in f16x2 mode)
@@ -122,12 +132,12 @@ class _PoseNetFn(torch.autograd.Function):
                     bn_momentum(m) if (track and use_batch) else 0.1, m.eps, use_batch), m
 
         rnd = None
-        if training and p_drop > 0.0:
+        if training and any(p > 0.0 for p in p_drop):
             rnd = torch.rand((2 * nst, B, Fh), device=x.device, dtype=torch.float32)      # one launch for every mask
         nbt = []
         saved = {"x": x, "rnd": rnd, "stages": []}
         # pre-processing Linear (posenet.py:79): the 2J-wide input as one zero-padded 64-wide tile
-        xp = F.pad(x, (0, _PAD - nin))
+        xp = F.pad(x, (0, _PAD - nin, 0, B - Br))
         W1 = P["w1.weight"]
         W1t = wc.get(("w1", "tpad"), W1, lambda: _pad_rows(W1.t(), _PAD))                          # W^T, [64, Fh]
         Pp, _, nch = ops.gemm_tn([xp.t().contiguous()], B, 0, W1t, _PAD, Fh, g_amax=amax_w("w1", W1), tname="pn_gemm", target_blocks=_PN_BLOCKS)
@@ -136,16 +146,22 @@ class _PoseNetFn(torch.autograd.Function):
         y = None
         for i in range(nst):
             bn1, m1 = bn_of(i, "batch_norm1")
-            y, a1, a1T, mu1, is1 = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=bias, resid=resid, bn=bn1,
-                                                    rnd=None if rnd is None else rnd[2 * i], p_drop=p_drop)
+            y, a1, a1T, mu1, is1 = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=bias, resid=resid, bn=bn1, B_real=Br,
+                                                    rnd=None if rnd is None else rnd[2 * i], p_drop=p_drop[i])
             Wa = P[f"linear_stages.{i}.w1.weight"]
             Pp, _, nch = lin_fwd(a1T, f"s{i}.w1", Wa)
             bn2, m2 = bn_of(i, "batch_norm2")
-            z1, a2, a2T, mu2, is2 = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=P[f"linear_stages.{i}.w1.bias"], bn=bn2,
-                                                     rnd=None if rnd is None else rnd[2 * i + 1], p_drop=p_drop)
+            z1, a2, a2T, mu2, is2 = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=P[f"linear_stages.{i}.w1.bias"], bn=bn2, B_real=Br,
+                                                     rnd=None if rnd is None else rnd[2 * i + 1], p_drop=p_drop[i])
             Wb = P[f"linear_stages.{i}.w2.weight"]
             Pp, _, nch = lin_fwd(a2T, f"s{i}.w2", Wb)
             bias, resid = P[f"linear_stages.{i}.w2.bias"], y
+            tap = getattr(net, "_tap", None)
+            if tap is not None:
+                # test hook (tests/test_gpu_posenet.py): what decides the ReLU masks - the stage input, the statistics used
+                # and the affine pair; the kernels' mask is exactly fmaf((z - mean) * invstd, gamma, beta) > 0
+                tap.append((2 * i, y, mu1, is1, bn1[0], bn1[1]))
+                tap.append((2 * i + 1, z1, mu2, is2, bn2[0], bn2[1]))
             if training:
                 for m in (m1, m2):
                     if m.track_running_stats and m.num_batches_tracked is not None:
@@ -154,7 +170,7 @@ class _PoseNetFn(torch.autograd.Function):
                 saved["stages"].append((y, a1, mu1, is1, z1, a2, mu2, is2, bn1[6], bn2[6]))
             del a1T, a2T
         # the last block's output (its own z + residual), transposed for the post-processing Linear (posenet.py:85)
-        y_last, _, yT, _, _ = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=bias, resid=resid, want_a=False)
+        y_last, _, yT, _, _ = ops.pn_stage_fwd(Pp, nch, B, Fh, bias=bias, resid=resid, want_a=False, B_real=Br)
         W2 = P["w2.weight"]
         W2p = wc.get(("w2", "pad"), W2, lambda: _pad_rows(W2, _PAD))                               # [64, Fh]
         W2t = wc.get(("w2", "tpad"), W2, lambda: _wt(W2p))                                         # [Fh, 64]
@@ -162,14 +178,14 @@ class _PoseNetFn(torch.autograd.Function):
         Pp, _, nch = ops.gemm_tn([yT], B, 0, W2t, Fh, _PAD, a_amax=ops.amax_of(yT), g_amax=amax_w("w2", W2),
                                  tname="pn_gemm", target_blocks=_PN_BLOCKS)
         b2 = wc.get(("w2", "bpad"), P["w2.bias"], lambda: F.pad(P["w2.bias"].detach(), (0, _PAD - nout)))
-        out64, _, _, _, _ = ops.pn_stage_fwd(Pp, nch, B, _PAD, bias=b2, want_a=False, want_aT=False)
+        out64, _, _, _, _ = ops.pn_stage_fwd(Pp, nch, B, _PAD, bias=b2, want_a=False, want_aT=False, B_real=Br)
         if nbt:
             torch._foreach_add_(nbt, 1)           # nn.BatchNorm1d.forward's `num_batches_tracked += 1`, one launch
             ops.bump_weight_epoch()               # running statistics moved behind torch's back (cached eval operands)
         saved["y_last"], saved["aux"] = y_last, aux
         ctx.net, ctx.saved, ctx.params, ctx.names = net, (saved if keep else None), params, names
-        ctx.training, ctx.p_drop, ctx.B = training, p_drop, B
-        return out64[:, :nout].contiguous()
+        ctx.training, ctx.p_drop, ctx.B, ctx.Br, ctx.ran = training, p_drop, B, Br, False
+        return out64[:Br, :nout].contiguous()
 
     @staticmethod
     def backward(ctx, g_out):
@@ -180,14 +196,20 @@ class _PoseNetFn(torch.autograd.Function):
     def _backward(ctx, g_out):
         net, saved, params, names = ctx.net, ctx.saved, ctx.params, ctx.names
         if saved is None:
+            if ctx.ran:
+                raise ops.P2MError("PoseNet: backward called a second time - the saved activations are freed by the first "
+                                   "backward (retain_graph is not supported on this path)")
             raise ops.P2MError("backward called but the forward ran without gradient tracking")
+        ctx.ran = True
         wc = net._weight_cache
         P = {n: t for n, t in zip(names, params)}
         idx = {n: i for i, n in enumerate(names)}
-        B, Fh = ctx.B, net.linear_size
+        B, Br, Fh = ctx.B, ctx.Br, net.linear_size
         nin, nout = net.input_size, net.output_size
         nst = len(net.linear_stages)
         rnd, p_drop = saved["rnd"], ctx.p_drop
+        # parameters that take a gradient (frozen ones: no contraction, no reduction, None to autograd)
+        needs = {n: bool(ctx.needs_input_grad[3 + i]) for i, n in enumerate(names)}
         dev = g_out.device
         grads = [None] * len(params)
         direct = net._direct_grad and all(
@@ -200,7 +222,10 @@ class _PoseNetFn(torch.autograd.Function):
             return aux[key] if key in aux else wc.get((key, "amax"), W, lambda: ops.param_amax(W))
 
         def target(name, shape=None):
-            """where the gradient of `name` is written: its .grad (accumulated into) or a fresh zero tensor"""
+            """where the gradient of `name` is written: its .grad (accumulated into) or a fresh zero tensor; None for a
+            parameter that takes no gradient"""
+            if not needs[name]:
+                return None
             if direct:
                 return P[name].grad
             t = torch.zeros_like(P[name])
@@ -209,17 +234,19 @@ class _PoseNetFn(torch.autograd.Function):
 
         def ready(*ns):
             if direct and net._grad_sink is not None:
-                net._grad_sink([P[n] for n in ns])
+                net._grad_sink([P[n] for n in ns if needs[n]])
 
         g = g_out.contiguous().float()
-        g64 = F.pad(g, (0, _PAD - nout))                                   # [B, 64]
+        g64 = F.pad(g, (0, _PAD - nout, 0, B - Br))                        # [B, 64]
         g64T = g64.t().contiguous()                                        # [64, B]
         y_last = saved["y_last"]
         # post-processing Linear (posenet.py:85): dW = g^T y, db = sum g, g_y = g W
         W2 = P["w2.weight"]
-        Pw, _, _ = ops.gemm_tn([g64], _PAD, 0, y_last, B, Fh, tname="pn_gemm", target_blocks=_PN_BLOCKS)               # [1, 64, Fh]: one chunk
-        target("w2.weight").add_(Pw.sum(0)[:nout] if Pw.shape[0] > 1 else Pw[0, :nout])
-        target("w2.bias").add_(g.sum(0))
+        if needs["w2.weight"]:
+            Pw, _, _ = ops.gemm_tn([g64], _PAD, 0, y_last, B, Fh, tname="pn_gemm", target_blocks=_PN_BLOCKS)           # [1, 64, Fh]: one chunk
+            target("w2.weight").add_(Pw.sum(0)[:nout] if Pw.shape[0] > 1 else Pw[0, :nout])
+        if needs["w2.bias"]:
+            target("w2.bias").add_(g.sum(0))
         ready("w2.weight", "w2.bias")
         W2p = aux["W2p"]                                                                       # [64, Fh]
         Pg, _, nchg = ops.gemm_tn([g64T], B, 0, W2p, _PAD, Fh, g_amax=amax_w("w2", W2), tname="pn_gemm", target_blocks=_PN_BLOCKS)
@@ -230,35 +257,39 @@ class _PoseNetFn(torch.autograd.Function):
             if gz2 is None:
                 # gradient w.r.t. the last block's output: the partials summed, row-major and transposed; its row sums
                 # are the bias gradient of this block's w2
-                gz2, gz2T = ops.pn_stage_bwd(Pg, nchg, B, Fh, dbias=target(pre + "w2.bias"), accumulate=True)
+                gz2, gz2T = ops.pn_stage_bwd(Pg, nchg, B, Fh, dbias=target(pre + "w2.bias"), accumulate=True, B_real=Br)
             Wb = P[pre + "w2.weight"]
-            ops.gemm_tn_acc(gz2, a2, target(pre + "w2.weight"))                               # dW2 += g_z2^T a2
+            if needs[pre + "w2.weight"]:
+                ops.gemm_tn_acc(gz2, a2, target(pre + "w2.weight"))                           # dW2 += g_z2^T a2
             ready(pre + "w2.weight", pre + "w2.bias")
             Pa, _, nch = ops.gemm_tn([gz2T], B, 0, Wb, Fh, Fh, a_amax=ops.amax_of(gz2T), g_amax=amax_w(f"s{i}.w2", Wb),
                                      tname="pn_gemm", target_blocks=_PN_BLOCKS)
             gz1, gz1T = ops.pn_stage_bwd(Pa, nch, B, Fh, bn=(z1, mu2, is2, P[pre + "batch_norm2.weight"],
                                                             P[pre + "batch_norm2.bias"], tr2),
-                                         rnd=None if rnd is None else rnd[2 * i + 1], p_drop=p_drop,
+                                         rnd=None if rnd is None else rnd[2 * i + 1], p_drop=p_drop[i],
                                          dgamma=target(pre + "batch_norm2.weight"), dbeta=target(pre + "batch_norm2.bias"),
-                                         dbias=target(pre + "w1.bias"), accumulate=True)
+                                         dbias=target(pre + "w1.bias"), accumulate=True, B_real=Br)
             Wa = P[pre + "w1.weight"]
-            ops.gemm_tn_acc(gz1, a1, target(pre + "w1.weight"))                               # dW1 += g_z1^T a1
+            if needs[pre + "w1.weight"]:
+                ops.gemm_tn_acc(gz1, a1, target(pre + "w1.weight"))                           # dW1 += g_z1^T a1
             ready(pre + "batch_norm2.weight", pre + "batch_norm2.bias", pre + "w1.weight", pre + "w1.bias")
             Pa, _, nch = ops.gemm_tn([gz1T], B, 0, Wa, Fh, Fh, a_amax=ops.amax_of(gz1T), g_amax=amax_w(f"s{i}.w1", Wa),
                                      tname="pn_gemm", target_blocks=_PN_BLOCKS)
             prev_bias = f"linear_stages.{i - 1}.w2.bias" if i > 0 else "w1.bias"
             gy, gyT = ops.pn_stage_bwd(Pa, nch, B, Fh, addend=gz2, bn=(y, mu1, is1, P[pre + "batch_norm1.weight"],
                                                                        P[pre + "batch_norm1.bias"], tr1),
-                                       rnd=None if rnd is None else rnd[2 * i], p_drop=p_drop,
+                                       rnd=None if rnd is None else rnd[2 * i], p_drop=p_drop[i],
                                        dgamma=target(pre + "batch_norm1.weight"), dbeta=target(pre + "batch_norm1.bias"),
-                                       dbias=target(prev_bias), accumulate=True, want_T=(i > 0 or ctx.needs_input_grad[2]))
+                                       dbias=target(prev_bias), accumulate=True, B_real=Br,
+                                       want_T=(i > 0 or ctx.needs_input_grad[2]))
             ready(pre + "batch_norm1.weight", pre + "batch_norm1.bias")
             gz2, gz2T = gy, gyT
             saved["stages"][i] = None
         # pre-processing Linear (posenet.py:79): dW = g_y0^T x (the input zero-padded to 64 columns)
-        xp = F.pad(saved["x"], (0, _PAD - nin))
-        Pw, _, nchw = ops.gemm_tn([gz2], Fh, 0, xp, B, _PAD, a_amax=ops.amax_of(gz2), tname="pn_gemm", target_blocks=_PN_BLOCKS)   # [1, Fh, 64]
-        target("w1.weight").add_((Pw[0] if nchw == 1 else Pw.sum(0))[:, :nin])
+        if needs["w1.weight"]:
+            xp = F.pad(saved["x"], (0, _PAD - nin, 0, B - Br))
+            Pw, _, nchw = ops.gemm_tn([gz2], Fh, 0, xp, B, _PAD, a_amax=ops.amax_of(gz2), tname="pn_gemm", target_blocks=_PN_BLOCKS)   # [1, Fh, 64]
+            target("w1.weight").add_((Pw[0] if nchw == 1 else Pw.sum(0))[:, :nin])
         ready("w1.weight", "w1.bias")
         gx = None
         if ctx.needs_input_grad[2]:
@@ -266,7 +297,7 @@ class _PoseNetFn(torch.autograd.Function):
             W1p = wc.get(("w1", "pad"), W1, lambda: F.pad(W1.detach(), (0, _PAD - nin)))       # [Fh, 64]
             Px, _, nchx = ops.gemm_tn([gz2T], B, 0, W1p, Fh, _PAD, a_amax=ops.amax_of(gz2T), g_amax=amax_w("w1", W1),
                                       tname="pn_gemm", target_blocks=_PN_BLOCKS)
-            gx = (Px[0] if nchx == 1 else Px.sum(0))[:, :nin].contiguous()
+            gx = (Px[0] if nchx == 1 else Px.sum(0))[:Br, :nin].contiguous()
         ctx.saved = None
         return (None, None, gx) + tuple(grads)
 
@@ -312,7 +343,7 @@ class LinearModel(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        if x.is_cuda and HIP_POSENET == "hip" and x.dtype == torch.float32 and B % 4 == 0 and B >= 32 \
+        if x.is_cuda and HIP_POSENET == "hip" and x.dtype == torch.float32 and B >= 1 \
                 and self.linear_size % 128 == 0 and self.input_size <= _PAD and self.output_size <= _PAD:
             names, params = self._param_list()
             keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))

@@ -196,14 +196,33 @@ def test_world_size_8_is_the_mean_of_the_shard_gradients(tmp_path):
 
 def test_bench_refuses_a_scaling_point_without_the_ranks():
     """`bench.py --gpus N` must not print a JSON line unless N ranks are really there (RCCL, N distinct
-    GPUs: checked on the GPU box by tests/test_gpu_dist.py).  Without torchrun WORLD_SIZE is 1: no line, non-zero exit, and
-    the message says how to launch."""
+    GPUs: checked on the GPU box by tests/test_gpu_dist.py).  A launcher that set another world size than --gpus: no line,
+    non-zero exit, and the message says how to launch.  (WORLD_SIZE unset: bench.py starts the ranks itself - next test.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
     assert "WORLD_SIZE=1" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+def test_bench_gpus_n_without_launcher_starts_n_ranks():
+    """bench.py's launch contract: `python bench.py --gpus 8` with WORLD_SIZE unset re-executes itself under
+    torch.distributed.run with 8 processes on one node and a 127.0.0.1 rendezvous (the command is printed, not run: no GPU
+    here); with WORLD_SIZE set by a launcher nothing is re-launched."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["P2M_BENCH_LAUNCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["self_launch"]
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]

@@ -159,6 +159,26 @@ def test_bench_two_ranks_on_one_gpu(hip_libs):
     assert j["value"] > 0 and "cpu_baseline" not in j
 
 
+def test_bench_self_launches_its_ranks(hip_libs):
+    """`python bench.py --gpus 2` with NO launcher around it (WORLD_SIZE unset - the form the driver uses for N=1) starts its
+    two ranks itself and prints rank 0's single line; with the gloo override (both ranks share the only GPU) the line says
+    it is not a valid scaling point.  Without the override on a 1-GPU box the ranks refuse: no line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(P2M_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    argv = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-kernel-timing"]
+    r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["valid_scaling_point"] is False
+    assert j["config"]["backend"] == "gloo" and j["value"] > 0
+    if torch.cuda.device_count() < 2:
+        env.pop("P2M_DIST_BACKEND")
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-2000:]
+
+
 ONE_RANK_RCCL = r'''
 import os, sys
 sys.path[:0] = [{root!r}, {root!r} + "/oracle", {root!r} + "/tests"]

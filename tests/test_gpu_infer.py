@@ -204,3 +204,54 @@ def test_graph_handle_finalizer_is_capture_safe(hip_libs):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(c, torch.full((8,), 3.0, device="cuda"))
+
+
+def test_two_back_to_back_captures_of_the_op_do_not_share_amax_words(hip_libs, monkeypatch):
+    """in f16x2 the stand-alone graph_conv_cheby draws its amax words from the device's current chunk.
+    A chunk created inside a stream capture is that graph's private memory; two captures taken back to back (no eager call
+    between them) used to share it (the chunk was keyed on a boolean "capturing").  Now the chunk is keyed on the capture's
+    identity (p2m_stream_capture_id): the second capture gets its own chunk, each graph's replays re-zero their own words,
+    and replaying either graph - also after the other one is destroyed - reproduces the eager result bitwise."""
+    from pose2mesh_release_amd import ops
+    from pose2mesh_release_amd.cheby_graph_conv import graph_conv_cheby
+    monkeypatch.setattr(ops, "GEMM_ARITH", "f16x2")
+    ops.bump_weight_epoch()
+    gL, _, _ = helpers.golden_graphs("mano")
+    L = gL[2]
+    V, Fin, Fout, B = L.shape[0], 64, 32, 3
+    torch.manual_seed(5)
+    cl = torch.nn.Linear(Fin * 3, Fout).cuda()
+    bn = torch.nn.BatchNorm1d(Fout).cuda().eval()
+    g = ops.DeviceGraph(L, "cuda:0")
+    xs = [torch.randn(B, V, Fin, device="cuda") * s for s in (1.0, 300.0)]       # different magnitudes: different amax words
+    with torch.no_grad():
+        eager = [graph_conv_cheby(x, cl, bn, g, Fout, 3).clone() for x in xs]
+        # one capture straight after the other; the static inputs are filled later
+        statics, graphs, outs, chunks = [torch.zeros_like(x) for x in xs], [], [], []
+        torch.cuda.synchronize()
+        for st in statics:
+            gr = torch.cuda.CUDAGraph()
+            with ops.capture_guard(), torch.cuda.graph(gr):
+                outs.append(graph_conv_cheby(st, cl, bn, g, Fout, 3))
+                chunks.append(ops._amax_chunks[0][0])
+            graphs.append(gr)
+    assert chunks[0].data_ptr() != chunks[1].data_ptr() or chunks[0] is not chunks[1]
+    assert chunks[0] is not chunks[1]
+    for rep in range(3):                                   # big magnitudes first: a word that only grew would poison the rest
+        for i in (1, 0):
+            statics[i].copy_(xs[i] * (1.0 if rep != 1 else 0.01))
+            graphs[i].replay()
+            torch.cuda.synchronize()
+            if rep != 1:
+                assert torch.equal(outs[i], eager[i]), (rep, i)
+    # the first graph goes away (its pool with it); the second still replays correctly
+    keep = outs[1]
+    del graphs[0], outs[0], chunks
+    torch.cuda.empty_cache()
+    junk = torch.full((1 << 20,), 7.0e30, device="cuda")   # whatever lands in the freed pool is not a valid amax word
+    statics[1].copy_(xs[1])
+    graphs[0].replay()
+    torch.cuda.synchronize()
+    assert torch.equal(keep, eager[1])
+    del junk
+    ops.bump_weight_epoch()

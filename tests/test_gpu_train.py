@@ -143,6 +143,22 @@ def test_fused_coord_loss_matches_the_stock_module(hip_libs):
         assert float(b.grad[0, 0].abs().max()) == 0.0 and float(a.grad[0, 0].abs().max()) == 0.0, name
     with pytest.raises(Exception):
         fused(pred0, tgt)                                          # CPU tensors: no silent fallback
+    # a mask with B elements is per-sample only when its shape says so - a [J, 1] mask with J == B broadcasts
+    # per JOINT in the reference's `pred * target_valid` (lib/core/loss.py:17-19), and so it does here
+    Bq = J
+    pq, tq = (torch.randn(Bq, J, 3, generator=g) * 300).cuda(), (torch.randn(Bq, J, 3, generator=g) * 300).cuda()
+    mj = (torch.rand(J, 1, generator=g) > 0.4).float().cuda()
+    assert 0 < float(mj.sum()) < J
+    a = pq.clone().requires_grad_(True)
+    b = pq.clone().requires_grad_(True)
+    ref = 1e-3 * L.CoordLoss(has_valid=True)(a, tq, mj)
+    ref.backward()
+    out = fused(b, tq, mj)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(a.grad.abs().max())
+    with pytest.raises(RuntimeError):
+        fused(pq, tq, torch.ones(J + 1, 1, device="cuda"))        # not broadcastable: raises, as torch would
 
 
 def test_in_place_gradient_accumulation_is_bitwise_the_autograd_path(hip_libs):
