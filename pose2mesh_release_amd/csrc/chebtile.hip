@@ -81,6 +81,7 @@ struct TileGemmArgs {
   float* E2;
   long x_rows, a0_rows, c_rows;
   int act_relu, a0_shift, B, Ka, N, Npad, nset, gpb;
+  int a0_in_x;                 // A0 is X and a row's own source row (row id >> a0_shift) is one of its union rows (plans 0, 1)
 };
 
 // MODE: what the epilogue does besides bias + store - compiled in, because an epilogue that tests addend / activation /
@@ -435,6 +436,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     }
     int ri[NRP];
     unsigned a0off[NRP];
+    // (Round 6, measured and removed: plane 0 from the union image - with A0 == X a row's own source row is one of the
+    //  tile's union rows, already in LDS - instead of 16 of a unit's 80 global wave-loads: xs store + loads 2 492 -> 2 286
+    //  cycles, but gather 5 962 -> 6 698 and image store 1 381 -> 2 046 (two more live registers per row in a kernel at its
+    //  168-register cap): 18.2 vs 18.0 ms over the step's shapes.  profiles/r06_p0_from_lds_trace.txt.  k_cheb_tile_gemm_v2
+    //  below keeps the idea.)
 #pragma unroll
     for (int ps = 0; ps < NRP; ps++) {
       ri[ps] = ps * RPP + pw * 2 + rlo;
@@ -691,6 +697,448 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         __builtin_amdgcn_sched_barrier(0);
         if (st == 1) lds_block_barrier();               // B3(w): the producers' xs stores for unit w + 1 (not ours to wait
                                                         //        for, but s_barrier is block-wide)
+      }
+      P2M_TRC(1, w, 3);
+      if (fc == nchunks - 1) {
+        tile_epilogue<TM, TN, MODE, CT_S, !LEPI>(g, pl, acc, rowvid, grp, tile, R, wm, wn, l31, lhi, descale);
+        grp++;
+      }
+      P2M_TRC(1, w, 4);
+      fc = fcn;
+    }
+    if (LEPI) {
+      lds_block_barrier();                              // F0
+      stage_acc();
+      lds_block_barrier();                              // E1
+      copy_out(grp - 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_cheb_tile_gemm_v2 (round 6; N <= 128): the same unit of work - one tile x 4 samples x 32 features -, restructured
+// around what the in-kernel phase trace of round 5 showed (profiles/r05_tile_phase_trace.txt): the unit's critical path ran
+// through the PRODUCER waves - after the gather (6 000 cycles) and the image store (1 400) they spent 2 500 more issuing the
+// next unit's 80 global loads (1 KB per wave-instruction, ~24 cycles each through the CU's vector-memory path) and storing
+// the union rows into LDS, with the four MFMA waves idle 5 200 of the unit's 12 200 cycles (and a first attempt of this round,
+// the same loads issued at the head of the gather by the producers themselves, made the gather 3 300 cycles longer).  Here:
+//
+//   * the union rows come in by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), 1 KB pieces = 4
+//     union rows x 2 samples x 128 B, lane-linear in LDS, four pieces per producer wave and half, issued where a half
+//     becomes free (first version: by the MFMA waves, the ones with slack - but every counted wait hipcc emits for their
+//     weight-fragment loads then also waits for the pieces queued in front, and the first two k-steps of a unit took 4 200
+//     cycles instead of 2 000);
+//   * the union image is double-buffered IN THE SAMPLE DIMENSION at no extra LDS: two halves H0 / H1 of 120 rows x 2 samples
+//     x 128 B (30 KB each; round 5: one image of 4 samples).  A producer lane owns (row, sample of the half, 4 features) -
+//     512 lanes = 32 rows x 2 samples x 8 column quads - and gathers one row per half: h0 from H0, barrier MID, h1 from H1.
+//     H0 is refilled (next unit) from MID on, H1 from B2 on - both under the other half's gather / the image store;
+//   * plane 0 is read from the union image (a row is in its own union: the diagonal of L) instead of from global - 16 of a
+//     unit's 80 KB; the un-paired plans only (plan 2 takes A0 from another tensor: global, as before);
+//   * activation on load (in_scale) is applied where x is READ in the gather (the DMA cannot transform), the same two
+//     roundings per element;
+//   * three block barriers per unit (MID, B2, B1), none of them with a wave doing global-load issue behind it.
+// Per unit and lane the producers now do: 2 x (gather of one row, three split_pack4, E1 / E2 out) + 18 ds_write_b64.
+// Planes bitwise k_basis_tile's (same entry order, same fmaf chain); C as before (same k order in the MFMA waves).
+// The LDS-DMA is inline asm (hipcc would drain vmcnt(0) at the next global-load use while one is in flight,
+// /opt/skills/guides/cdna_hip_programming.md "Pipelining across barriers"): its completion is counted by hand - loads
+// retire in order, every wave issues EXACTLY 4 pieces per half, so `vmcnt(4)` after the H1 burst proves the H0 pieces landed;
+// the issuing waves hold no other global load in flight.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int CT2_XH_BYTES = TILE_UCAP * 2 * CT_CF * 4;                // one half of the union image: 30 720 B
+constexpr int CT2_ROWB = 2 * CT_CF * 4;                                // bytes per union row of a half (2 samples x 128 B)
+constexpr int CT2_NPIECE = TILE_UCAP / 4;                              // 1 KB pieces per half (4 union rows each): 30
+constexpr int CT2_TAB_BYTES = 1536 + 2048;    // rowoff[40], rowvid[32], rowlen[32], rawoff[40], diag[32], ucolb[120]; at 1536:
+                                              // in_scale[256], in_shift[256] (activation on load: no global load in the loop)
+constexpr int ct2_lds_bytes(int ns) { return ct_as_bytes(ns) + 2 * CT2_XH_BYTES + CT_ENT_BYTES + CT2_TAB_BYTES; }
+static_assert(TILE_UCAP % 4 == 0 && CT2_NPIECE <= 32, "4 pieces per producer wave and half");
+static_assert(ct2_lds_bytes(3) <= 160 * 1024, "LDS budget of one CU");
+
+// one LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KB of LDS at lds_dst (wave-uniform byte address)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int TM, int TN, int MODE, int NS>
+__global__ __launch_bounds__(768, 3) void k_cheb_tile_gemm_v2(TileGemmArgs g) {
+  typedef typename SliceFrag<NS>::type frag_t;
+  constexpr int CT_AS_BYTES = ct_as_bytes(NS);
+  constexpr int NT = 768;                      // 4 MFMA waves + 8 producer waves
+  constexpr int WM = CT_S / TM;
+  constexpr int WN = 4 / WM;
+  constexpr int NCOL = WN * TN * 32;
+  constexpr bool LEPI = NS == 3 && TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4;
+  constexpr int MIDST = 2;                     // the MFMA waves pass MID in front of this k-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(ct_smem);
+  unsigned char* xs = ct_smem + CT_AS_BYTES;                   // H0 | H1
+  f32x4* ents = reinterpret_cast<f32x4*>(ct_smem + CT_AS_BYTES + 2 * CT2_XH_BYTES);
+  int* rowoff = reinterpret_cast<int*>(ct_smem + CT_AS_BYTES + 2 * CT2_XH_BYTES + CT_ENT_BYTES);
+  int* rowvid = rowoff + 40;
+  int* rowlen = rowvid + 32;
+  int* rawoff = rowlen + 32;
+  int* diag = rawoff + 40;                     // [32] local index of a row's own source row in the union (-1: none)
+  unsigned* ucolb = reinterpret_cast<unsigned*>(diag + 32);    // [120] byte offset of union row u inside one sample of X
+  float* actc = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(rowoff) + 1536);     // [2][256]
+
+  const TilePlan& pl = g.pl;
+  const int ngroups = (g.B + CT_S - 1) / CT_S;
+  const int nbg = (ngroups + g.gpb - 1) / g.gpb;
+  const int lid = xcd_contiguous(blockIdx.x, gridDim.x);
+  if (lid >= pl.ntiles * nbg) return;
+  const int tile = lid % pl.ntiles;
+  const int bg = lid / pl.ntiles;
+  const int grp0 = bg * g.gpb;
+  int grp1 = grp0 + g.gpb;
+  if (grp1 > ngroups) grp1 = ngroups;
+  const int nchunks = g.Ka / CT_CF;
+  const int nunits = (grp1 - grp0) * nchunks;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int r0 = pl.tile_row[tile], R = pl.tile_row[tile + 1] - r0;
+  const int u0 = pl.tile_u[tile], U = pl.tile_u[tile + 1] - u0;
+  if (t < 32) {
+    rowlen[t] = t < R ? pl.erow[r0 + t + 1] - pl.erow[r0 + t] : 0;
+    const int vid = t < R ? g.row_ids[r0 + t] : -1;
+    rowvid[t] = vid;
+    int dg = -1;
+    if (vid >= 0 && g.a0_in_x) {               // the row's own source row (vid >> a0_shift) in the sorted union
+      const int want = vid >> g.a0_shift;
+      int lo = 0, hi = U - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1, c = pl.ucol[u0 + mid];
+        if (c == want) { dg = mid; break; }
+        if (c < want) lo = mid + 1; else hi = mid - 1;
+      }
+    }
+    diag[t] = dg;
+  }
+  for (int u = t; u < TILE_UCAP; u += NT) ucolb[u] = (unsigned)pl.ucol[u0 + (u < U ? u : U - 1)] * (unsigned)(g.Ka * 4);
+  if (g.in_scale != nullptr && t < g.Ka) {
+    actc[t] = g.in_scale[t];
+    actc[256 + t] = g.in_shift[t];
+  }
+  __syncthreads();
+  if (t <= 32) {
+    int po = 0, ro = 0;
+    for (int r = 0; r < t; r++) {
+      po += (rowlen[r] + 3) & ~3;
+      ro += rowlen[r];
+    }
+    rowoff[t] = po;
+    rawoff[t] = ro;
+  }
+  __syncthreads();
+  {
+    const int e0 = pl.erow[r0];
+    for (int r = t >> 6; r < R; r += NT / 64) {
+      const int eb = e0 + rawoff[r], len = rowlen[r], o = rowoff[r];
+      for (int k = lane; k < ((len + 3) & ~3); k += 64) {
+        f32x4 en = {0.f, 0.f, 0.f, 0.f};
+        if (k < len) {
+          en = *reinterpret_cast<const f32x4*>(&pl.ent[eb + k]);
+          en[2] = __int_as_float(__float_as_int(en[2]) * CT2_ROWB);          // local index -> byte offset in a half
+        }
+        ents[o + k] = en;
+      }
+    }
+  }
+  __syncthreads();
+
+  const bool producer = t >= 256;
+#ifdef P2M_TILE_TRACE
+  const bool trc_on = lid == P2M_TILE_TRACE && (t == 0 || t == 256);
+#endif
+  float x_sc = 1.f;
+  int descale = 0;
+  if (NS == 2) {
+    const int sx = slice_scale_exp(*g.x_amax, g.x_bits);
+    x_sc = exp2_int(sx);
+    descale = -(sx + slice_scale_exp(*g.b_amax, 0));
+  }
+
+  auto copy_out = [&](int egrp) {
+    constexpr int C4 = NCOL / 4, NPIECE = CT_S * 32 * C4, NIT = (NPIECE + NT - 1) / NT;
+    const float* stg = reinterpret_cast<const float*>(ct_smem);
+    f32x4 v[NIT], ad[NIT];
+    long off[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int p = t + k * NT;
+      const int c4 = p % C4, row = (p / C4) % 32, i = p / (C4 * 32);
+      const int vid = p < NPIECE ? rowvid[row] : -1;
+      const int b = egrp * CT_S + i;
+      off[k] = (vid >= 0 && b < g.B) ? ((long)b * g.c_rows + vid) * g.N + c4 * 4 : -1;
+      if (off[k] >= 0) {
+        v[k] = *reinterpret_cast<const f32x4*>(stg + (i * 32 + row) * NCOL + c4 * 4);
+        if (MODE == CT_ADDEND) ad[k] = *reinterpret_cast<const f32x4*>(g.addend + off[k]);
+      }
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      if (off[k] >= 0) {
+        if (MODE == CT_ADDEND) v[k] += ad[k];
+        *reinterpret_cast<f32x4*>(g.C + off[k]) = v[k];
+#pragma unroll
+        for (int c = 0; c < 4; c++) vmax = fmaxf(vmax, amax_abs(v[k][c]));
+      }
+    }
+    if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
+  };
+
+  if (producer) {
+    // ------------------------------------------------------------------------------------------------------------
+    const int pt = t - 256;
+    const int q = pt & 7, s2 = (pt >> 3) & 1;           // this lane's 4 features (16 bytes) of sample s2 of a half
+    const int i = pt >> 4;                              // ... of tile row i: 4 rows per wave, 16 lanes per row
+    const unsigned lane_off = (unsigned)(s2 * (CT_CF * 4) + q * 16);          // inside a 256-byte row of a half
+    const int vid = rowvid[i];
+    const int dg = diag[i];
+    const int j0 = rowoff[i], je = rowoff[i + 1];
+    const unsigned a0off = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
+    const bool in_act = g.in_scale != nullptr;          // block-uniform
+    // ---- LDS-DMA of the union rows: piece p of half h = union rows 4p .. 4p + 3, lane = (row >> 4, sample, quad).  Producer
+    // wave pw issues pieces pw, pw + 8, pw + 16, pw + 24 (clamped: a constant FOUR per wave and half, so that the counted
+    // waits below are exact).  These waves hold no other global load in flight in the loop (plane 0 and the activation
+    // coefficients come from LDS), so nothing hipcc counts is queued behind a piece.
+    const int pw = __builtin_amdgcn_readfirstlane(pt >> 6);
+    const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)xs;
+    const int du = lane >> 4;
+    auto dma_half = [&](int h, int dgrp, int dfc) {
+      int b = dgrp * CT_S + h * 2 + s2;
+      b = b < g.B ? b : g.B - 1;
+      const char* base = reinterpret_cast<const char*>(g.X) + ((long)b * g.x_rows) * (g.Ka * 4) + dfc * (CT_CF * 4) + q * 16;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int p = pw + 8 * k;
+        p = p < CT2_NPIECE ? p : CT2_NPIECE - 1;
+        glds16(base + ucolb[p * 4 + du], xs_lds + h * CT2_XH_BYTES + p * 1024);
+      }
+    };
+    int d0g = grp0, d0f = 0, d1g = grp0, d1f = 0;       // next unit of the H0 / H1 stream
+    auto adv = [&](int& dg_, int& df_) { if (++df_ == nchunks) { df_ = 0; dg_++; } };
+    dma_half(0, d0g, d0f);
+    dma_half(1, d1g, d1f);
+    adv(d0g, d0f);
+    adv(d1g, d1f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // both halves of unit 0 landed
+    lds_block_barrier();                                // B1(-1)
+    int grp = grp0, fc = 0;
+    for (int w = 0; w < nunits; w++) {
+      P2M_TRC(0, w, 0);
+      u32x2 sp[2][3][NS];                               // [half][plane][slice]: this lane's part of the A image of unit w
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (in_act) {
+        sc = *reinterpret_cast<const f32x4*>(actc + fc * CT_CF + q * 4);
+        sh = *reinterpret_cast<const f32x4*>(actc + 256 + fc * CT_CF + q * 4);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const unsigned char* xh = xs + h * CT2_XH_BYTES + lane_off;
+        const int b = grp * CT_S + h * 2 + s2;
+        f32x4 p0 = {0.f, 0.f, 0.f, 0.f};
+        if (dg >= 0) p0 = *reinterpret_cast<const f32x4*>(xh + dg * CT2_ROWB);
+        else if (vid >= 0)
+          p0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(g.A0) +
+                                               ((long)(b < g.B ? b : g.B - 1) * g.a0_rows) * (g.Ka * 4) + a0off +
+                                               fc * (CT_CF * 4) + q * 16);
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+        int j = j0;
+        f32x4 en[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) en[k] = ents[j + k];
+        for (; j < je; j += 4) {
+          f32x4 x[4], nn[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            x[k] = *reinterpret_cast<const f32x4*>(xh + (unsigned)__float_as_int(en[k][2]));
+#pragma unroll
+          for (int k = 0; k < 4; k++) nn[k] = ents[j + 4 + k];
+          if (in_act) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+              for (int c = 0; c < 4; c++) x[k][c] = fmaxf(fmaf(x[k][c], sc[c], sh[c]), 0.f);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              t1[c] = fmaf(en[k][0], x[k][c], t1[c]);
+              t2[c] = fmaf(en[k][1], x[k][c], t2[c]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) en[k] = nn[k];
+        }
+        auto planes_out = [&]() {
+          if (g.E1 != nullptr && i < R && b < g.B) {
+            const long o = ((long)b * g.nset + r0 + i) * g.Ka + fc * CT_CF + q * 4;
+            __builtin_nontemporal_store(t1, reinterpret_cast<f32x4*>(g.E1 + o));
+            __builtin_nontemporal_store(t2, reinterpret_cast<f32x4*>(g.E2 + o));
+          }
+        };
+        if (h == 1) planes_out();                       // (half 0: behind MID - no store in flight at its counted wait)
+        if (in_act) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) p0[c] = fmaxf(fmaf(p0[c], sc[c], sh[c]), 0.f);
+        }
+        split_pack4<NS>(p0[0], p0[1], p0[2], p0[3], x_sc, sp[h][0]);
+        split_pack4<NS>(t1[0], t1[1], t1[2], t1[3], x_sc, sp[h][1]);
+        split_pack4<NS>(t2[0], t2[1], t2[2], t2[3], x_sc, sp[h][2]);
+        if (h == 0) {
+          P2M_TRC(0, w, 1);
+          // H1(w) landed: its pieces (issued behind B2(w - 1)) are this wave's only loads in flight
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          lds_block_barrier();                          // MID(w): every producer is done with H0(w) - it may be refilled
+          if (w + 1 < nunits) {
+            dma_half(0, d0g, d0f);                      // H0(w + 1), under the gather of half 1 and the image store
+            adv(d0g, d0f);
+          }
+          planes_out();
+          P2M_TRC(0, w, 2);
+        }
+      }
+      P2M_TRC(0, w, 3);
+      lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
+                                                        //        every producer is done with H1(w)
+      if (w + 1 < nunits) {
+        dma_half(1, d1g, d1f);                          // H1(w + 1), under the image store and the next gather of half 0
+        adv(d1g, d1f);
+      }
+      P2M_TRC(0, w, 4);
+      if (LEPI && w > 0 && fc == 0) {
+        lds_block_barrier();                            // E1: staged
+        copy_out(grp - 1);
+        lds_block_barrier();                            // E2
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int s = h * 2 + s2;
+        unsigned short* d = As + (s * 32 + i) * CT_LDA + s * CT_SPAD + q * 4;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+          for (int sl = 0; sl < NS; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[h][p][sl];
+      }
+      if (++fc == nchunks) { fc = 0; grp++; }
+      P2M_TRC(0, w, 5);
+      // H0(w + 1) landed: loads retire in order and the 4 pieces of H1(w + 1) are the only younger ones
+      if (w + 1 < nunits) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      lds_block_barrier();                              // B1(w): image of unit w visible; H0(w + 1) landed
+      P2M_TRC(0, w, 6);
+    }
+    if (LEPI) {
+      lds_block_barrier();                              // F0
+      lds_block_barrier();                              // E1
+      copy_out(grp - 1);
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------------------
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const long bx_slice = (long)g.Npad * 32;
+    const long bx_plane = (long)(g.Ka / 16) * NS * bx_slice;
+    const char* bx_lane = reinterpret_cast<const char*>(g.Bx) + ((wn * TN * 32 + l31) * 16 + lhi * 8) * 2;
+    constexpr int NB = TN == 1 ? 3 : 2;
+    frag_t fb[NB][NS][TN];
+    auto load_b = [&](int fc, int st, frag_t (&b)[NS][TN]) {
+      const char* src = bx_lane + (st >> 1) * bx_plane + (long)(fc * 2 + (st & 1)) * NS * bx_slice;
+#pragma unroll
+      for (int sl = 0; sl < NS; sl++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          b[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(src + sl * bx_slice + j * (32 * 16 * 2)));
+    };
+    const unsigned short* a_lane = As + ((wm * TM) * 32 + l31) * CT_LDA + (wm * TM) * CT_SPAD + lhi * 8;
+    auto read_a = [&](int sl, int st, frag_t (&a)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+        a[i] = __builtin_bit_cast(
+            frag_t, *reinterpret_cast<const u32x4*>(a_lane + sl * CT_SLICE + i * (32 * CT_LDA + CT_SPAD) + st * 16));
+    };
+    auto stage_acc = [&]() {
+      float* stg = reinterpret_cast<float*>(ct_smem);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            stg[((wm * TM + i) * 32 + row) * NCOL + wn * TN * 32 + j * 32 + l31] = acc[i][j][r];
+          }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    };
+    load_b(0, 0, fb[0]);
+    if (NB == 3) load_b(0, 1, fb[1]);
+    lds_block_barrier();                                // B1(-1)
+    // gather(0) runs now; nothing to multiply yet
+    lds_block_barrier();                                // MID(0)
+    int grp = grp0, fc = 0;
+    for (int w = 0; w < nunits; w++) {
+      const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
+      P2M_TRC(1, w, 0);
+      lds_block_barrier();                              // B2(w): H1(w) is free
+      P2M_TRC(1, w, 1);
+      const bool more1 = w + 1 < nunits;                // block-uniform
+      if (LEPI && w > 0 && fc == 0) {
+        stage_acc();
+        lds_block_barrier();                            // E1
+        copy_out(grp - 1);
+        zero_acc();
+        lds_block_barrier();                            // E2
+      }
+      lds_block_barrier();                              // B1(w): image of unit w is in LDS
+      P2M_TRC(1, w, 2);
+      frag_t fl[TM];
+      read_a(NS - 1, 0, fl);
+#pragma unroll
+      for (int st = 0; st < 6; st++) {
+        if (st == MIDST && more1) lds_block_barrier();  // MID(w + 1) (the producers' hand-over of H0; block-wide barrier)
+        constexpr int AH = NB - 1;
+        if (st + AH < 6) load_b(fc, st + AH, fb[(st + AH) % NB]);
+        else load_b(fcn, st + AH - 6, fb[(st + AH) % NB]);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_t fh[TM], fm[TM];
+        read_a(0, st, fh);
+        if constexpr (NS == 3) read_a(1, st, fm);
+#define P2M_PAIR(FA, SB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
+      acc[i][j] = slice_mfma<NS>(FA[i], fb[st % NB][SB][j], acc[i][j]);
+        P2M_PAIR(fl, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st < 5) read_a(NS - 1, st + 1, fl);
+        if constexpr (NS == 3) {
+          P2M_PAIR(fh, 2)
+          P2M_PAIR(fm, 1)
+          P2M_PAIR(fm, 0)
+          P2M_PAIR(fh, 1)
+          P2M_PAIR(fh, 0)
+        } else {
+          P2M_PAIR(fh, 1)
+          P2M_PAIR(fh, 0)
+        }
+#undef P2M_PAIR
+        __builtin_amdgcn_sched_barrier(0);
       }
       P2M_TRC(1, w, 3);
       if (fc == nchunks - 1) {
@@ -1171,6 +1619,33 @@ static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
   if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT, NS>(a, s);
   return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN, NS>(a, s);
 }
+// k_cheb_tile_gemm_v2 (N <= 128; round 6).  P2M_TILE_V2=0 (read once per process) keeps the round-5 kernel for A/B runs.
+static bool tile_v2() {
+  static const bool v = [] { const char* e = getenv("P2M_TILE_V2"); return e ? atoi(e) != 0 : false; }();
+  return v;
+}
+template <int TM, int TN, int MODE, int NS>
+static int launch_tile_gemm_v2_mode(const TileGemmArgs& a, hipStream_t s) {
+  constexpr int LDS_BYTES = ct2_lds_bytes(NS);
+  static DeviceOnce attr_set;
+  if (const int rc = attr_set.run([] {
+        return hipFuncSetAttribute((const void*)k_cheb_tile_gemm_v2<TM, TN, MODE, NS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      }, "p2m_cheb_tile_gemm(v2)", LDS_BYTES))
+    return rc;
+  const int ngroups = cdiv(a.B, CT_S);
+  const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
+  hipLaunchKernelGGL((k_cheb_tile_gemm_v2<TM, TN, MODE, NS>), dim3(nblocks), dim3(768), LDS_BYTES, s, a);
+  return check_launch("cheb_tile_gemm(v2)");
+}
+template <int TM, int TN, int NS>
+static int launch_tile_gemm_v2(const TileGemmArgs& a, hipStream_t s) {
+  if (a.stats != nullptr) return launch_tile_gemm_v2_mode<TM, TN, CT_STATS, NS>(a, s);
+  if (a.addend != nullptr) return launch_tile_gemm_v2_mode<TM, TN, CT_ADDEND, NS>(a, s);
+  if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_v2_mode<TM, TN, CT_ACT, NS>(a, s);
+  return launch_tile_gemm_v2_mode<TM, TN, CT_PLAIN, NS>(a, s);
+}
+
 template <int TMS, int TN, int NPW, int MODE, int NS>
 static int launch_mg_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
   constexpr int SG = 2 * TMS;
@@ -1217,6 +1692,7 @@ static int launch_tile_gemm(const TileGemmArgs& a, hipStream_t s) {
     if constexpr (TN == 1) {
       if (mg_exact() && a.pl.ltx3 != nullptr)
         return a.N == 128 ? launch_mg_gemm<1, 2, 4, 3>(a, s) : launch_mg_gemm<1, 1, 4, 3>(a, s);
+      if (tile_v2()) return launch_tile_gemm_v2<TM, TN, 3>(a, s);
     }
     return launch_tile_gemm_ns<TM, TN, NPW, 3>(a, s);
   }
@@ -1285,6 +1761,7 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   a.a0_rows = plan == 0 ? g.V : g.V / 2;
   a.c_rows = paired ? g.V / 2 : g.V;
   a.a0_shift = plan == 1 ? 1 : 0;
+  a.a0_in_x = (A0 == X && !paired) ? 1 : 0;
   a.B = B;
   a.Ka = Ka;
   a.N = N;

@@ -764,6 +764,26 @@ def test_exact_matrix_core_gather_in_a_subprocess(hip_libs):
     assert " passed" in r.stdout
 
 
+def test_tile_kernel_v2_in_a_subprocess(hip_libs):
+    """Round 6: k_cheb_tile_gemm_v2 (N <= 128, bf16x3) - union rows by LDS-DMA into a union image double-buffered in the sample
+    dimension, plane 0 from that image, activation applied where x is read - is opt-in (P2M_TILE_V2=1, read once per process
+    by the library): built to take the global-load issue off the producers' critical path, measured 4-9 % SLOWER than the
+    round-5 kernel (profiles/r06_v2_*.txt).  Its parity runs here in a child process: C against basis
+    kernel + plane contraction and float64, planes BITWISE the basis kernel's, BatchNorm partials, addend, fused activation,
+    activation on load, the paired backward."""
+    import os
+    import subprocess
+    import sys
+    child_env = dict(os.environ, P2M_TILE_V2="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k",
+                        "(basis_inside_the_contraction or activation_on_load or paired_backward) and bf16x3"],
+                       env=child_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("V,Fin,Fout,B", [(736, 128, 128, 5), (1472, 128, 64, 3), (2944, 64, 128, 2)])
 @pytest.mark.parametrize("slices", ["f16x2", "bf16x3"])
 def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, slices, V, Fin, Fout, B):

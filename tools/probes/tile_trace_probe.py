@@ -39,8 +39,13 @@ assert rc == 0, rc
 p, m = buf[0].astype(np.int64), buf[1].astype(np.int64)
 nu = int((p[:, 0] > 0).sum())
 print(f"case level={lvl} Ka={Ka} N={N} plan={plan} form={form} arith={ops.GEMM_ARITH}: {nu} units traced")
-print("producer wave:  unit | gather+split | wait B2 | (copy-out of the closed group +) image store | wait B1 | xs store + loads | "
-      "wait B3 | unit total")
+V2 = os.environ.get("P2M_TILE_V2", "1") != "0" and N <= 128 and ops.GEMM_ARITH == "bf16x3"
+if V2:       # k_cheb_tile_gemm_v2 (round 6): stamps 0 head, 1 half 0 gathered, 2 past MID, 3 half 1 gathered, 4 past B2, 5 image stored, 6 past B1
+    print("producer wave:  unit | gather + split h0 | wait MID | gather + split h1 | wait B2 | (copy-out of the closed group +) "
+          "image store | wait B1 | unit total")
+else:
+    print("producer wave:  unit | gather+split | wait B2 | (copy-out of the closed group +) image store | wait B1 | xs store + loads | "
+          "wait B3 | unit total")
 tot = np.zeros(7)
 for w in range(nu):
     d = [p[w, 1] - p[w, 0], p[w, 2] - p[w, 1], p[w, 3] - p[w, 2], p[w, 4] - p[w, 3], p[w, 5] - p[w, 4], p[w, 6] - p[w, 5]]
@@ -50,7 +55,7 @@ for w in range(nu):
         tot += np.array(d + [nxt])
 if nu > 2:
     print("   avg | " + " | ".join(f"{v / (nu - 2):7.0f}" for v in tot))
-print("MFMA wave:  unit | wait B2 | (stage + copy-out +) wait B1 | 6 k-steps (incl. B3) | epilogue values / partials | unit total")
+print("MFMA wave:  unit | wait B2 | (DMA of H1, stage + copy-out +) wait B1 | 6 k-steps (incl. MID / B3) | epilogue values / partials | unit total")
 tot = np.zeros(5)
 for w in range(nu):
     d = [m[w, 1] - m[w, 0], m[w, 2] - m[w, 1], m[w, 3] - m[w, 2], m[w, 4] - m[w, 3]]
