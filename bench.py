@@ -52,6 +52,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from pose2mesh_release_amd import build as p2m_build  # noqa: E402
 from pose2mesh_release_amd import dist as p2m_dist  # noqa: E402
 from pose2mesh_release_amd import loss as p2m_loss  # noqa: E402
 from pose2mesh_release_amd import ops, optim, pose2mesh_net, synth  # noqa: E402
@@ -325,7 +326,37 @@ def _traffic_for(*kernel_prefixes):
             n += rec["launches"]
     if n == 0:
         return None, None
-    return {"hbm_bytes_per_launch": tot / n, "launches": n}, t.get("source")
+    return {"hbm_bytes_per_launch": tot / n, "launches": n, "code_id": t.get("code_id")}, t.get("source")
+
+
+def parity_check(step, n=4):
+    """Untimed, after the timed region (rank 0, N = 1, beside the CPU baseline): the model the bench just trained, put in
+    eval(), on the first `n` samples of the TIMED batch - FlatPose2Mesh forward on the GPU against the CPU oracle
+    (oracle/meshnet_oracle.py: the reference's operator sequence, lib/models/pose2mesh_net.py:16-22) with the same weights
+    and running statistics.  Max per-vertex L2 in metres; BASELINE's bar is 1e-4."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import meshnet_oracle as mo
+    model = step.model
+    was_training = model.training
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = step.pose2d[:n].contiguous()
+    try:
+        model.eval()
+        with torch.no_grad():
+            mesh, lift = model(x)
+        torch.cuda.synchronize()
+    finally:
+        model.train(was_training)
+    glt = [mo.scipy_to_torch_coo(L) for L in mo.trim_graph_list(step.graph_L)]
+    mano = step.V0 < 2000
+    with torch.no_grad():
+        rmesh, rlift = mo.flat_forward(sd, glt, x.cpu(), mano, False)
+    e = float((mesh.cpu().double() - rmesh.double()).norm(dim=-1).max())
+    el = float((lift.cpu() - rlift).abs().max() / max(1.0, float(rlift.abs().max())))
+    return {"max_vertex_l2_m": e, "tol": 1e-4, "ok": bool(e <= 1e-4), "lifted_pose_rel_err": el, "samples": n,
+            "arith": ops.GEMM_ARITH,
+            "what": f"eval forward of the first {n} samples of the timed batch with the weights the timed steps left, GPU "
+                    f"(this package, {ops.GEMM_ARITH}) vs the CPU oracle port of the reference path; untimed"}
 
 
 def timed_run(step, warmup, steps, barrier):
@@ -671,6 +702,7 @@ def main():
                 f_m, f_h = tf / pipe_peak, gbs / PEAK_HBM_GBPS
                 tr, tr_src = _traffic_for(*prefixes)
                 alg = rec["bytes"] / rec["launches"]
+                cur_id = p2m_build.source_id()
                 o = {"bound": "hbm" if f_h >= f_m else "mfma", "kernel": f"{kernel} ({arith_note})",
                      "achieved": round(gbs, 1) if f_h >= f_m else round(tf, 2),
                      "peak": PEAK_HBM_GBPS if f_h >= f_m else round(pipe_peak, 1),
@@ -689,9 +721,14 @@ def main():
                              "in algorithmic fp32 FLOPs = 2500 / slice products (or the f32 MFMA's 157.3); algorithmic "
                              "bytes = every operand row and every output row once"}
                 if tr is not None:
+                    # the PMC passes are a separate (profiled) run: say which code they measured, and whether it is this code
+                    o["traffic_code_id"], o["code_id"] = tr.get("code_id"), cur_id
+                    o["traffic_stale"] = tr.get("code_id") != cur_id
                     o["traffic_note"] = (f"HBM bytes per launch (FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE) averaged "
                                          f"over the {tr['launches']} launches of this family in the rocprofv3 --pmc passes of "
-                                         f"{tr_src}")
+                                         f"{tr_src}; NOT measured in this run: traffic_code_id = the source hash "
+                                         f"(pose2mesh_release_amd.build.source_id) of the code those passes ran, "
+                                         f"traffic_stale = it differs from the code of this run")
                 if fwd and fwd["ms"] > 0 and not infer:
                     fs = fwd["ms"] * 1e-3
                     o["exclusive"] = {"note": "forward launches only (nothing else on the GPU)",
@@ -782,6 +819,8 @@ def main():
             line["also"] = also_out
         if multi is not None:
             line["multi_gpu"] = multi
+        if world == 1 and not args.no_cpu_baseline and not infer:
+            line["parity_check"] = parity_check(step)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.joint_set, args.cpu_seconds, edge_loss=not args.no_edge_loss,
                                                 batch=64 if infer else 32, mode=args.mode)

@@ -244,6 +244,13 @@ int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* scale, const
                       int64_t M, int32_t F, p2m_graph_t classes, void* stream);
 int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                         float* coef, int32_t accumulate, int32_t F, void* stream);
+/* The reduce pass over the FAKE-vertex rows of a level only (b * V + fake id; with classes: the representatives, which
+ * carry their class's summed gradient) - the complement of a reduction whose real-vertex rows were summed by the kernel
+ * that produced gx (p2m_cheb_tile_gemm, bnr_*).  part: [p2m_bn_bwd_blocks_fake(g, B, F)][2][F]; F in {32, 64, 128, 256}.  */
+int32_t p2m_bn_bwd_blocks_fake(p2m_graph_t g, int32_t B, int32_t F);
+int p2m_bn_bwd_reduce_fake(p2m_graph_t g, const float* gx, const float* y, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, int32_t relu, float* part, int32_t B, int32_t F,
+                           void* stream);
 /* pair_gx / pair_gy (optional, [M/2, F]; M even, F in {32,64,128,256}): by-products pair_gx[q] = gx[2q] + gx[2q+1] and
  * pair_gy[q] = gy[2q] + gy[2q+1] -- the pair-sums the backward of an un-pooled conv needs (residual gradient for the
  * coarser level; plane S g of the paired operator), produced while the rows are in registers anyway.
@@ -353,8 +360,17 @@ int p2m_bn_finalize_split(p2m_graph_t g, const float* stats_real, const float* s
  * raw output y of the previous conv and the operand is x = max(fma(y, in_scale[f], in_shift[f]), 0), its BatchNorm + ReLU
  * (lib/models/backbones/cheby_graph_conv.py:39, lib/models/meshnet.py:100) with the two roundings of p2m_bn_act_fwd, applied in
  * the producer waves between the global load and the LDS image: the activated tensor never exists in HBM.  With
- * P2M_ARITH_F16X2 x_amax must then bound x (p2m_act_bound); P2M_ARITH_BF16X3 needs no bound.                               */
+ * P2M_ARITH_F16X2 x_amax must then bound x (p2m_act_bound); P2M_ARITH_BF16X3 needs no bound.
+ * bnr_y / bnr_co / bnr_part (optional, all or none; round 6): the BatchNorm-backward REDUCTION of the layer in front, fused
+ * into the store of C.  In the backward pass C is g = dL/dx with x = relu(batch_norm(y)) the input of this conv
+ * (lib/models/backbones/cheby_graph_conv.py:39, lib/models/meshnet.py:100), and the next step is p2m_bn_bwd_reduce over g
+ * and y.  With bnr_y = y [B, c_rows, N] and bnr_co = [4][N] (mean, invstd, scale, shift of that BatchNorm) every block sums
+ * g m and g m yhat (m = [y scale + shift > 0], yhat = (y - mean) invstd - the arithmetic of p2m_bn_bwd_reduce) over the
+ * rows it stores and writes bnr_part[slot][2][N], slot < p2m_cheb_tile_gemm_bnr_slots (0: this arithmetic / width has no
+ * fused reduction).  The fake-vertex rows of C come from another launch: p2m_bn_bwd_reduce_fake sums those, and
+ * p2m_bn_bwd_finalize takes both partial sets as one array.  Saves the stand-alone pass over g and y for the real rows.  */
 int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t g, int32_t plan, int32_t Ka, int32_t N);
+int32_t p2m_cheb_tile_gemm_bnr_slots(p2m_graph_t g, int32_t plan, int32_t arith, int32_t N, int32_t B);
 /* 1 when a p2m_cheb_tile_gemm launch of this arithmetic and output width forms the planes with the gather ON THE MATRIX
  * CORES (the tile's operator as a dense pre-sliced block, TilePlan::ltx / ltx3): P2M_ARITH_F16X2 (two scaled fp16 slices,
  * 4 samples per unit) and - round 5 - P2M_ARITH_BF16X3 (three exact bf16 slices of operator and operand, 2 samples per
@@ -364,8 +380,8 @@ int32_t p2m_cheb_tile_gemm_mg(int32_t arith, int32_t N);
 int p2m_cheb_tile_gemm(p2m_graph_t g, int32_t plan, const float* X, const float* A0, int32_t Ka, const void* Bx,
                        int32_t arith, const void* x_amax, const float* bias, const float* addend, float* C, int32_t N,
                        float* stats, float* E1, float* E2, const float* act_scale, const float* act_shift,
-                       int32_t act_relu, void* amax_out, const float* in_scale, const float* in_shift, int32_t B,
-                       void* stream);
+                       int32_t act_relu, void* amax_out, const float* in_scale, const float* in_shift,
+                       const float* bnr_y, const float* bnr_co, float* bnr_part, int32_t B, void* stream);
 /* Bound of x = max(fma(y, scale[f], shift[f]), 0) over a tensor y whose amax word is y_amax:
  *     atomic max of max_f fma(amax(y), |scale[f]|, max(shift[f], 0)) into the amax word `word`
  * (a true bound in fp32: fma and max are monotone) - the x_amax / a_amax of a consumer that applies the activation on

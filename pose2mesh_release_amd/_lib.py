@@ -53,7 +53,10 @@ HIP_SYMBOLS = {
     "p2m_cheb_tile_gemm_supported": (_i32, [_vp, _i32, _i32, _i32]),
     "p2m_cheb_tile_gemm_mg": (_i32, [_i32, _i32]),
     "p2m_cheb_tile_gemm": (_c.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
-                                      _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+                                      _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "p2m_cheb_tile_gemm_bnr_slots": (_i32, [_vp, _i32, _i32, _i32, _i32]),
+    "p2m_bn_bwd_blocks_fake": (_i32, [_vp, _i32, _i32]),
+    "p2m_bn_bwd_reduce_fake": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "p2m_act_bound": (_c.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "p2m_graph_plane_bits": (_i32, [_vp, _i32]),
     "p2m_amax": (_c.c_int, [_vp, _i64, _vp, _vp]),

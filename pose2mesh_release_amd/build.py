@@ -23,6 +23,22 @@ HIP_LIB = os.path.join(LIBDIR, "libp2m_hip.so")
 HOST_LIB = os.path.join(LIBDIR, "libp2m_host.so")
 
 
+def source_id():
+    """Content hash of what the HIP library is built from plus the host-side launch layer (12 hex digits): the identity of
+    `the running code` where there is no git (the GPU boxes get a snapshot without .git).  bench.py compares it with the id
+    stored in profiles/traffic_latest.json by tools/rocprof_traffic.sh and marks the PMC traffic figures stale when they
+    were measured on other code."""
+    import hashlib
+    h = hashlib.sha1()
+    names = [os.path.join(CSRC, n) for n in sorted(os.listdir(CSRC)) if n.endswith((".hip", ".h", ".cpp"))]
+    names += [os.path.normpath(os.path.join(CSRC, "..", "..", "include", "p2m.h"))]
+    names += [os.path.join(HERE, n) for n in ("ops.py", "meshnet.py", "posenet.py", "cheby_graph_conv.py", "optim.py", "loss.py")]
+    for n in names:
+        with open(n, "rb") as f:
+            h.update(os.path.basename(n).encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
+
+
 def _stale(target, sources):
     if not os.path.exists(target):
         return True
@@ -86,4 +102,7 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--source-id" in sys.argv:
+        print(source_id())
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

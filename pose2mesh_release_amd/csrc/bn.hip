@@ -1118,6 +1118,43 @@ extern "C" int p2m_bn_bwd_reduce(const float* gx, const float* y, const float* s
   return check_launch("bn_bwd_reduce");
 }
 
+// The reduction over the FAKE-vertex rows of a level only (its fake_ids: every fake vertex, or - with classes - the
+// representatives, which carry their class's summed gradient): the other half of a reduction whose real-vertex rows were
+// summed by the kernel that produced gx (p2m_cheb_tile_gemm, bnr_* arguments).
+static bool fake_map_of(p2m_graph_t gh, int32_t B, RowMap* m, long* Mlog) {
+  if (gh == nullptr || B <= 0) return false;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.n_fake <= 0 || (long)B * g.V >= (1LL << 32)) return false;
+  m->w = nullptr; m->ids = g.fake_ids; m->n = (unsigned)g.n_fake; m->V = (unsigned)g.V;
+  *Mlog = (long)B * g.n_fake;
+  return true;
+}
+extern "C" int32_t p2m_bn_bwd_blocks_fake(p2m_graph_t gh, int32_t B, int32_t F) {
+  RowMap m;
+  long Mlog;
+  if (!fake_map_of(gh, B, &m, &Mlog)) return 0;
+  return p2m_bn_bwd_blocks(Mlog, F);
+}
+extern "C" int p2m_bn_bwd_reduce_fake(p2m_graph_t gh, const float* gx, const float* y, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, int32_t relu,
+                                      float* part, int32_t B, int32_t F, void* stream) {
+  P2M_CHECK_ARG(gx && y && scale && shift && mean && invstd && part && F > 0, "null pointer or empty shape");
+  P2M_CHECK_ARG(F == 32 || F == 64 || F == 128 || F == 256, "F must be 32, 64, 128 or 256");
+  RowMap m;
+  long Mlog;
+  P2M_CHECK_ARG(fake_map_of(gh, B, &m, &Mlog), "the level has no fake vertices (or B * V does not fit 32 bits)");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = p2m_bn_bwd_blocks(Mlog, F);
+  const int rpb = bwd_rows_per_block(Mlog);
+  switch (F) {
+    case 32:  hipLaunchKernelGGL(k_bn_bwd_reduce<8>,  dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    case 64:  hipLaunchKernelGGL(k_bn_bwd_reduce<16>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    case 128: hipLaunchKernelGGL(k_bn_bwd_reduce<32>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+    default:  hipLaunchKernelGGL(k_bn_bwd_reduce<64>, dim3(grid), dim3(256), 0, s, gx, y, scale, shift, mean, invstd, relu, part, Mlog, m, rpb); break;
+  }
+  return check_launch("bn_bwd_reduce_fake");
+}
+
 extern "C" int p2m_bn_bwd_finalize(const float* part, int32_t nblk, int64_t M, float* dgamma, float* dbeta,
                                    float* coef, int32_t accumulate, int32_t F, void* stream) {
   P2M_CHECK_ARG(part && nblk > 0 && M > 0 && F > 0, "null pointer or empty shape");

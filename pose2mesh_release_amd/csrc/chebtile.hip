@@ -82,6 +82,16 @@ struct TileGemmArgs {
   long x_rows, a0_rows, c_rows;
   int act_relu, a0_shift, B, Ka, N, Npad, nset, gpb;
   int a0_in_x;                 // A0 is X and a row's own source row (row id >> a0_shift) is one of its union rows (plans 0, 1)
+  // BatchNorm-backward REDUCTION fused into the store of C (round 6; k_cheb_tile_gemm with the LDS-staged epilogue only).
+  // In the backward pass C is a gradient g = dL/dx with x = relu(batch_norm(y)) the input of this conv, i.e. the output of
+  // the conv in front of it (lib/models/backbones/cheby_graph_conv.py:39 + lib/models/meshnet.py:100): the next thing the
+  // backward does is sum_r g m and sum_r g m xhat over all rows (m = [y scale + shift > 0], xhat = (y - mean) invstd).  With
+  // bnr_y (that conv's raw output, C's shape) and bnr_co ([4][N]: mean, invstd, scale, shift) given, every block adds up
+  // its rows' terms while it copies the staged tile out (y comes in with the same 16-byte accesses) and writes
+  // bnr_part[logical block][2][N]; p2m_bn_bwd_finalize merges them with the partials of the fake-vertex rows.
+  const float* bnr_y;
+  const float* bnr_co;
+  float* bnr_part;
 };
 
 // MODE: what the epilogue does besides bias + store - compiled in, because an epilogue that tests addend / activation /
@@ -300,7 +310,10 @@ __device__ unsigned long long g_tile_trc[2][40][8];
 #endif
 // TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
 // the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
-template <int TM, int TN, int NPW, int MODE, int NS>
+// BNR: the BatchNorm-backward reduction fused into the copy-out (TileGemmArgs::bnr_*) - compiled in only for the launches
+// that ask for it: the kernel sits at its 168-register cap, and the first version (a run-time branch in every
+// instantiation) made the FORWARD launches 13 % slower through spills they never needed (gpurun bench, round 6).
+template <int TM, int TN, int NPW, int MODE, int NS, bool BNR = false>
 __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gemm(TileGemmArgs g) {
   typedef typename SliceFrag<NS>::type frag_t;
   constexpr int CT_AS_BYTES = ct_as_bytes(NS);
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   // B2 and the next image store) and ALL waves of the block copy whole rows out with 16-byte accesses (6 per lane; the addend
   // comes in with 16-byte loads).  Same values, same BatchNorm partials (they come from the registers, as before).
   constexpr int NCOL = WN * TN * 32;                    // columns of the block's output tile (= N)
-  constexpr bool LEPI = NS == 3 && TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4;
+  constexpr bool LEPI = NS == 3 && TN == 1 && CT_AS_BYTES >= CT_S * 32 * NCOL * 4 + (NT / 64) * 2 * NCOL * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
   unsigned short* As = reinterpret_cast<unsigned short*>(ct_smem);
   unsigned char* xs = ct_smem + CT_AS_BYTES;
@@ -390,34 +403,98 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
 
   // copy-out of the staged tile of sample group egrp by every thread of the block (LEPI): piece p = (sample, row, 16-byte column
   // group); a row of C is N * 4 contiguous bytes at (sample, vertex id of the tile row)
+  float bnr_run = 0.f;                        // threads t < 2 * NCOL: running sum of one (which, column) over the block's groups
   auto copy_out = [&](int egrp) {
     constexpr int C4 = NCOL / 4, NPIECE = CT_S * 32 * C4, NIT = (NPIECE + NT - 1) / NT;
-    const float* stg = reinterpret_cast<const float*>(ct_smem);
-    f32x4 v[NIT], ad[NIT];
-    long off[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; k++) {
+    static_assert(NT % C4 == 0, "a thread's column group is the same for all of its pieces");
+    float* stg = reinterpret_cast<float*>(ct_smem);
+    auto piece_off = [&](int k, int& lds_at) -> long {       // global element offset of piece k of this thread, or -1
       const int p = t + k * NT;
       const int c4 = p % C4, row = (p / C4) % 32, i = p / (C4 * 32);
       const int vid = p < NPIECE ? rowvid[row] : -1;
       const int b = egrp * CT_S + i;
-      off[k] = (vid >= 0 && b < g.B) ? ((long)b * g.c_rows + vid) * g.N + c4 * 4 : -1;
-      if (off[k] >= 0) {
-        v[k] = *reinterpret_cast<const f32x4*>(stg + (i * 32 + row) * NCOL + c4 * 4);
-        if (MODE == CT_ADDEND) ad[k] = *reinterpret_cast<const f32x4*>(g.addend + off[k]);
+      lds_at = (i * 32 + row) * NCOL + c4 * 4;
+      return (vid >= 0 && b < g.B) ? ((long)b * g.c_rows + vid) * g.N + c4 * 4 : -1;
+    };
+    {
+      f32x4 v[NIT], ad[NIT];
+      long off[NIT];
+      int at[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        off[k] = piece_off(k, at[k]);
+        if (off[k] >= 0) {
+          v[k] = *reinterpret_cast<const f32x4*>(stg + at[k]);
+          if (MODE == CT_ADDEND) ad[k] = *reinterpret_cast<const f32x4*>(g.addend + off[k]);
+        }
+      }
+      float vmax = 0.f;
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        if (off[k] >= 0) {
+          if (MODE == CT_ADDEND) {
+            v[k] += ad[k];
+            if (BNR) *reinterpret_cast<f32x4*>(stg + at[k]) = v[k];      // (the reduction pass below re-reads the FINAL value)
+          }
+          *reinterpret_cast<f32x4*>(g.C + off[k]) = v[k];
+#pragma unroll
+          for (int c = 0; c < 4; c++) vmax = fmaxf(vmax, amax_abs(v[k][c]));
+        }
+      }
+      if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
+    }
+    if constexpr (BNR) {
+      // Second pass over the thread's own pieces (its own LDS words: no barrier in between): y comes in with the same
+      // 16-byte accesses, g from the staged tile - kept apart from the store pass so that its registers (24 for y) are not
+      // live beside v / addend / offsets in a kernel at its register cap.  The arithmetic of k_bn_bwd_reduce (csrc/bn.hip).
+      f32x4 yq[NIT];
+      int at[NIT];
+      bool ok[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        const long o = piece_off(k, at[k]);
+        ok[k] = o >= 0;
+        if (ok[k]) yq[k] = *reinterpret_cast<const f32x4*>(g.bnr_y + o);
+      }
+      const int c = (t % C4) * 4;
+      const f32x4 bmu = *reinterpret_cast<const f32x4*>(g.bnr_co + c);
+      const f32x4 bis = *reinterpret_cast<const f32x4*>(g.bnr_co + g.N + c);
+      const f32x4 bsc = *reinterpret_cast<const f32x4*>(g.bnr_co + 2 * g.N + c);
+      const f32x4 bsh = *reinterpret_cast<const f32x4*>(g.bnr_co + 3 * g.N + c);
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+      for (int k = 0; k < NIT; k++) {
+        if (ok[k]) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(stg + at[k]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float gm = fmaf(yq[k][e], bsc[e], bsh[e]) <= 0.f ? 0.f : gv[e];
+            s0[e] += gm;
+            s1[e] = fmaf(gm, (yq[k][e] - bmu[e]) * bis[e], s1[e]);
+          }
+        }
+      }
+      // lanes that share a column group (lane % C4) first, then the 12 waves through the LDS behind the staged tile
+      float* red = stg + CT_S * 32 * NCOL;                                     // [NT / 64][2][NCOL]
+#pragma unroll
+      for (int o = 32; o >= C4; o >>= 1)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          s0[e] += __shfl_xor(s0[e], o);
+          s1[e] += __shfl_xor(s1[e], o);
+        }
+      if (lane < C4) {
+        *reinterpret_cast<f32x4*>(red + ((t >> 6) * 2 + 0) * NCOL + lane * 4) = s0;
+        *reinterpret_cast<f32x4*>(red + ((t >> 6) * 2 + 1) * NCOL + lane * 4) = s1;
+      }
+      lds_block_barrier();
+      if (t < 2 * NCOL) {
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) a += red[wv * 2 * NCOL + t];
+        bnr_run += a;
       }
     }
-    float vmax = 0.f;
-#pragma unroll
-    for (int k = 0; k < NIT; k++) {
-      if (off[k] >= 0) {
-        if (MODE == CT_ADDEND) v[k] += ad[k];
-        *reinterpret_cast<f32x4*>(g.C + off[k]) = v[k];
-#pragma unroll
-        for (int c = 0; c < 4; c++) vmax = fmaxf(vmax, amax_abs(v[k][c]));
-      }
-    }
-    if (g.amax_out != nullptr) amax_commit(g.amax_out, vmax);
   };
 
   if (producer) {
@@ -573,18 +650,15 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
           for (int sl = 0; sl < NS; sl++) *reinterpret_cast<u32x2*>(d + sl * CT_SLICE + p * CT_CF) = sp[ps][p][sl];
       }
       P2M_TRC(0, w, 3);
-      lds_block_barrier();                              // B1(w): image of unit w visible - the MFMA waves go; everything
-                                                        //        below runs under their MFMAs, not in front of them
-      P2M_TRC(0, w, 4);
       if (w + 1 < nunits) {
-        store_xs();                                     // xs(w + 1) from the registers loaded a unit ago
+        store_xs();                                     // xs(w + 1) from the registers loaded a unit ago (xs(w) is free: B2)
         load_p0();
         if (w + 2 < nunits) load_union();
       }
       if (++fc == nchunks) { fc = 0; grp++; }
+      P2M_TRC(0, w, 4);
+      lds_block_barrier();                              // B1(w): image of unit w AND xs(w + 1) visible
       P2M_TRC(0, w, 5);
-      lds_block_barrier();                              // B3(w): xs(w + 1) visible to every producer (the MFMA waves pass
-                                                        //        it between two of their k-steps)
       P2M_TRC(0, w, 6);
     }
     if (LEPI) {                                         // the last unit's tile
@@ -695,8 +769,6 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         }
 #undef P2M_PAIR
         __builtin_amdgcn_sched_barrier(0);
-        if (st == 1) lds_block_barrier();               // B3(w): the producers' xs stores for unit w + 1 (not ours to wait
-                                                        //        for, but s_barrier is block-wide)
       }
       P2M_TRC(1, w, 3);
       if (fc == nchunks - 1) {
@@ -711,6 +783,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
       stage_acc();
       lds_block_barrier();                              // E1
       copy_out(grp - 1);
+      if (BNR && t < 2 * NCOL) g.bnr_part[(long)lid * 2 * g.N + t] = bnr_run;
     }
   }
 }
@@ -1596,24 +1669,34 @@ static int pick_gpb(int ntiles, int ngroups, int gpb_max = 8) {
   return gpb;
 }
 
-template <int TM, int TN, int NPW, int MODE, int NS>
+template <int TM, int TN, int NPW, int MODE, int NS, bool BNR = false>
 static int launch_tile_gemm_mode(const TileGemmArgs& a, hipStream_t s) {
   constexpr int LDS_BYTES = ct_lds_bytes(NS);
   static DeviceOnce attr_set;       // once per DEVICE and instantiation (never inside a stream capture: the first call
                                     // of every shape happens in the eager warm-up steps)
   if (const int rc = attr_set.run([] {
-        return hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>,
+        return hipFuncSetAttribute((const void*)k_cheb_tile_gemm<TM, TN, NPW, MODE, NS, BNR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       }, "p2m_cheb_tile_gemm", LDS_BYTES))
     return rc;
   const int ngroups = cdiv(a.B, CT_S);
   const int nblocks = cdiv((long)a.pl.ntiles * cdiv(ngroups, a.gpb), 8) * 8;
-  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE, NS>), dim3(nblocks), dim3(256 + 64 * NPW), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_cheb_tile_gemm<TM, TN, NPW, MODE, NS, BNR>), dim3(nblocks), dim3(256 + 64 * NPW), LDS_BYTES, s, a);
   return check_launch("cheb_tile_gemm");
 }
 
 template <int TM, int TN, int NPW, int NS>
 static int launch_tile_gemm_ns(const TileGemmArgs& a, hipStream_t s) {
+  if constexpr (NS == 3 && TN == 1) {       // the fused BatchNorm-backward reduction: backward launches (no stats, no activation)
+    if (a.bnr_y != nullptr) {
+      if (a.stats != nullptr || a.act_scale != nullptr || a.act_relu) {
+        set_error("p2m_cheb_tile_gemm: bnr_* excludes stats and the fused activation");
+        return P2M_ERR_INVALID;
+      }
+      if (a.addend != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_ADDEND, NS, true>(a, s);
+      return launch_tile_gemm_mode<TM, TN, NPW, CT_PLAIN, NS, true>(a, s);
+    }
+  }
   if (a.stats != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_STATS, NS>(a, s);
   if (a.addend != nullptr) return launch_tile_gemm_mode<TM, TN, NPW, CT_ADDEND, NS>(a, s);
   if (a.act_scale != nullptr || a.act_relu) return launch_tile_gemm_mode<TM, TN, NPW, CT_ACT, NS>(a, s);
@@ -1715,12 +1798,28 @@ extern "C" int32_t p2m_cheb_tile_gemm_supported(p2m_graph_t gh, int32_t plan, in
   return (N == 64 || N == 128 || N == 256) ? 1 : 0;
 }
 
+// Partial-sum slots a launch with the fused BatchNorm-backward reduction writes (bnr_part: [slots][2][N]), or 0 when this
+// (arithmetic, width) does not take the kernel that has it (k_cheb_tile_gemm with the LDS-staged epilogue: three bf16
+// slices, N <= 128, the VALU gather)
+extern "C" int32_t p2m_cheb_tile_gemm_bnr_slots(p2m_graph_t gh, int32_t plan, int32_t arith, int32_t N, int32_t B) {
+  if (!gh || plan < 0 || plan > 2 || B <= 0) return 0;
+  const Graph& g = *reinterpret_cast<const Graph*>(gh);
+  if (g.plan[plan].ntiles <= 0 || arith != P2M_ARITH_BF16X3 || (N != 64 && N != 128) || mg_exact() || tile_v2()) return 0;
+  const int ngroups = cdiv(B, CT_S);
+  return g.plan[plan].ntiles * cdiv(ngroups, pick_gpb(g.plan[plan].ntiles, ngroups));
+}
+
 extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, const float* A0, int32_t Ka,
                                   const void* Bx, int32_t arith, const void* x_amax, const float* bias,
                                   const float* addend, float* C, int32_t N, float* stats, float* E1, float* E2,
                                   const float* act_scale, const float* act_shift, int32_t act_relu, void* amax_out,
-                                  const float* in_scale, const float* in_shift, int32_t B, void* stream) {
+                                  const float* in_scale, const float* in_shift, const float* bnr_y, const float* bnr_co,
+                                  float* bnr_part, int32_t B, void* stream) {
   P2M_CHECK_ARG(gh && X && A0 && Bx && C, "null pointer");
+  P2M_CHECK_ARG((bnr_y == nullptr) == (bnr_co == nullptr) && (bnr_y == nullptr) == (bnr_part == nullptr),
+                "bnr_y / bnr_co / bnr_part must all be given or all NULL");
+  P2M_CHECK_ARG(bnr_y == nullptr || p2m_cheb_tile_gemm_bnr_slots(gh, plan, arith, N, B) > 0,
+                "the fused BatchNorm-backward reduction is not available for this launch (p2m_cheb_tile_gemm_bnr_slots)");
   P2M_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must both be given or both NULL");
   P2M_CHECK_ARG(in_scale == nullptr || E1 == nullptr, "activation on load excludes the planes out");
   P2M_CHECK_ARG(arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "arith must be P2M_ARITH_BF16X3 or P2M_ARITH_F16X2");
@@ -1762,6 +1861,9 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
   a.c_rows = paired ? g.V / 2 : g.V;
   a.a0_shift = plan == 1 ? 1 : 0;
   a.a0_in_x = (A0 == X && !paired) ? 1 : 0;
+  a.bnr_y = bnr_y;
+  a.bnr_co = bnr_co;
+  a.bnr_part = bnr_part;
   a.B = B;
   a.Ka = Ka;
   a.N = N;

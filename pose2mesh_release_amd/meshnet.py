@@ -424,6 +424,8 @@ class _MeshNetFn(torch.autograd.Function):
                     self.cm.__exit__(*a)
                 return False
         Gs_block = None    # S G of the current block (pair-sum of the gradient w.r.t. the block output), when produced
+        bnr_pending = None  # (graph, partial sums, fake blocks): the real-row half of the NEXT layer's BatchNorm-backward
+                            # reduction, summed by the kernel that produced g_cur (ops.cheb_tile_gemm bnr=; round 6)
         for L in reversed(net._layers):
             gph = graphs[L.graph]
             M = B * gph.V
@@ -534,7 +536,8 @@ class _MeshNetFn(torch.autograd.Function):
                 tg = tgt(f"bn.{L.ci}.weight", f"bn.{L.ci}.bias")
                 kw = dict(dgamma=tg[0], dbeta=tg[1]) if tg is not None else {}
                 res = ops.bn_relu_bwd(g_cur, y, co, gamma, True, training, M, L.Fout, pair_in=want_Gs,
-                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, **kw)
+                                      pair_out=want_P0, classes=gph, zero_holes=not gph.split, real_part=bnr_pending, **kw)
+                bnr_pending = None
                 gy = res[0]
                 if tg is None:
                     grads[P[f"bn.{L.ci}.weight"]], grads[P[f"bn.{L.ci}.bias"]] = res[1], res[2]
@@ -584,8 +587,19 @@ class _MeshNetFn(torch.autograd.Function):
                 opb = cws.bwd(L.ci, Wl) if (cws is not None and L.ci in cws.images) else wc.get(
                     (L.ci, "split_bwd"), Wl, lambda: ops.split_operands(W2, L.Fout, L.Fin, gph.fake_a, gph.fake_b,
                                                                       wc.get((L.ci, "amax"), Wl, lambda: ops.param_amax(Wl))))
+                # dXf of a block's SECOND conv is exactly the gradient the first conv's BatchNorm backward reduces next (no
+                # residual, no un-pool in between): its real rows are summed while the tile kernel stores them
+                bnr = None
+                if not L.first_in_block and not x_shift and L.ci > 0:
+                    Lp, sp = net._layers[L.ci - 1], saved[L.ci - 1]
+                    if Lp.has_bn and Lp.graph == L.graph and sp is not None and sp[5] is not None \
+                            and ops.tile_gemm_ok(gph, 0, L.Fout, L.Fin, True, B=B):
+                        pr = ops.bnr_parts(gph, 0, L.Fin, B, gy.device)
+                        if pr is not None:
+                            bnr = (sp[4], sp[5], pr[0][pr[1]:])
+                            bnr_pending = (gph, pr[0], pr[1])
                 E1, E2, _, _, _ = ops.conv_split(gph, B, gy, L.Fout, 0, W2, None, add, dXf, L.Fin, gph.fake_a,
-                                                 gph.fake_b, operands=opb)
+                                                 gph.fake_b, operands=opb, bnr=bnr)
                 dX = ops.pair_sum(dXf, M >> 1, L.Fin) if x_shift else dXf
                 # the weight gradient is off the critical path (nothing downstream in backward reads it): it runs on
                 # a side stream, so its MFMA work overlaps the HBM-bound BatchNorm / basis passes of the next layers

@@ -126,6 +126,11 @@ CLASSES = _os.environ.get("P2M_CLASSES", "1") == "1"
 # projection) and its weight gradients read the raw y and apply fma + max on the way into LDS.  0 = the separate pass (A/B form).
 FOLD_ACT = _os.environ.get("P2M_FOLD_ACT", "1") == "1"
 TILE_GEMM = _os.environ.get("P2M_TILE_GEMM", "auto")
+# Round 6: the BatchNorm-backward reduction of a block's first conv summed by the kernel that produces its incoming
+# gradient (the dX tile kernel of the block's second conv) instead of a stand-alone pass over g and y; 0: the separate pass
+# (opt-in: same-box A/B at B = 256 - 43.44 / 43.39 ms fused vs 43.33 / 43.37 separate: the planes-out tile kernels grow by
+# what the stand-alone reduce passes cost, 0.73 vs ~0.8 ms)
+BN_FUSE = _os.environ.get("P2M_BN_FUSE", "0") == "1"
 if TILE_GEMM not in ("auto", "0", "1"):
     raise ValueError(f"P2M_TILE_GEMM must be auto, 0 or 1, not {TILE_GEMM!r}")
 TILE_GEMM_MG_MIN_ROWS = 300    # "auto", f16x2 and N <= 128: every split level with a 128- or 64-wide output (SMPL-like: 6890,
@@ -750,12 +755,22 @@ def tile_gemm_ok(g, plan, Ka, N, want_planes=False, B=None):
     return not want_planes and g.n_real >= TILE_GEMM_MIN_ROWS and (B is None or B >= TILE_GEMM_MIN_BATCH)
 
 
+def tile_bnr_slots(g, plan, N, B):
+    """Partial-sum slots of the BatchNorm-backward reduction fused into p2m_cheb_tile_gemm (bnr=...), 0: not available for
+    the current arithmetic / this width (include/p2m.h)."""
+    if not BN_FUSE or GEMM_ARITH == "f32":
+        return 0
+    return int(_lib.hip().p2m_cheb_tile_gemm_bnr_slots(g.handle, plan, arith_code(), N, B))
+
+
 def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, want_planes=False, act=None,
-                   amax=None, amax_out=None, in_act=None):
+                   amax=None, amax_out=None, in_act=None, bnr=None):
     """C[rows of the plan] = [A0 | L X | L2 X] W (+bias)(+addend) in one kernel (include/p2m.h).  Returns
     (stats [B*ntiles, 2, N] or None, (E1, E2) compact planes or None).  f16x2: amax = the word bounding X and A0 (default:
     X's own); amax_out: a zeroed word that receives the bound of what is stored.  in_act = (scale[Ka], shift[Ka]):
-    activation on load - X / A0 hold a raw conv output y, the operand is relu(y * scale + shift); amax must bound THAT."""
+    activation on load - X / A0 hold a raw conv output y, the operand is relu(y * scale + shift); amax must bound THAT.
+    bnr = (y [B*c_rows, N], co [4, N], part [slots, 2, N]): the BatchNorm-backward reduction of the layer in front over the
+    rows this launch stores, written to `part` (tile_bnr_slots(g, plan, N, B) slots)."""
     nset = g.n_pair_real if plan == 2 else g.n_real
     if in_act is not None and amax is None and f16x2():
         raise P2MError("cheb_tile_gemm: activation on load needs the amax word of the activated operand (act_bound)")
@@ -775,7 +790,10 @@ def cheb_tile_gemm(g, plan, X, A0, Ka, Bx, bias, addend, C, N, B, stats=False, w
                                             _p(E1), _p(E2), _p(None if act is None else act[0]),
                                             _p(None if act is None else act[1]), int(bool(act and act[2])),
                                             _p(amax_out), _p(None if in_act is None else _req(in_act[0], "in_scale")),
-                                            _p(None if in_act is None else _req(in_act[1], "in_shift")), B, _stream()),
+                                            _p(None if in_act is None else _req(in_act[1], "in_shift")),
+                                            _p(None if bnr is None else _req(bnr[0], "bnr_y")),
+                                            _p(None if bnr is None else _req(bnr[1], "bnr_co")),
+                                            _p(None if bnr is None else bnr[2]), B, _stream()),
               "p2m_cheb_tile_gemm")
     return st, ((E1, E2) if want_planes else None)
 
@@ -839,7 +857,7 @@ def act_bound(scale, shift, y_amax, word):
 
 
 def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, stats=False, operands=None, want_planes=True,
-               amax_out=None, in_act=None):
+               amax_out=None, in_act=None, bnr=None):
     """One split contraction: the real-vertex rows [X | L X | L2 X] Bm (K = 3*Ka), then the fake-vertex GEMM (K = Ka,
     W0 + a*W1 + b*W2).  All on the current stream: running the fake-vertex GEMM or half of the batch's basis on a side
     stream was measured neutral (DESIGN.md "Streams").  Returns (T1c, T2c, st_real, st_fake, tiled): the compact basis
@@ -866,9 +884,11 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
         st2 = gemm_planes_rows(g, 2, B, [X], Ka, 0, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
                                amax_out=amax_out, in_act=in_act)
         return None, None, st1, st2, tiled
+    if bnr is not None and not (in_act is None and tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B)):
+        raise P2MError("conv_split: bnr needs the tile kernel (tile_bnr_slots > 0 and tile_gemm_ok)")
     if tile_gemm_ok(g, a0_shift, Ka, N, want_planes, B=B):
         st1, planes = cheb_tile_gemm(g, a0_shift, X, X, Ka, Bx, bias, addend, C, N, B, stats=stats,
-                                     want_planes=want_planes, amax=xa, amax_out=amax_out)
+                                     want_planes=want_planes, amax=xa, amax_out=amax_out, bnr=bnr)
         st2 = gemm_planes_rows(g, 2, B, [X], Ka, a0_shift, False, We, bias, addend, C, N, stats, Bx=Wex, amax=xa,
                                amax_out=amax_out)
         T1c, T2c = planes if planes is not None else (None, None)
@@ -1097,24 +1117,47 @@ def bn_act_fwd(y, co, relu, resid, Fres, res_shift, M, F, classes=None, real_row
     return x
 
 
+def bnr_parts(g, plan, N, B, device):
+    """The partial-sum array of a BatchNorm-backward reduction split between the tile kernel (real-vertex rows, slots
+    [nfake:]) and p2m_bn_bwd_reduce_fake (slots [:nfake]), or None when the fused form is not available."""
+    slots = tile_bnr_slots(g, plan, N, B)
+    if slots <= 0:
+        return None
+    nfake = int(_lib.hip().p2m_bn_bwd_blocks_fake(g.handle, B, N)) if g.n_fake > 0 else 0
+    part = torch.empty((nfake + slots, 2, N), device=device, dtype=torch.float32)
+    return part, nfake
+
+
 def bn_relu_bwd(gx, y, co, gamma, relu, training, M, F, dgamma=None, dbeta=None, pair_in=False, pair_out=False,
-                classes=None, zero_holes=False):
+                classes=None, zero_holes=False, real_part=None):
     """Returns (gy, dgamma, dbeta).  dgamma/dbeta given: ACCUMULATE into them (the parameters' .grad).
     pair_in / pair_out: also return the pair-sums [M/2, F] of gx / of gy as by-products of the apply pass:
     (gy, dgamma, dbeta, pair_gx or None, pair_gy or None).
     classes: the level's DeviceGraph (include/p2m.h "classes"): holes are skipped -- not read, not written; zero_holes:
-    the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows)."""
+    the outputs are zero there instead of undefined (levels whose other kernels walk ALL rows).
+    real_part = (g, part [nfake + slots, 2, F], nfake): the real-vertex rows of the reduction were already summed into
+    part[nfake:] by the kernel that produced gx (cheb_tile_gemm bnr=); only the fake-vertex rows are reduced here."""
     lib = _lib.hip()
     cls = classes.handle if (classes is not None and classes.classes) else None
-    nblk = int(lib.p2m_bn_bwd_blocks(M, F) if cls is None else lib.p2m_bn_bwd_blocks_classes(cls, M, F))
-    part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
+    if real_part is not None:
+        gfr, part, nfake = real_part
+        nblk = part.shape[0]
+    else:
+        nblk = int(lib.p2m_bn_bwd_blocks(M, F) if cls is None else lib.p2m_bn_bwd_blocks_classes(cls, M, F))
+        part = torch.empty((nblk, 2, F), device=y.device, dtype=torch.float32)
     acc = 1 if dgamma is not None else 0
     if dgamma is None:
         dgb = torch.empty((2, F), device=y.device, dtype=torch.float32)
         dgamma, dbeta = dgb[0], dgb[1]
     coef = torch.empty((2, F), device=y.device, dtype=torch.float32)
-    check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
-                                int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
+    if real_part is not None:
+        if nfake > 0:
+            check(lib.p2m_bn_bwd_reduce_fake(gfr.handle, _p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]),
+                                             _p(co[1]), int(relu), _p(part), M // gfr.V, F, _stream()),
+                  "p2m_bn_bwd_reduce_fake")
+    else:
+        check(lib.p2m_bn_bwd_reduce(_p(_req(gx, "gx")), _p(_req(y, "y")), _p(co[2]), _p(co[3]), _p(co[0]), _p(co[1]),
+                                    int(relu), _p(part), M, F, cls, _stream()), "p2m_bn_bwd_reduce")
     check(lib.p2m_bn_bwd_finalize(_p(part), nblk, M, _p(dgamma), _p(dbeta), _p(coef), acc, F, _stream()),
           "p2m_bn_bwd_finalize")
     gy = torch.empty((M, F), device=y.device, dtype=torch.float32)      # (zero_holes: the pass itself stores the zeros)

@@ -25,12 +25,23 @@ def run(joint_set, B, mode, wseed, xseed, gseed, keep_on_gpu=False, tap=False):
     x = helpers.meshnet_input(B, J, seed=xseed).cuda().requires_grad_(True)
     if tap:
         net._tap = []
+    from pose2mesh_release_amd import ops
+    fused = [0]
+    real_bwd = ops.bn_relu_bwd
+
+    def counting_bwd(*a, **kw):                  # how many BatchNorm-backward reductions took the fused real-row half
+        fused[0] += kw.get("real_part") is not None
+        return real_bwd(*a, **kw)
+    ops.bn_relu_bwd = counting_bwd
     y = net(x)
     w = torch.randn(y.shape, generator=torch.Generator().manual_seed(gseed)).cuda()
     (y * w).sum().backward()
     torch.cuda.synchronize()
+    ops.bn_relu_bwd = real_bwd
     conv = (lambda t: t.detach()) if keep_on_gpu else (lambda t: t.detach().cpu().numpy())
     out = {"out": conv(y), "grad::__input__": conv(x.grad)}
+    if not keep_on_gpu:
+        out["meta::bnr_fused"] = np.asarray(fused[0])
     for k, p in net.named_parameters():
         out[f"grad::{k}"] = conv(p.grad)
     for k, v in net.state_dict().items():

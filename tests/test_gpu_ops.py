@@ -745,6 +745,54 @@ def test_basis_inside_the_contraction_matches_basis_plus_contraction(ops, monkey
     assert err < 2e-5 * max(1.0, yd.abs().max().item()), err
 
 
+@pytest.mark.parametrize("V,Fin,Fout,B,addend", [(736, 128, 128, 5, False), (1472, 128, 64, 9, True), (2944, 64, 128, 4, True)])
+def test_tile_kernel_sums_the_next_batchnorm_backward_reduction(ops, monkeypatch, V, Fin, Fout, B, addend):
+    """p2m_cheb_tile_gemm bnr_* (round 6): while the kernel copies its staged output tile g out it sums g m and g m yhat
+    (m = [y scale + shift > 0], yhat = (y - mean) invstd) over the rows it stores; with p2m_bn_bwd_reduce_fake for the
+    fake-vertex rows and p2m_bn_bwd_finalize over both partial sets this IS ops.bn_relu_bwd (d gamma, d beta, g_y) - against
+    the stand-alone pass on the same g and against a float64 sum.  B is not a multiple of the 4-sample groups."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", "bf16x3")
+    monkeypatch.setattr(ops, "TILE_GEMM", True)
+    monkeypatch.setattr(ops, "BN_FUSE", True)
+    L = _band_graph(V, 11 + V)
+    g = ops.DeviceGraph(L, "cuda:0")
+    assert g.plan_tiles[0] > 0 and ops.tile_bnr_slots(g, 0, Fout, B) > 0
+    gen = torch.Generator().manual_seed(V + Fin)
+    M = B * V
+    X = torch.randn(M, Fin, generator=gen).cuda()
+    Wt = (torch.randn(3 * Fin, Fout, generator=gen) / (3 * Fin) ** 0.5).cuda()
+    add = torch.randn(M, Fout, generator=gen).cuda() if addend else None
+    y = torch.randn(M, Fout, generator=gen).cuda()                       # raw output of the conv in front
+    gamma, beta = (torch.rand(Fout, generator=gen) + 0.5).cuda(), torch.randn(Fout, generator=gen).cuda()
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    co = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    Bx = ops.weight_split(Wt)
+    We = ops.weight_eff(Wt, Fin, Fout, g.fake_a, g.fake_b)
+    part, nfake = ops.bnr_parts(g, 0, Fout, B, X.device)
+    part.fill_(float("nan"))                                             # every slot must be written
+    C = torch.zeros(M, Fout, device="cuda")
+    ops.cheb_tile_gemm(g, 0, X, X, Fin, Bx, None, add, C, Fout, B, want_planes=True, bnr=(y, co, part[nfake:]))
+    ops.gemm_planes_rows(g, 2, B, [X], Fin, 0, False, We, None, add, C, Fout, False)       # the fake-vertex rows of C
+    res = ops.bn_relu_bwd(C, y, co, gamma, True, True, M, Fout, real_part=(g, part, nfake))
+    ref = ops.bn_relu_bwd(C, y, co, gamma, True, True, M, Fout)
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    # float64 sums over all rows
+    m = (y.double() * co[2].double() + co[3].double()) > 0
+    gm = torch.where(m, C.double(), torch.zeros_like(C, dtype=torch.float64))
+    dbeta64 = gm.sum(0)
+    dgamma64 = (gm * ((y.double() - mean.double()) * invstd.double())).sum(0)
+    for got, r64, r32 in ((res[2], dbeta64, ref[2]), (res[1], dgamma64, ref[1])):
+        scale = float(r64.abs().max())
+        assert float((got.double() - r64).abs().max()) <= 2e-5 * scale
+        assert float((r32.double() - r64).abs().max()) <= 2e-5 * scale
+    assert float((res[0] - ref[0]).abs().max()) <= 1e-5 * float(ref[0].abs().max())
+    with pytest.raises(Exception):                                       # N = 256 has no fused form
+        ops.cheb_tile_gemm(g, 0, X, X, Fin, ops.weight_split(torch.randn(3 * Fin, 256).cuda()), None, None,
+                           torch.zeros(M, 256, device="cuda"), 256, B, bnr=(y, co, part[nfake:]))
+
+
 def test_exact_matrix_core_gather_in_a_subprocess(hip_libs):
     """Round 5: k_cheb_mg_gemm in the three-bf16-slice arithmetic (operator block and operands as exact bf16 triples, 2 samples
     per unit) is opt-in - P2M_MG_EXACT=1, read once per process by the library - because it only ties the VALU-gather kernel

@@ -43,9 +43,9 @@ V2 = os.environ.get("P2M_TILE_V2", "1") != "0" and N <= 128 and ops.GEMM_ARITH =
 if V2:       # k_cheb_tile_gemm_v2 (round 6): stamps 0 head, 1 half 0 gathered, 2 past MID, 3 half 1 gathered, 4 past B2, 5 image stored, 6 past B1
     print("producer wave:  unit | gather + split h0 | wait MID | gather + split h1 | wait B2 | (copy-out of the closed group +) "
           "image store | wait B1 | unit total")
-else:
-    print("producer wave:  unit | gather+split | wait B2 | (copy-out of the closed group +) image store | wait B1 | xs store + loads | "
-          "wait B3 | unit total")
+else:        # k_cheb_tile_gemm since round 6 (two barriers per unit): 0 head, 1 gathered, 2 past B2, 3 image stored, 4 xs stored + loads issued, 5 past B1
+    print("producer wave:  unit | gather+split | wait B2 | (copy-out of the closed group +) image store | xs store + loads | wait B1 | "
+          "- | unit total")
 tot = np.zeros(7)
 for w in range(nu):
     d = [p[w, 1] - p[w, 0], p[w, 2] - p[w, 1], p[w, 3] - p[w, 2], p[w, 4] - p[w, 3], p[w, 5] - p[w, 4], p[w, 6] - p[w, 5]]

@@ -18,9 +18,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_${TAG}_$C
   timeout -k 5 ${PMC_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/tr_${TAG}_$C -o $TAG -- python "$REPO/bench.py" $ARGS > "$REPO/gpurun_out/${TAG}_traffic_$C.log" 2>&1
 done
-python3 - "$TAG" "$REPO/gpurun_out/${TAG}_traffic.json" "$ARGS" <<'PY'
+CODE_ID=$(cd "$REPO" && python3 -m pose2mesh_release_amd.build --source-id 2>/dev/null | tail -1)
+python3 - "$TAG" "$REPO/gpurun_out/${TAG}_traffic.json" "$ARGS" "$CODE_ID" <<'PY'
 import csv, glob, json, sys, collections
-tag, out, args = sys.argv[1:4]
+tag, out, args, code_id = sys.argv[1:5]
 rec = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0], "dur": [0.0, 0]})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"/tmp/tr_{tag}_{c}/**/*counter_collection.csv", recursive=True)
@@ -53,7 +54,7 @@ for k, v in rec.items():
     kern[k] = {"launches": n, "fetch_bytes_avg": fetch, "write_bytes_avg": write, "hbm_bytes_per_launch": fetch + write,
                "total_hbm_bytes": (fetch + write) * n,
                "avg_duration_ns": v["dur"][0] / v["dur"][1] if v["dur"][1] else None}
-json.dump({"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python bench.py {args}",
+json.dump({"code_id": code_id, "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python bench.py {args}",
            "note": "fetch_bytes_avg already carries the x2 gfx950 correction of MI355X_MICROARCH.md (HBM section)",
            "kernels": kern}, open(out, "w"), indent=1, sort_keys=True)
 top = sorted(kern.items(), key=lambda kv: -kv[1]["total_hbm_bytes"])[:25]
