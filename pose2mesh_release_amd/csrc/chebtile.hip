@@ -372,6 +372,26 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     rowoff[t] = po;                           // rows >= R: empty
     rawoff[t] = ro;
   }
+  // Round 6: BALANCED row assignment of the gather.  A producer wave gathers two rows at a time (its two half-waves), for as
+  // many 4-entry blocks as the LONGER of the two has, and the block waits at B2 for its slowest wave: with the rows dealt out
+  // in tile order the traced wave waited 2 200 of a unit's 12 800 cycles there (profiles/r06_tile_phase_trace_two_barriers.txt).
+  // Rows sorted by length, neighbours of the sorted order paired (equal lengths share a wave pass), pairs dealt to the
+  // waves in snake order (wave w: pairs w and 2 NPW - 1 - w, ...): every wave gets the same number of blocks to within one row.
+  int* rowsel = rawoff + 40;                  // [32] slot (pass * RPP + wave * 2 + half) -> tile row
+  if (t >= 64 && t < 96) {                    // 32 lanes of the second wave (the first is busy above): rank sort, one row each
+    const int r = t - 64;
+    const int len = rowlen[r];
+    int rank = 0;
+#pragma unroll 8
+    for (int q = 0; q < 32; q++) {
+      const int lq = rowlen[q];
+      rank += (lq > len || (lq == len && q < r)) ? 1 : 0;
+    }
+    const int pr = rank >> 1;                 // pair pr = sorted rows 2 pr, 2 pr + 1 -> (pass, wave) in snake order
+    const int ps = pr / NPW, k = pr % NPW;
+    const int wv = (ps & 1) ? NPW - 1 - k : k;
+    rowsel[ps * RPP + wv * 2 + (rank & 1)] = r;
+  }
   __syncthreads();
   {
     const int e0 = pl.erow[r0];
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     //  below keeps the idea.)
 #pragma unroll
     for (int ps = 0; ps < NRP; ps++) {
-      ri[ps] = ps * RPP + pw * 2 + rlo;
+      ri[ps] = rowsel[ps * RPP + pw * 2 + rlo];
       const int vid = rowvid[ri[ps]];
       a0off[ps] = (unsigned)((vid < 0 ? 0 : vid) >> g.a0_shift) * (unsigned)(g.Ka * 4);
     }
