@@ -301,12 +301,20 @@ __device__ __forceinline__ void tile_epilogue(const TileGemmArgs& g, const TileP
 // Probe build only (tools/tile_trace.sh, tools/probes/tile_trace_probe.py): s_memtime stamps of one producer wave and one MFMA
 // wave of one block at the phase boundaries of every unit.  [role][unit][event]
 __device__ unsigned long long g_tile_trc[2][40][8];
+// ... and, per WAVE of that block, the stamps at the head of a unit and where the wave arrives at B2 (the end of its gather /
+// of its k-steps): which wave is the block waiting for?   [wave][unit][0 head, 1 arrival at B2]
+__device__ unsigned long long g_tile_trw[12][40][2];
 #define P2M_TRC(role, w, ev)                                                                          \
   do {                                                                                                \
     if (trc_on && (w) < 40) g_tile_trc[role][w][ev] = __builtin_amdgcn_s_memtime();                   \
   } while (0)
+#define P2M_TRW(w, ev)                                                                                \
+  do {                                                                                                \
+    if (trw_on && (w) < 40) g_tile_trw[threadIdx.x >> 6][w][ev] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
 #else
 #define P2M_TRC(role, w, ev) do { } while (0)
+#define P2M_TRW(w, ev) do { } while (0)
 #endif
 // TM x TN: MFMA tiles (samples x 32-column tiles) per consumer wave; NPW: producer waves (4: 256 registers per wave, for
 // the 128-register accumulator of N = 256; 8: two producer waves per SIMD cover each other's LDS latencies)
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
   const bool producer = t >= 256;             // wave-uniform
 #ifdef P2M_TILE_TRACE
   const bool trc_on = lid == P2M_TILE_TRACE && (t == 0 || t == 256);
+  const bool trw_on = lid == P2M_TILE_TRACE && (t & 63) == 0 && (t >> 6) < 12;
 #endif
   float x_sc = 1.f;                           // two-fp16-slice mode: the planes are staged times 2^sx
   int descale = 0;
@@ -599,6 +608,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     int grp = grp0, fc = 0;
     for (int w = 0; w < nunits; w++) {
       P2M_TRC(0, w, 0);
+      P2M_TRW(w, 0);
       u32x2 sp[NRP][3][NS];                             // [row][plane][slice]: the A operand of this unit, held until the
                                                         // MFMA waves release the image
       if (in_act) {                                     // plane 0 of unit w = (grp, fc)
@@ -653,6 +663,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
         split_pack4<NS>(t2[0], t2[1], t2[2], t2[3], x_sc, sp[ps][2]);
       }
       P2M_TRC(0, w, 1);
+      P2M_TRW(w, 1);
       lds_block_barrier();                              // B2(w): the MFMA waves are done with the image of unit w - 1,
                                                         //        every producer is done reading xs(w)
       P2M_TRC(0, w, 2);
@@ -746,6 +757,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, (4 + NPW) / 4) void k_cheb_tile_gem
     for (int w = 0; w < nunits; w++) {
       const int fcn = fc + 1 == nchunks ? 0 : fc + 1;
       P2M_TRC(1, w, 0);
+      P2M_TRW(w, 1);                                    // (the wave arrives at B2(w) with the k-steps of unit w - 1 behind it)
       lds_block_barrier();                              // B2(w)
       P2M_TRC(1, w, 1);
       if (LEPI && w > 0 && fc == 0) {                   // (grp was advanced by the epilogue of the unit before)
@@ -943,6 +955,8 @@ __global__ __launch_bounds__(768, 3) void k_cheb_tile_gemm_v2(TileGemmArgs g) {
   const bool producer = t >= 256;
 #ifdef P2M_TILE_TRACE
   const bool trc_on = lid == P2M_TILE_TRACE && (t == 0 || t == 256);
+  const bool trw_on = false;
+  (void)trw_on;
 #endif
   float x_sc = 1.f;
   int descale = 0;
@@ -1903,6 +1917,11 @@ extern "C" int p2m_cheb_tile_gemm(p2m_graph_t gh, int32_t plan, const float* X, 
 }
 
 #ifdef P2M_TILE_TRACE
+extern "C" int p2m_tile_trace_dump_waves(unsigned long long* out /* [12][40][2] host */) {
+  if (hipDeviceSynchronize() != hipSuccess) return P2M_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2m::g_tile_trw), sizeof(unsigned long long) * 12 * 40 * 2) == hipSuccess ? P2M_OK
+                                                                                                                   : P2M_ERR_HIP;
+}
 extern "C" int p2m_tile_trace_dump(unsigned long long* out /* [2][40][8] host */) {
   if (hipDeviceSynchronize() != hipSuccess) return P2M_ERR_HIP;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2m::g_tile_trc), sizeof(unsigned long long) * 2 * 40 * 8) == hipSuccess ? P2M_OK

@@ -39,7 +39,7 @@ assert rc == 0, rc
 p, m = buf[0].astype(np.int64), buf[1].astype(np.int64)
 nu = int((p[:, 0] > 0).sum())
 print(f"case level={lvl} Ka={Ka} N={N} plan={plan} form={form} arith={ops.GEMM_ARITH}: {nu} units traced")
-V2 = os.environ.get("P2M_TILE_V2", "1") != "0" and N <= 128 and ops.GEMM_ARITH == "bf16x3"
+V2 = os.environ.get("P2M_TILE_V2", "0") == "1" and N <= 128 and ops.GEMM_ARITH == "bf16x3"
 if V2:       # k_cheb_tile_gemm_v2 (round 6): stamps 0 head, 1 half 0 gathered, 2 past MID, 3 half 1 gathered, 4 past B2, 5 image stored, 6 past B1
     print("producer wave:  unit | gather + split h0 | wait MID | gather + split h1 | wait B2 | (copy-out of the closed group +) "
           "image store | wait B1 | unit total")
@@ -67,3 +67,16 @@ if nu > 2:
     print("   avg | " + " | ".join(f"{v / (nu - 2):7.0f}" for v in tot))
 print(f"(s_memtime ticks; first stamp of the two roles: producer {p[0, 0]}, MFMA {m[0, 0]}; block span "
       f"{int(max(p[nu - 1, 6], m[nu - 1, 4]) - min(p[0, 0], m[0, 0]))} ticks)")
+
+# per-wave arrival at B2 (round 6): which wave is the block waiting for?
+wbuf = np.zeros((12, 40, 2), dtype=np.uint64)
+if hasattr(lib, "p2m_tile_trace_dump_waves") and lib.p2m_tile_trace_dump_waves(wbuf.ctypes.data_as(ctypes.c_void_p)) == 0:
+    wv = wbuf.astype(np.int64)
+    print("arrival at B2(w), cycles after producer wave 4's unit head; waves 0-3 MFMA (k-steps of unit w - 1), 4-11 producers "
+          "(gather of unit w):")
+    for w in range(1, min(nu, 8)):
+        base = wv[4, w, 0]
+        print(f"   unit {w}: " + " ".join(f"{int(wv[k, w, 1] - base):6d}" for k in range(12)))
+    print("the producers' own gather time (arrival at B2 - their own unit head), waves 4-11:")
+    for w in range(1, min(nu, 8)):
+        print(f"   unit {w}: " + " ".join(f"{int(wv[k, w, 1] - wv[k, w, 0]):6d}" for k in range(4, 12)))
