@@ -42,4 +42,7 @@ P2M_GEMM_ARITH=bf16x3 PROBE_CASE=0,128,128,0 bash tools/rocprof_pmc.sh ${T}_pmc_
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_a "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_b "FETCH_SIZE GRBM_GUI_ACTIVE" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
 bash tools/rocprof_pmc.sh ${T}_pmc_basis_c "WRITE_SIZE GRBM_GUI_ACTIVE" python $R/tools/probes/basis_probe.py finest > /dev/null 2>&1
+# in-kernel phase / per-wave stamps of the tile kernel (probe build made by `bash tools/tile_trace.sh build` before the call)
+if [ -f pose2mesh_release_amd/lib/abl/libp2m_hip_TRACE.so ]; then bash tools/tile_trace.sh run > gpurun_out/${T}_tile_phase_trace.txt 2>&1; fi
+P2M_GEMM_ARITH=bf16x3 python tools/probes/tile_gemm_probe.py all > gpurun_out/${T}_probe_tile.txt 2>&1
 grep -h "gemm_planes_ws\|k_basis_tile\|k_cheb_tile_gemm" gpurun_out/${T}_pmc_*.csv | cut -c1-60,150-260
