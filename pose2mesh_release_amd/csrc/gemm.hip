@@ -363,16 +363,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_planes(GemmArgs g) {
 // in turn (a 4-wave form of the same kernel spent 24 % of a wave's phase in MFMAs).
 //   * producers: two register stages of lead (they hold no accumulators), loads unconditional in the steady state,
 //     LDS ring of two 16-wide chunks; during iteration kc they store chunk kc+1 and refill that stage with chunk kc+3;
-//   * one LDS-only block barrier per chunk.  2 blocks (16 waves) per CU, 74 KB of LDS each.
+//   * one LDS-only block barrier per chunk.  2 blocks (16 waves) per CU, 74 KB of LDS each (where the registers allow:
+//     see the launch bound below).
 // (Measured and removed in round 3: the 4-wave form, a 3-chunk ring with double-buffered fragments at 1 block per CU
 //  (-1.4 % on the step), the BatchNorm-backward reduction in this kernel's epilogue (its 4-byte strided reads of the
 //  layer's raw input cost the contraction +4.5 ms, the pass they replace 3.3 ms).)
 // ---------------------------------------------------------------------------------------------
 template <int BN, bool EXTRA, bool ROWS, int NS>
-__global__ __launch_bounds__(512, 2) void k_gemm_planes_ws(GemmArgs g) {
+// Round 6: the ROW-SET instantiations are held to 128 registers (launch bound 4 waves per SIMD = TWO blocks per CU, as this
+// header always assumed): hipcc gave the 128-wide ones 152-174 - one block per CU, one MFMA wave per SIMD and nothing to
+// cover its fragment reads and barriers.  At 128 the epilogue spills 28-46 dwords per lane (none in the k loop) and
+// k_gemm_planes_ws<128, true, true, 3> (the paired backward) runs 360 instead of 513 us, <128, false, true, 3> 94 instead of
+// 103 us; the plain-row ones measured 4 % slower that way and keep their bound (same-box rocprofv3 --stats, 9 steps).
+__global__ __launch_bounds__(512, (BN == 128 && ROWS) ? 4 : 2) void k_gemm_planes_ws(GemmArgs g) {
   constexpr int KB = 16;
   typedef typename SliceFrag<NS>::type frag_t;
-  constexpr int NBUF = 2, NST = 2;    // LDS ring of two chunks, two register stages of lead
+  constexpr int NBUF = 2, NST = 2;    // LDS ring of two chunks, two register stages of lead (three: no change, round 6)
   constexpr int AHEAD = NBUF - 1;     // the producers store chunk kc + AHEAD during iteration kc
   constexpr int WTN = BN / 2;
   constexpr int TN = WTN / 32;
