@@ -138,6 +138,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
           csum[j] += wst ? wtab[ml] * v : v;
           vmax = fmaxf(vmax, amax_abs(v));
         }
+        // (round 6) the row addresses of four accumulator registers at a time: left alone, the scheduler forms all 64 store
+        // addresses first - 150-170 registers for a kernel whose k loop needs 112, i.e. one block per CU instead of two
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       if (EXTRA && g.pair_out && Cq != nullptr) {   // rows (r, r+1), r even: the two children of one coarse vertex
 #pragma unroll
