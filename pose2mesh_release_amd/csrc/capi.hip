@@ -249,7 +249,7 @@ extern "C" int p2m_stream_capture_id(void* stream, unsigned long long* id_out) {
   return 0;
 }
 
-extern "C" const char* p2m_version(void) { return "p2m-hip 0.6 (gfx950; PoseNet stages, locality-ordered tiles; fp32 contractions as 2 scaled fp16 slices or 3 exact bf16 slices on the matrix pipe, or on the f32 MFMA; basis inside the contraction, paired operator, fake-row classes, activation on load)"; }
+extern "C" const char* p2m_version(void) { return "p2m-hip 0.7 (gfx950; PoseNet stages at any batch, locality-ordered tiles, two-barrier tile kernel, two-block plane contraction; fp32 contractions as 2 scaled fp16 slices or 3 exact bf16 slices on the matrix pipe, or on the f32 MFMA; basis inside the contraction, paired operator, fake-row classes, activation on load)"; }
 
 // Host-side bake: merged CSR of L and L2 = 2*L*L - I (double accumulation, one rounding to fp32).
 extern "C" int p2m_graph_create(const int32_t* row_ptr, const int32_t* col, const float* val, int32_t V, int32_t nnz,

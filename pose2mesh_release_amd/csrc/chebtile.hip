@@ -18,9 +18,10 @@
 //   waves 0..3  CONSUMERS   per chunk 6 k-steps of 16: A fragments from LDS (ds_read_b128, conflict-free: 208-byte rows),
 //               B fragments (the pre-split weight, p2m_weight_split layout) straight from L2 into registers one step
 //               ahead, 6 slice products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-//   Two LDS-only block barriers per chunk; the producers' gather / split of chunk c+1 runs under the MFMAs of chunk c.
-//   A block walks `gpb` sample groups of its tile (tables loaded once; the epilogue of group g overlaps the gather of
-//   group g+1's first chunk).
+//   Two LDS-only block barriers per chunk (round 6; three before): B2 - the image of the previous chunk is free and every
+//   producer is done with the union rows - and B1 - the image of this chunk and the union rows of the next are stored; the
+//   producers' gather / split of chunk c+1 runs under the MFMAs of chunk c.  A block walks `gpb` sample groups of its tile
+//   (tables loaded once); the tile rows are dealt to the producer waves by entry count (rowsel).
 //
 // HBM traffic per real row: the union rows once per tile (re-use across neighbouring tiles through L2, as in
 // k_basis_tile), plane 0 once (L2-warm: the row is in its own union), C once; optionally the two gathered planes
