@@ -359,6 +359,75 @@ def parity_check(step, n=4):
                     f"(this package, {ops.GEMM_ARITH}) vs the CPU oracle port of the reference path; untimed"}
 
 
+class PowerWatch:
+    """Samples the GPU's shader clock and package power (amdgpu hwmon in sysfs: freq1_input, power1_input, power1_cap)
+    every `period` seconds from a side thread while the timed steps run: two small file reads per sample, no
+    subprocess.  The MFMA kernels of this path run INTO the package power cap: the clock they
+    sustain, not the nominal 2.4 GHz, is what their pipe peak scales with."""
+
+    def __init__(self, device_index=0, period=0.02):
+        import glob
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+        dirs = []
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            dirs = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:  # noqa: BLE001  (older torch: no pci ids) -> the busiest card below
+            dirs = []
+        self.how = "hwmon of cuda device %d" % device_index if dirs else "hwmon of the card drawing the most power"
+        self.dirs = dirs or glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            best = None
+            for d in self.dirs:
+                pw = self._read(d + "/power1_input")
+                if pw is None:
+                    pw = self._read(d + "/power1_average")
+                ck = self._read(d + "/freq1_input")
+                if pw is not None and ck is not None and (best is None or pw > best[1]):
+                    best = (ck / 1e6, pw / 1e6, d)
+            if best is not None:
+                self.samples.append(best)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dirs:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+
+    def report(self):
+        if len(self.samples) < 3:
+            return None
+        s = self.samples[len(self.samples) // 5:]              # the first fifth: clocks still ramping
+        ck = np.asarray([x[0] for x in s])
+        pw = np.asarray([x[1] for x in s])
+        cap = self._read(s[-1][2] + "/power1_cap")
+        return {"sclk_mhz_median": round(float(np.median(ck)), 0), "sclk_mhz_min": round(float(ck.min()), 0),
+                "sclk_mhz_max": round(float(ck.max()), 0), "sclk_nominal_mhz": 2400,
+                "power_w_median": round(float(np.median(pw)), 0), "power_w_max": round(float(pw.max()), 0),
+                "power_cap_w": None if cap is None else round(cap / 1e6, 0), "samples": len(s), "source": self.how,
+                "note": "sampled every %d ms DURING the timed steps; every peak in the roofline objects is the guide's "
+                        "figure at the nominal 2.4 GHz - at the median clock here the matrix-pipe peaks are "
+                        "sclk_mhz_median / 2400 of that" % int(self.period * 1e3)}
+
+
 def timed_run(step, warmup, steps, barrier):
     """`warmup` untimed steps, then EXACTLY `steps` steps between two barrier + synchronize pairs -> (wall seconds,
     per-step milliseconds).  The timed region is clean: no per-launch events in it, only one HIP event per STEP on the
@@ -499,7 +568,8 @@ def main():
         step = p2m_train.GraphedTrainStep(eager_step.model, eager_step.opt, eager_step.loss_fn, warmup=2)
         args.warmup = max(args.warmup, 4)              # 2 eager steps, the capture, one replay before the clock starts
         graphed = True
-    dt, per_step_ms = timed_run(step, args.warmup, args.steps, barrier)
+    with PowerWatch(local) as pwatch:
+        dt, per_step_ms = timed_run(step, args.warmup, args.steps, barrier)
     ksteps = min(args.steps, 10)          # steps of the per-kernel timing pass (untimed; ~1 200 HIP events per step)
     if not args.no_kernel_timing:
         # per-kernel rooflines: the SAME steps once more, launch by launch, every launch bracketed by HIP events on its
@@ -657,6 +727,9 @@ def main():
                        **({"train_step": "one captured hipGraph (train.GraphedTrainStep); kernel timings from the same "
                                          "launches issued one by one after the timed region"} if train_graph else {})},
         }
+        pw = pwatch.report()
+        if pw is not None:
+            line["power"] = pw
         # "MFMA util = meshes/s * FLOPs / 157.3e12" over the WHOLE step (all kernels, not only GEMM time)
         gf = step.dense_gflop_fwd if infer else step.dense_gflop_fwd_bwd
         line["step_dense"] = {("gflop_per_mesh_fwd" if infer else "gflop_per_mesh_fwd_bwd"): round(gf, 2),

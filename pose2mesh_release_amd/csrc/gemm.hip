@@ -134,6 +134,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, floatx16 (&acc)
         if (EXTRA && g.addend != nullptr && rok && Cq != nullptr) v += g.addend[row * g.N + n];
         acc[i][j][r] = rok ? v : 0.f;
         if (!(EXTRA && g.pair_out) && rok && Cq != nullptr) {
+#ifdef P2M_PL_ABL_NOSTORE
+          if (v == 12345.678f)
+#endif
           Cq[row * g.Nc + c] = v;
           csum[j] += wst ? wtab[ml] * v : v;
           vmax = fmaxf(vmax, amax_abs(v));
@@ -497,7 +500,11 @@ __global__ __launch_bounds__(512, (BN == 128 && ROWS) ? 4 : 2) void k_gemm_plane
       const char* Ab = reinterpret_cast<const char*>(g.A[p] + (p == 0 ? sbase0 : sbase12) + k0);     // uniform
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++)
+#ifdef P2M_PL_ABL_NOLOAD
+        a[ps] = f32x4{__uint_as_float(voff0[ps]), 1.f, 2.f, (float)(long)Ab};
+#else
         a[ps] = *reinterpret_cast<const f32x4*>(Ab + (p == 0 ? voff0[ps] : voff12[ps]));
+#endif
       const char* src0 = reinterpret_cast<const char*>(g.Bx + (long)((p * g.Ka + k0) >> 4) * (NS * bx_slice));   // uniform
 #pragma unroll
       for (int sl = 0; sl < NS; sl++) b[sl] = *reinterpret_cast<const u32x4*>(src0 + sl * 2 * bx_slice + bx_voff);
@@ -518,7 +525,11 @@ __global__ __launch_bounds__(512, (BN == 128 && ROWS) ? 4 : 2) void k_gemm_plane
 #pragma unroll
       for (int ps = 0; ps < APASS; ps++) {
         u32x2 sl[NS];
+#ifdef P2M_PL_ABL_NOSLICE
+        for (int q = 0; q < NS; q++) sl[q] = u32x2{__float_as_uint(a[ps][q & 1]), __float_as_uint(a[ps][2 + (q & 1)])};
+#else
         split_pack4<NS>(a[ps][0], a[ps][1], a[ps][2], a[ps][3], a_sc, sl);
+#endif
         unsigned short* d = as + (ps * AROWS + a_row) * LDX + a_k4;
 #pragma unroll
         for (int q = 0; q < NS; q++) *reinterpret_cast<u32x2*>(d + q * BM * LDX) = sl[q];
@@ -578,6 +589,13 @@ __global__ __launch_bounds__(512, (BN == 128 && ROWS) ? 4 : 2) void k_gemm_plane
 #define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
       acc[i][j] = slice_mfma<NS>(a[SA][i], b[SB][j], acc[i][j]);
+#ifdef P2M_PL_ABL_NOMFMA
+      if constexpr (NS == 3) {
+        P2M_PAIR(0, 0)
+        for (int sl = 1; sl < NS; sl++)
+          for (int i = 0; i < TM; i++) for (int j = 0; j < TN; j++) { asm volatile("" :: "v"(a[sl][i])); asm volatile("" :: "v"(b[sl][j])); }
+      } else
+#endif
       if constexpr (NS == 3) {          // smallest products first
         P2M_PAIR(2, 0)
         P2M_PAIR(0, 2)
@@ -969,6 +987,23 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TnArgs g) {
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef P2M_TN_TRACE
+// Probe build only (tools/tn_trace.sh, tools/probes/tn_trace_probe.py): s_memtime stamps of every wave of one block at the
+// phase boundaries of 32 steady-state stages.  [wave][stage - P2M_TN_TRACE_S0][event]; events: 0 past the barrier,
+// 1 operands there (staging: global loads landed; MFMA: fragments read), 2 work issued (LDS stores / last MFMA), 3 at the barrier
+__device__ unsigned long long g_tn_tr[8][32][4];
+#ifndef P2M_TN_TRACE_S0
+#define P2M_TN_TRACE_S0 40
+#endif
+#define P2M_TNT(s, ev)                                                                                          \
+  do {                                                                                                          \
+    if (tnt_on && (s) >= P2M_TN_TRACE_S0 && (s) < P2M_TN_TRACE_S0 + 32)                                         \
+      g_tn_tr[threadIdx.x >> 6][(s) - P2M_TN_TRACE_S0][ev] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define P2M_TNT(s, ev) do { } while (0)
+#endif
+
 // Wave-specialised (4 MFMA waves + 4 staging waves, one LDS-only barrier per 16-row stage, two register stages of lead);
 // see k_gemm_planes_ws.
 template <int BN, bool ROWS, int NS>
@@ -1013,6 +1048,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 
   const int t = threadIdx.x;
   const bool producer = t >= 256;          // waves 4..7 stage, waves 0..3 run the MFMAs (k_gemm_planes_ws)
+#ifdef P2M_TN_TRACE
+  const bool tnt_on = blockIdx.x == P2M_TN_TRACE && (t & 63) == 0 && BN == 128 && ROWS;
+#endif
   const int pt = t & 255;
   const int lane = t & 63, wave = (t >> 6) & 3;
   const int wm = wave >> 1, wn = wave & 1;
@@ -1104,7 +1142,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       if (CLAMP && rel > nrows_m1) rel = nrows_m1;
       if (ROWS && !compact_rows) rel = id[ps];             // vertex id inside the sample (slack entries: vertex 0)
       const unsigned off = __umul24((unsigned)(rel >> shift), pitch4);
+#ifdef P2M_TN_ABL_NOLOAD
+      x[ps] = f32x4{__uint_as_float(off), 1.f, 2.f, 3.f};
+#else                                   // (non-temporal loads - `nt` - of G, or of both operands: +6.5 % / +5 %, round 6)
       x[ps] = *reinterpret_cast<const f32x4*>(srcb + off);
+#endif
     }
   };
   // TAIL = true: rows past the end of the chunk are zeroed before they are used
@@ -1112,6 +1154,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) asm volatile("" : "+v"(x[ps]));     // see k_gemm_planes_bx
+    P2M_TNT(kc, 1);
     if (a_act) {                                                        // (before the tail's zeroing: act(0) != 0)
 #pragma unroll
       for (int ps = 0; ps < 4; ps++)
@@ -1132,7 +1175,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       u32x2 sl[NS];
+#ifdef P2M_TN_ABL_NOSLICE
+      for (int q = 0; q < NS; q++) sl[q] = u32x2{__float_as_uint(x[q & 1][e]), __float_as_uint(x[2 + (q & 1)][e])};
+#else
       split_pack4<NS>(x[0][e], x[1][e], x[2][e], x[3][e], my_sc, sl);
+#endif
       // LDS rows are PERMUTED inside every block of 16: column 4 c + e of the block lives in row 2 c + (e & 1) + 8 (e >> 1).
       // The 16 lanes of a ds_write_b64 group are 4 column quads x 4 row quads: with the natural order their rows are 4
       // apart = 48 dwords = 16 banks, i.e. 2-way conflicts on every store (PMC: 33 % of the kernel's LDS cycles); rows
@@ -1141,10 +1188,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       for (int q = 0; q < NS; q++)
         *reinterpret_cast<u32x2*>(d + ((e & 1) + 8 * (e >> 1)) * LDX + q * slice_stride) = sl[q];
     }
+    P2M_TNT(kc, 2);
   };
   using std::false_type;
   using std::true_type;
-  auto compute = [&](int cur) {
+  auto compute = [&](int cur, int kc) {
     // (row permutation of the staging stores: logical row j of a 16-block -> 2 (j >> 2) + (j & 1) + 8 ((j & 3) >> 1))
     const int lrow = (l31 & 16) + 2 * ((l31 & 15) >> 2) + (l31 & 1) + 8 * ((l31 & 3) >> 1);
     const unsigned short* as = As + cur * A_BUF + (wm * 64 + lrow) * LDX + lhi * 8;
@@ -1159,9 +1207,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       for (int j = 0; j < TN; j++)
         fb[sl][j] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(gs + (sl * BN + j * 32) * LDX));
     }
+#ifdef P2M_TN_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P2M_TNT(kc, 1);
+#endif
 #define P2M_PAIR(SA, SB)                                                                       \
   _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) \
       acc[i][j] = slice_mfma<NS>(fa[SA][i], fb[SB][j], acc[i][j]);
+#ifdef P2M_TN_ABL_NOMFMA
+    if constexpr (NS == 3) {
+      P2M_PAIR(0, 0)
+      for (int sl = 1; sl < NS; sl++)
+        for (int i = 0; i < TM; i++) for (int j = 0; j < TN; j++) { asm volatile("" :: "v"(fa[sl][i])); asm volatile("" :: "v"(fb[sl][j])); }
+    } else
+#endif
     if constexpr (NS == 3) {            // smallest products first
       P2M_PAIR(2, 0)
       P2M_PAIR(0, 2)
@@ -1175,6 +1234,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       P2M_PAIR(0, 0)
     }
 #undef P2M_PAIR
+    P2M_TNT(kc, 2);
+    (void)kc;
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -1196,13 +1257,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
       // steady state: stages up to kc+4 are FULL stages (the possibly partial last stage nst-1 is left to the tail), so
       // neither the loads nor the stores carry clamps, zeroing or conditions
       for (; kc + 5 < nst; kc += 2) {
+        P2M_TNT(kc + 1, 0);
         store_stage(1, kc + 1, x1, false_type{});
         load_stage(kc + 3, x1, id1, false_type{});
         load_ids(kc + 5, id1);
+        P2M_TNT(kc + 1, 3);
         lds_barrier();
+        P2M_TNT(kc + 2, 0);
         store_stage(0, kc + 2, x0, false_type{});
         load_stage(kc + 4, x0, id0, false_type{});
         load_ids(kc + 6, id0);
+        P2M_TNT(kc + 2, 3);
         lds_barrier();
       }
       for (; kc < nst; kc += 2) {                // tail: same rotation, range-checked
@@ -1224,7 +1289,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
     } else {
       lds_barrier();                             // stage 0 is in LDS
       for (int kc = 0; kc < nst; kc++) {
-        compute(kc & 1);
+        P2M_TNT(kc, 0);
+        compute(kc & 1, kc);
+        P2M_TNT(kc, 3);
         lds_barrier();
       }
     }
@@ -1942,3 +2009,11 @@ extern "C" int p2m_weight_grad_unpack(const float* P, const float* Pdb, int32_t 
                      dW, db, Fout, Fin, K, accumulate, layout, pdb_stride, nullptr, nullptr, 0, 0.f, 0.f);
   return check_launch("weight_grad_unpack");
 }
+
+#ifdef P2M_TN_TRACE
+extern "C" int p2m_tn_trace_dump(unsigned long long* out /* [8][32][4] host */) {
+  if (hipDeviceSynchronize() != hipSuccess) return P2M_ERR_HIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2m::g_tn_tr), sizeof(unsigned long long) * 8 * 32 * 4) == hipSuccess ? P2M_OK
+                                                                                                                : P2M_ERR_HIP;
+}
+#endif

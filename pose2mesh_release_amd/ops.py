@@ -902,7 +902,9 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 
 
 # blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,
-# 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce)
+# 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce).  Round 6: 1536 blocks (three full
+# rounds of the 512 slots) instead of 768 (one and a half) for the finest level's gradients: 8.44 vs 8.45-8.52 ms over the
+# step's shapes, the step 43.2 vs 43.0 ms - the kernel runs into the package power cap, not out of blocks
 TN_TARGET_BLOCKS = 768
 
 

@@ -226,3 +226,28 @@ def test_bench_gpus_n_without_launcher_starts_n_ranks():
     assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_power_watch_reads_hwmon_files(tmp_path):
+    """bench.PowerWatch over a fake amdgpu hwmon directory: the medians of what the files held while it ran, the cap, and no
+    `power` object at all when nothing could be sampled (a box without the files must not break the bench line)."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    d = tmp_path / "hwmon0"
+    d.mkdir()
+    (d / "freq1_input").write_text("2100000000\n")
+    (d / "power1_input").write_text("1197000000\n")
+    (d / "power1_cap").write_text("1400000000\n")
+    w = bench.PowerWatch(0, period=0.002)
+    w.dirs, w.how = [str(d)], "test"
+    with w:
+        time.sleep(0.1)
+    r = w.report()
+    assert r["sclk_mhz_median"] == 2100 and r["power_w_median"] == 1197 and r["power_cap_w"] == 1400 and r["samples"] >= 3
+    empty = bench.PowerWatch(0, period=0.002)
+    empty.dirs = [str(tmp_path / "missing")]
+    with empty:
+        time.sleep(0.02)
+    assert empty.report() is None
