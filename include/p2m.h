@@ -312,7 +312,9 @@ int32_t p2m_rows_tiles_per_sample(p2m_graph_t g, int32_t row_set);
 /* P[b*splits + s][k][n] = sum over the s-th slice of the row set of sample b of A[row][k] * G[row][n]
  * (G0 at the actual row, G1/G2 compact when planes_compact); Pdb likewise.  a_scale / a_shift [Ka] (optional, slice
  * arithmetics only): activation on load of A, as in p2m_cheb_tile_gemm - A holds the raw conv output y and the operand is
- * max(fma(y, a_scale[k], a_shift[k]), 0); a_amax then bounds that (p2m_act_bound).                                  */
+ * max(fma(y, a_scale[k], a_shift[k]), 0); a_amax then bounds that (p2m_act_bound).
+ * splits <= -2 (round 6; slice arithmetics only): a chunk is -splits consecutive WHOLE samples instead of a slice of one -
+ * P[c] (c < ceil(B / -splits)) sums the row sets of samples c * -splits ... : fewer partials where a sample has few rows.  */
 int p2m_gemm_tn_rows(p2m_graph_t g, int32_t row_set, int32_t B, const float* A, int32_t Ka, int32_t a0_shift,
                      const float* G0, const float* G1, const float* G2, int32_t nplanesG, int32_t Gc,
                      int32_t planes_compact, int32_t splits, float* P, float* Pdb, int32_t arith,

@@ -802,6 +802,9 @@ struct TnArgs {
   // b*V + ids[i], G planes 1,2 at the compact row b*nset + i when `compact`
   const int* ids;
   int nset, V, splits, compact;
+  // k_gemm_tn_ws, row-set mode, splits = 1: a chunk is `spc` consecutive WHOLE samples (the last chunk: what is left of the B
+  // samples) - fewer partials for the unpack to read where a sample has few rows and the gradient many tiles
+  int spc = 1, B = 0;
   // two-fp16-slice mode: amax words of the A planes and of the G planes (+ binades of headroom), p2m_split.h
   const unsigned* a_amax;
   const unsigned* g_amax;
@@ -1040,8 +1043,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   if (chunk >= g.nchunks) return;
   const int kt = tile / g.ntn, nt = tile % g.ntn;
   const int kk0 = kt * BM, n0 = nt * BN;
-  const int rs_b = ROWS ? chunk / g.splits : 0;
-  const long r_begin = ROWS ? (long)(chunk - rs_b * g.splits) * g.chunk_rows : (long)chunk * g.chunk_rows;
+  const int spc = ROWS ? g.spc : 1;
+  const int rs_b = ROWS ? (spc > 1 ? chunk * spc : chunk / g.splits) : 0;      // (first) sample of this chunk
+  const int nsamp = (ROWS && spc > 1) ? (g.B - rs_b < spc ? g.B - rs_b : spc) : 1;
+  const long r_begin = ROWS ? (spc > 1 ? 0L : (long)(chunk - rs_b * g.splits) * g.chunk_rows) : (long)chunk * g.chunk_rows;
   long r_end = r_begin + g.chunk_rows;
   if (r_end > (ROWS ? (long)g.nset : g.M)) r_end = ROWS ? (long)g.nset : g.M;
   const int nst = r_end > r_begin ? (int)((r_end - r_begin + RK - 1) / RK) : 0;
@@ -1123,6 +1128,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   // (V is even whenever shift = 1; chunk_rows is a multiple of 16), so (base + rel) >> shift == (base >> shift) + (rel >> shift).
   const long base_row = ROWS ? (compact_rows ? (long)rs_b * g.nset + r_begin : (long)rs_b * g.V) : r_begin;
   const char* srcb = reinterpret_cast<const char*>(src + (base_row >> shift) * pitch);
+  const long samp_bytes = ROWS ? (((long)(compact_rows ? g.nset : g.V) >> shift) * pitch) * 4 : 0;   // sample to sample
   const unsigned pitch4 = (unsigned)pitch * 4u;
   const int nrows_m1 = (int)(r_end - r_begin) - 1;
 
@@ -1239,6 +1245,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+  for (int sb = 0; sb < nsamp; sb++) {      // (one pass unless the chunk is several whole samples: same stages, next sample)
   if (nst > 0) {
     if (producer) {
       // stage s lives in register set s & 1 and LDS buffer s & 1; ids of stage s in id set s & 1.  During iteration
@@ -1295,6 +1302,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_ws(TnArgs g) {
         lds_barrier();
       }
     }
+  }
+  srcb += samp_bytes;
   }
   __syncthreads();
 
@@ -1929,7 +1938,9 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   P2M_CHECK_ARG(arith == P2M_ARITH_F32 || arith == P2M_ARITH_BF16X3 || arith == P2M_ARITH_F16X2, "unknown arithmetic");
   P2M_CHECK_ARG(arith != P2M_ARITH_F16X2 || (a_amax && g_amax), "P2M_ARITH_F16X2 needs the amax words of both operands");
   P2M_CHECK_ARG(row_set_valid(row_set), "row_set must be 1 (real), 2 (fake), 3 (paired real) or 4 (paired fake)");
-  P2M_CHECK_ARG(nplanesG >= 1 && nplanesG <= 3 && splits >= 1, "plane count must be 1..3, splits >= 1");
+  P2M_CHECK_ARG(nplanesG >= 1 && nplanesG <= 3 && (splits >= 1 || splits <= -2),
+                "plane count must be 1..3; splits >= 1, or <= -2 (that many whole samples per chunk)");
+  P2M_CHECK_ARG(splits >= 1 || arith != P2M_ARITH_F32, "several samples per chunk exist in the slice arithmetics only");
   P2M_CHECK_ARG(Ka % 32 == 0 && Gc % 32 == 0, "Ka and Gc must be multiples of 32");
   P2M_CHECK_ARG(a0_shift == 0 || a0_shift == 1, "a0_shift must be 0 or 1");
   const Graph& gr = *reinterpret_cast<const Graph*>(gh);
@@ -1941,13 +1952,16 @@ extern "C" int p2m_gemm_tn_rows(p2m_graph_t gh, int32_t row_set, int32_t B, cons
   for (int p = 0; p < nplanesG; p++) P2M_CHECK_ARG(g.G[p] != nullptr, "missing G plane");
   const int N = nplanesG * Gc;
   g.P = P; g.Pdb = Pdb; g.M = (long)B * rs.n;
+  const int spc = splits < 0 ? -splits : 1;
+  if (splits < 0) splits = 1;
   g.chunk_rows = cdiv(rs.n, splits);
   g.nplanesA = 1; g.Ka = Ka; g.a0_shift = a0_shift; g.Ktot = Ka; g.N = N;
   g.ids = rs.ids; g.nset = rs.n; g.V = rs.V; g.splits = splits; g.compact = planes_compact;
+  g.spc = spc; g.B = B;
   g.a_amax = static_cast<const unsigned*>(a_amax); g.g_amax = static_cast<const unsigned*>(g_amax);
   g.a_bits = 0; g.g_bits = g_bits;
   g.a_scale = a_scale; g.a_shift = a_shift;
-  const int nchunks = B * splits;
+  const int nchunks = spc > 1 ? cdiv(B, spc) : B * splits;
   g.nchunks = nchunks;
   hipStream_t s = (hipStream_t)stream;
   g.nkt = cdiv(g.Ktot, BM);

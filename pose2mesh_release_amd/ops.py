@@ -901,17 +901,27 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
     return T1c, T2c, st1, st2, False
 
 
-# blocks a weight-gradient launch should have at least (512 block slots: 2 per CU).  Measured: 768 -> 4112 meshes/s,
-# 1536 -> 4066, 2560 -> 4008, 4096 -> 3698 (more partial buffers for the unpack to reduce).  Round 6: 1536 blocks (three full
-# rounds of the 512 slots) instead of 768 (one and a half) for the finest level's gradients: 8.44 vs 8.45-8.52 ms over the
-# step's shapes, the step 43.2 vs 43.0 ms - the kernel runs into the package power cap, not out of blocks
-TN_TARGET_BLOCKS = 768
+# Blocks a weight-gradient launch should have at least (512 block slots: 2 per CU), and the row-set policy that follows from it:
+# a launch whose one-chunk-per-sample form has >= 2 TN_TARGET_BLOCKS blocks takes floor(blocks / TN_TARGET_BLOCKS) WHOLE samples
+# per chunk (include/p2m.h, p2m_gemm_tn_rows with splits < 0).  Every chunk costs a partial buffer P[chunk][Ka][N] that the
+# contraction writes and the unpack reads: at one chunk per sample the 256 x 768 gradients of the levels with 544 - 1 021 rows per
+# sample moved 0.4 - 0.7 of their operand bytes again as partials.  Round 6, same box, bf16x3 step: one chunk per sample at
+# 768 blocks 43.49 ms; whole samples per chunk at 768: 43.05; at 512: 42.28 (42.10); at 384: **42.00 (41.70)**; at 320 / 256:
+# 42.0 / 42.08 (`profiles/r06_tn_samples_per_chunk_ab.txt`).  The kernel ALONE is slower with fewer blocks (weight gradients
+# of the step's shapes 8.67 ms at 768, 9.72 at 384, 12.97 at 256): in the step it shares the GPU with the main stream's
+# kernels and the package power cap with everything, and what counts there is bytes and co-residency, not
+# its own critical path.  Earlier rounds (one chunk per sample, other kernels): 768 -> 4112 meshes/s, 1536 -> 4066, 2560 -> 4008,
+# 4096 -> 3698; round 6: 1536 blocks (three full rounds of the slots) instead of 768 at the finest level 8.44 vs 8.45-8.52 ms.
+TN_TARGET_BLOCKS = int(_os.environ.get("P2M_TN_TARGET_BLOCKS", "384"))
+TN_SAMPLES_PER_CHUNK = _os.environ.get("P2M_TN_SPC", "1") == "1"       # 0: one chunk per sample (or less), the A/B form
 
 
-def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_amax=None, g_bits=0, a_act=None):
-    """Weight-gradient partials over a row set: returns (P[B*splits, Ka, len(G)*Gc], Pdb, nchunks).  f16x2: the amax
+def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_amax=None, g_bits=0, a_act=None,
+                 samples_per_chunk=None):
+    """Weight-gradient partials over a row set: returns (P[nchunks, Ka, len(G)*Gc], Pdb, nchunks).  f16x2: the amax
     words of A and of the G planes (after g_bits binades); default: the tensors' own.  a_act = (scale[Ka], shift[Ka]):
-    activation on load of A (a raw conv output); a_amax must then bound the activated operand."""
+    activation on load of A (a raw conv output); a_amax must then bound the activated operand.  samples_per_chunk: whole
+    samples per chunk (>= 2, slice arithmetics; default: the policy at TN_SAMPLES_PER_CHUNK)."""
     n = g.set_size(row_set)
     if a_act is not None and a_amax is None and f16x2():
         raise P2MError("gemm_tn_rows: activation on load needs the amax word of the activated operand (act_bound)")
@@ -924,6 +934,11 @@ def gemm_tn_rows(g, row_set, B, A, Ka, a0_shift, G, Gc, compact, a_amax=None, g_
     ntiles = ((Ka + 127) // 128) * ((N + 127) // 128)
     splits = max(1, -(-TN_TARGET_BLOCKS // (B * ntiles)))
     nch = B * splits
+    spc = (B * ntiles) // TN_TARGET_BLOCKS if (TN_SAMPLES_PER_CHUNK and GEMM_ARITH != "f32") else 1
+    if samples_per_chunk is not None:
+        spc = int(samples_per_chunk)
+    if spc >= 2:                    # many tiles, few rows per sample: several whole samples per chunk (include/p2m.h)
+        splits, nch = -spc, -(-B // spc)
     P = torch.empty((nch, Ka, N), device=A.device, dtype=torch.float32)
     Pdb = torch.empty((nch, N), device=A.device, dtype=torch.float32)
     gp = [_p(_req(t, "G plane")) for t in G] + [None] * (3 - len(G))

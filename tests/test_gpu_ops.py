@@ -279,6 +279,39 @@ def test_fake_vertex_split_matches_unsplit(ops, arith):
     assert (db - dbref).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+def test_weight_gradient_chunks_of_whole_samples(ops, monkeypatch, arith):
+    """p2m_gemm_tn_rows with splits = -S (S whole samples per chunk, the last chunk short): fewer partial buffers, the same
+    gradient - against the one-chunk-per-sample form (sums in a different order: fp32 round-off) and against float64."""
+    monkeypatch.setattr(ops, "GEMM_ARITH", arith)
+    V, Fin, Fout, B = 736, 128, 64, 7
+    L = _rand_graph(V, 11, fake_frac=0.4)
+    g = ops.DeviceGraph(L, "cuda:0")
+    gen = torch.Generator().manual_seed(9)
+    X = torch.randn(B * V, Fin, generator=gen).cuda()
+    gy = torch.randn(B * V, Fout, generator=gen).cuda()
+    E1c, E2c = ops.cheb_basis_fwd_real(g, gy, B, Fout, 0)
+    P1, Pb1, n1 = ops.gemm_tn_rows(g, 1, B, X, Fin, 0, [gy, E1c, E2c], Fout, True, samples_per_chunk=1)
+    assert n1 % B == 0                      # (few samples: every sample's rows in n1 / B slices)
+    P1 = P1.view(B, n1 // B, Fin, 3 * Fout).sum(1)
+    Pb1 = Pb1.view(B, n1 // B, 3 * Fout).sum(1)
+    for S in (2, 3, 7, 9):
+        P, Pb, n = ops.gemm_tn_rows(g, 1, B, X, Fin, 0, [gy, E1c, E2c], Fout, True, samples_per_chunk=S)
+        assert n == -(-B // S) and P.shape == (n, Fin, 3 * Fout)
+        assert torch.isfinite(P).all()
+        scale = max(1.0, P1.sum(0).abs().max().item())
+        assert (P.sum(0) - P1.sum(0)).abs().max() < 2e-5 * scale, S
+        assert (Pb.sum(0) - Pb1.sum(0)).abs().max() < 1e-4 * max(1.0, Pb1.sum(0).abs().max().item())
+        # chunk c holds samples c*S ..: its partial is the sum of those samples' one-chunk partials
+        for c in range(n):
+            ref = P1[c * S:(c + 1) * S].sum(0)
+            assert (P[c] - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (S, c)
+    # the fake rows' gradient (one plane), several samples per chunk
+    Q1, Qb1, m1 = ops.gemm_tn_rows(g, 2, B, X, Fin, 0, [gy], Fout, False, samples_per_chunk=1)
+    Q, Qb, m = ops.gemm_tn_rows(g, 2, B, X, Fin, 0, [gy], Fout, False, samples_per_chunk=4)
+    assert m == 2 and (Q.sum(0) - Q1.sum(0)).abs().max() < 2e-5 * max(1.0, Q1.sum(0).abs().max().item())
+
+
 def _bf16_bits_to_float(t):
     return (t.to(torch.int32) << 16).view(torch.float32)
 
