@@ -919,6 +919,14 @@ def test_activation_on_load_is_bitwise_the_separate_pass(ops, monkeypatch, slice
                                 g_bits=g.plane_bits, a_act=(co[2], co[3]))
     torch.cuda.synchronize()
     assert n == n_ref and torch.equal(P, P_ref) and torch.equal(Pb, Pb_ref)
+    if B >= 2:                       # ... and with two whole samples per chunk (round 6: the policy of the large batches)
+        Ps_ref, Pbs_ref, ns_ref = ops.gemm_tn_rows(g, 1, B, x, Fin, 0, [gy, E1, E2], Fout, True, a_amax=word, g_amax=ga,
+                                                   g_bits=g.plane_bits, samples_per_chunk=2)
+        Ps, Pbs, ns = ops.gemm_tn_rows(g, 1, B, y, Fin, 0, [gy, E1, E2], Fout, True, a_amax=word, g_amax=ga,
+                                       g_bits=g.plane_bits, a_act=(co[2], co[3]), samples_per_chunk=2)
+        torch.cuda.synchronize()
+        assert ns == ns_ref == -(-B // 2) and torch.equal(Ps, Ps_ref) and torch.equal(Pbs, Pbs_ref)
+        assert (Ps.sum(0) - P.sum(0)).abs().max() < 2e-5 * max(1.0, P.sum(0).abs().max().item())
     # the two-kernel form (LDS-staged basis kernel + plane contraction, what the N = 256 levels run) and the fake-row /
     # narrow-projection contractions: planes and C bitwise those on the materialised x
     T1r, T2r = ops.cheb_basis_fwd_real(g, x, B, Fin, 0)
