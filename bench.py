@@ -833,6 +833,12 @@ def main():
                                 merged_serial("cheb_tile_gemm", "cheb_tile_gemm_bwd")),
             }
             fams = {k: v for k, v in fams.items() if v is not None}
+            if pw is not None and pw["sclk_mhz_median"] > 0:
+                # the same fraction against the pipe peak AT THE CLOCK THE STEP RAN AT (`power`): the package power cap, not
+                # the pipe, is what these kernels run into; `frac` stays the nominal-clock figure
+                for v in fams.values():
+                    if v.get("bound") == "mfma":
+                        v["frac_at_step_sclk"] = round(v["frac"] * pw["sclk_nominal_mhz"] / pw["sclk_mhz_median"], 4)
             if fams:
                 top = max(fams, key=lambda k: fams[k]["ms_per_step"])
                 line["roofline"] = dict(fams[top], family=top)

@@ -906,13 +906,17 @@ def conv_split(g, B, X, Ka, a0_shift, Bm, bias, addend, C, N, fake_a, fake_b, st
 # per chunk (include/p2m.h, p2m_gemm_tn_rows with splits < 0).  Every chunk costs a partial buffer P[chunk][Ka][N] that the
 # contraction writes and the unpack reads: at one chunk per sample the 256 x 768 gradients of the levels with 544 - 1 021 rows per
 # sample moved 0.4 - 0.7 of their operand bytes again as partials.  Round 6, same box, bf16x3 step: one chunk per sample at
-# 768 blocks 43.49 ms; whole samples per chunk at 768: 43.05; at 512: 42.28 (42.10); at 384: **42.00 (41.70)**; at 320 / 256:
+# 768 blocks 43.49 ms; whole samples per chunk at 768: 43.05; at 512: 42.28 (42.10); at 384: 42.00 (41.70); at 320 / 256:
 # 42.0 / 42.08 (`profiles/r06_tn_samples_per_chunk_ab.txt`).  The kernel ALONE is slower with fewer blocks (weight gradients
 # of the step's shapes 8.67 ms at 768, 9.72 at 384, 12.97 at 256): in the step it shares the GPU with the main stream's
 # kernels and the package power cap with everything, and what counts there is bytes and co-residency, not
 # its own critical path.  Earlier rounds (one chunk per sample, other kernels): 768 -> 4112 meshes/s, 1536 -> 4066, 2560 -> 4008,
 # 4096 -> 3698; round 6: 1536 blocks (three full rounds of the slots) instead of 768 at the finest level 8.44 vs 8.45-8.52 ms.
-TN_TARGET_BLOCKS = int(_os.environ.get("P2M_TN_TARGET_BLOCKS", "384"))
+# Later the same day, two more boxes: 384 -> 41.60-41.65, 256 -> 41.72, 224 / 208 -> 41.8-41.96 (3 samples per chunk: 86 chunks,
+# the last one short), **192 -> 40.98-41.03** (4 samples per chunk at the finest levels, 8 / 16 below: 192 blocks everywhere),
+# 176 -> 41.16, 160 -> 41.40, 150 -> 41.8, 128 -> 42.6; with the kernel held to ONE block per CU (16 KB more LDS): 192 -> 41.3-41.4,
+# 128 / 96 -> 42.6-42.9 (`profiles/r06_tn_target_blocks_sweep.txt`).
+TN_TARGET_BLOCKS = int(_os.environ.get("P2M_TN_TARGET_BLOCKS", "192"))
 TN_SAMPLES_PER_CHUNK = _os.environ.get("P2M_TN_SPC", "1") == "1"       # 0: one chunk per sample (or less), the A/B form
 
 
