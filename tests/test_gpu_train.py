@@ -370,3 +370,39 @@ def test_graph_replays_without_host_sync_keep_their_own_step_scalars(hip_libs):
         finals.append((opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+def test_bench_line_carries_the_contract_keys(hip_libs):
+    """`python bench.py` at a small batch, as the driver runs it for N = 1: ONE JSON line with the contract's keys, the
+    roofline object of the dominant kernel family (live HIP-event timing; PMC traffic with its code id and staleness flag), the
+    untimed parity check against the CPU oracle, the CPU baseline object and - where the amdgpu hwmon files exist - the
+    shader clock / package power sampled during the timed steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "2", "--batch", "32", "--also", "none",
+                        "--no-arith-ab", "--cpu-seconds", "2"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["unit"] == "meshes/s" and d["value"] > 0
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "traffic_code_id", "code_id"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert d["parity_check"]["ok"] and d["parity_check"]["max_vertex_l2_m"] <= 1e-4
+    if "power" in d:               # (no hwmon files: the key is absent, never a guess)
+        pw = d["power"]
+        assert 100 <= pw["sclk_mhz_median"] <= 3000 and 50 <= pw["power_w_median"] <= 2000 and pw["samples"] >= 3
+        if rf["bound"] == "mfma":
+            assert abs(rf["frac_at_step_sclk"] - rf["frac"] * 2400 / pw["sclk_mhz_median"]) < 1e-3
